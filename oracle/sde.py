@@ -1,0 +1,62 @@
+"""Oracle restatement of the perturbation kernels the hot path uses.
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.
+"""
+import math
+import torch
+
+
+class VESDE:
+    """Variance-exploding SDE, /root/reference/sde_lib.py:316-347.
+
+    Only ``marginal_prob`` is on the hot path: mean = x,
+    std = sigma_min * (sigma_max / sigma_min) ** t, computed in t's dtype.
+    """
+
+    def __init__(self, sigma_min=0.01, sigma_max=50, N=1000):
+        self.sigma_min, self.sigma_max, self.N = sigma_min, sigma_max, N
+
+    def marginal_prob(self, x, t):
+        lo = torch.tensor(self.sigma_min).type_as(t)
+        hi = torch.tensor(self.sigma_max).type_as(t)
+        return x, lo * (hi / lo) ** t
+
+
+class VPSDE:
+    """Variance-preserving SDE, /root/reference/sde_lib.py:222-252 (marginal_prob only)."""
+
+    def __init__(self, beta_min=0.1, beta_max=20., N=1000):
+        self.beta_0, self.beta_1, self.N = beta_min, beta_max, N
+
+    def marginal_prob(self, x, t):
+        log_coeff = -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        mean = torch.exp(log_coeff).reshape((-1,) + (1,) * (x.ndim - 1)) * x
+        return mean, torch.sqrt(1. - torch.exp(2. * log_coeff))
+
+
+def make_sde(config):
+    """(sde, sampling_eps) as /root/reference/lightning_modules/BaseSdeGenerativeModel.py:27-47."""
+    kind = config.training.sde.lower()
+    if kind == "vesde":
+        return VESDE(config.model.sigma_min, config.model.sigma_max, config.model.num_scales), 1e-5
+    if kind == "vpsde":
+        return VPSDE(config.model.beta_min, config.model.beta_max, config.model.num_scales), 1e-3
+    raise NotImplementedError(f"SDE {config.training.sde} is not on the manifold_dimension path")
+
+
+def get_score_fn(sde, model, conditional=False, train=False, continuous=True):
+    """Unconditional branch of /root/reference/models/utils.py:238-268.
+
+    labels = t*(N-1); out = model.eval()(x, labels); std = marginal_prob(0,t)[1];
+    score = -out/std (VE and VP continuous alike).
+    """
+    if conditional or not continuous:
+        raise NotImplementedError("only the unconditional continuous branch is on the hot path")
+
+    def score_fn(x, t):
+        model.eval()
+        out = model(x, t * (sde.N - 1))
+        std = sde.marginal_prob(torch.zeros_like(x), t)[1]
+        return -out / std.reshape((-1,) + (1,) * (x.ndim - 1))
+
+    return score_fn

@@ -1,0 +1,57 @@
+"""Shared helpers for the test-suite (config builders mirroring tests/golden/make_golden.py)."""
+import ast
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import id_diff_amd  # noqa: E402
+from id_diff_amd.configs.config_dict import ConfigDict  # noqa: E402
+
+
+def fcn_config(hidden_nodes=2048, hidden_layers=5, state_size=100):
+    c = ConfigDict()
+    c.model = ConfigDict(name="fcn", state_size=state_size, hidden_layers=hidden_layers,
+                         hidden_nodes=hidden_nodes, dropout=0.0, sigma_min=1e-2, sigma_max=4,
+                         num_scales=1000)
+    c.training = ConfigDict(sde="vesde", continuous=True, batch_size=500)
+    c.data = ConfigDict(shape=[state_size])
+    return c
+
+
+def ncsnpp_config(**over):
+    c = ConfigDict()
+    c.data = ConfigDict(image_size=32, effective_image_size=32, num_channels=3, centered=False,
+                        shape=[3, 32, 32])
+    c.training = ConfigDict(continuous=True, sde="vesde", batch_size=128)
+    c.model = ConfigDict(
+        name="ncsnpp", nf=8, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,),
+        dropout=0.1, resamp_with_conv=True, conditional=True, fir=True, fir_kernel=[1, 3, 3, 1],
+        skip_rescale=True, resblock_type="biggan", progressive="none", progressive_input="residual",
+        progressive_combine="sum", embedding_type="fourier", init_scale=0., fourier_scale=16,
+        nonlinearity="swish", normalization="GroupNorm", sigma_min=0.01, sigma_max=50, num_scales=1000,
+        scale_by_sigma=True, conv_size=3)
+    for k, v in over.items():
+        c[k] = v
+    return c
+
+
+def overrides_from_golden(z):
+    keys = [str(k) for k in z["override_keys"]]
+    vals = [ast.literal_eval(str(v)) for v in z["override_vals"]]
+    return dict(zip(keys, vals))
+
+
+def state_dict_from_golden(z, prefix="sd::"):
+    return {k[len(prefix):]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith(prefix)}
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))

@@ -1,0 +1,142 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden, rel_err
+from oracle import ops as oops, sde as osde, models as omodels, ksphere as oks, dim as odim
+
+
+def test_upfirdn2d_matches_reference(golden):
+    z = golden("upfirdn2d.npz")
+    for i in range(int(z["n_cases"])):
+        up, down, p0, p1 = (int(v) for v in z[f"c{i}::params"])
+        y = oops.upfirdn2d(torch.from_numpy(z[f"c{i}::x"]), torch.from_numpy(z[f"c{i}::k"]), up=up, down=down,
+                           pad=(p0, p1))
+        ref = torch.from_numpy(z[f"c{i}::y"])
+        assert y.shape == ref.shape, i
+        torch.testing.assert_close(y, ref, rtol=1e-6, atol=1e-6)
+    ux, uy, dx, dy, px0, px1, py0, py1 = (int(v) for v in z["xy::params"])
+    y = oops.upfirdn2d_ref(torch.from_numpy(z["xy::x"]), torch.from_numpy(z["xy::k"]), ux, uy, dx, dy, px0, px1,
+                           py0, py1)
+    torch.testing.assert_close(y, torch.from_numpy(z["xy::y"]), rtol=1e-6, atol=1e-6)
+
+
+def test_fused_leaky_relu_matches_reference_cpu_branch(golden):
+    z = golden("fused_act.npz")
+    for i in range(int(z["n_cases"])):
+        x, b = torch.from_numpy(z[f"c{i}::x"]), torch.from_numpy(z[f"c{i}::b"])
+        torch.testing.assert_close(oops.fused_leaky_relu(x, b), torch.from_numpy(z[f"c{i}::y_default"]),
+                                   rtol=1e-6, atol=1e-7)
+        # slope argument is ignored on the reference's CPU branch, scale is honoured
+        torch.testing.assert_close(oops.fused_leaky_relu(x, b, negative_slope=0.05, scale=1.25),
+                                   torch.from_numpy(z[f"c{i}::y_slope0.05_scale1.25"]), rtol=1e-6, atol=1e-7)
+
+
+def test_sde_marginals(golden):
+    z = golden("sde.npz")
+    t, x = torch.from_numpy(z["t"]), torch.from_numpy(z["x"])
+    for name in ("ve_ksphere", "ve_image", "ve_mnist"):
+        smin, smax, n = z[f"{name}::params"]
+        mean, std = osde.VESDE(float(smin), float(smax), int(n)).marginal_prob(x, t)
+        assert torch.equal(mean, torch.from_numpy(z[f"{name}::mean"]))
+        assert torch.equal(std, torch.from_numpy(z[f"{name}::std"]))
+    mean, std = osde.VPSDE(0.1, 20., 1000).marginal_prob(x, t)
+    assert torch.equal(mean, torch.from_numpy(z["vp::mean"]))
+    assert torch.equal(std, torch.from_numpy(z["vp::std"]))
+
+
+def test_fcn_score_fn_tiny(golden):
+    z = golden("fcn_tiny.npz")
+    model = omodels.create_model(fcn_config(hidden_nodes=64))
+    model.load_state_dict(state_dict_from_golden(z), strict=True)
+    score_fn = osde.get_score_fn(osde.VESDE(1e-2, 4, 1000), model)
+    with torch.no_grad():
+        y = score_fn(torch.from_numpy(z["x"]), torch.from_numpy(z["t"]))
+    assert torch.equal(y, torch.from_numpy(z["score"]))
+
+
+def test_fcn_full_size_from_seed(golden):
+    """Full-size fcn (10dim.py:97-103): weights are rebuilt from torch.manual_seed(0), not stored."""
+    z = golden("fcn_full_seed0.npz")
+    torch.manual_seed(0)
+    model = omodels.create_model(fcn_config(hidden_nodes=2048))
+    sums = np.array([float(v.double().abs().sum()) for v in model.state_dict().values()])
+    np.testing.assert_allclose(sums, z["weight_abs_sums"], rtol=1e-12)
+    score_fn = osde.get_score_fn(osde.VESDE(1e-2, 4, 1000), model)
+    with torch.no_grad():
+        y = score_fn(torch.from_numpy(z["x"]), torch.from_numpy(z["t"]))
+    torch.testing.assert_close(y, torch.from_numpy(z["score"]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("variant", ["bench_init0", "bench_init1", "ddpm_outskip", "biggan_nofir",
+                                     "biggan_outskip_sum"])
+def test_ncsnpp_score_fn(golden, variant):
+    z = golden(f"ncsnpp_{variant}.npz")
+    cfg = ncsnpp_config(**overrides_from_golden(z))
+    model = omodels.create_model(cfg)
+    assert len(model.all_modules) == int(z["n_modules"])
+    model.load_state_dict(state_dict_from_golden(z), strict=True)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    with torch.no_grad():
+        raw = model.eval()(x, t * 999)
+        y = osde.get_score_fn(osde.VESDE(0.01, 50, 1000), model)(x, t)
+    # same ATen kernels on the same host; the einsum contraction order is the only freedom
+    assert rel_err(raw, z["model_out"]) < 2e-6
+    assert rel_err(y, z["score"]) < 2e-6
+
+
+def test_reference_broken_switches_are_reported():
+    with pytest.raises(NotImplementedError):
+        omodels.create_model(ncsnpp_config(**{"model.progressive": "residual"}))
+    with pytest.raises(NotImplementedError):
+        omodels.create_model(ncsnpp_config(**{"model.resblock_type": "ddpm"}))  # fir + resamp_with_conv upsample
+
+
+def test_ksphere_data(golden):
+    z = golden("ksphere.npz")
+    for k in (10, 50):
+        torch.manual_seed(42)
+        data = oks.ksphere_data(32, 100, k)
+        torch.testing.assert_close(data, torch.from_numpy(z[f"k{k}::data"]), rtol=0, atol=1e-6)
+        q = oks.isometry(100, k)
+        # the embedded points live on the unit sphere of span(Q)
+        torch.testing.assert_close(torch.linalg.norm(data @ q, dim=1), torch.ones(32), rtol=0, atol=1e-5)
+
+
+def test_spectrum_and_id_rule(golden):
+    z = golden("svd_rule.npz")
+    for i in range(int(z["n_mats"])):
+        s_mat = torch.from_numpy(z[f"m{i}::S"])
+        s = odim.spectrum(s_mat)
+        ref32, ref64 = z[f"m{i}::sv_ref_f32"], z[f"m{i}::sv_f64"]
+        np.testing.assert_allclose(s.numpy(), ref32, rtol=1e-5)
+        np.testing.assert_allclose(odim.spectrum_f64(s_mat).numpy(), ref64, rtol=1e-10)
+        assert odim.estimate_dim(s.tolist()) == int(z[f"m{i}::dim"]) == int(z[f"m{i}::k_true"])
+    for i in range(int(z["n_rules"])):
+        assert odim.estimate_dim(z[f"r{i}::s"].tolist()) == int(z[f"r{i}::dim"])
+    svd = {"singular_values": [z["r0::s"].tolist(), z["agg::s1"].tolist()]}
+    for mode in ("first", "mean", "all"):
+        assert odim.estimate_dims(svd, mode) == [int(v) for v in z[f"agg::{mode}"]]
+
+
+def test_batching_arithmetic():
+    # dim_reduction.py:166-171 on the three BASELINE workloads
+    assert odim.batching((100,), 500) == (4, 1, 1501)
+    assert odim.batching((3, 32, 32), 128) == (36, 0, 4480)
+    assert odim.batching((3, 64, 64), 128) == (132, 0, 16768)
+
+
+@pytest.mark.parametrize("k", [10, 50])
+def test_cfg1_exact_score_recovers_id_on_cpu(k):
+    """BASELINE config 1 (CPU plumbing): the reference recipe with the exact k-sphere score gives ID = k."""
+    torch.manual_seed(42)
+    data = oks.ksphere_data(2000, 100, k)
+    sde = osde.VESDE(1e-2, 4, 1000)
+    model = oks.KSphereExact(100, k, 1e-2, 4)
+    score_fn = osde.get_score_fn(sde, model)
+    loader = [data[i:i + 500] for i in range(0, 2000, 500)]
+    out = odim.get_manifold_dimension(score_fn, sde, 1e-5, loader, 500, num_datapoints=3,
+                                      generator=torch.Generator().manual_seed(0))
+    assert len(out["singular_values"]) == 2 and len(out["singular_values"][0]) == 100
+    assert odim.estimate_dims(out) == [k, k]
