@@ -1,0 +1,292 @@
+"""ctypes binding of libidiff_hip.so (C ABI declared in include/idiff_hip.h).
+
+PyTorch is used for device memory and streams only: every wrapper below takes
+CUDA(=HIP) fp32/fp64 tensors, checks device / dtype / contiguity / shape on
+the host, passes ``tensor.data_ptr()`` and the current stream handle to the
+library and raises ``RuntimeError`` if the call reports an error.  There is no
+CPU path: a missing library or a CPU tensor is an error, never a fallback.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "csrc", "libidiff_hip.so")
+_lib = None
+
+ACT = {None: 0, "none": 0, "linear": 0, "silu": 1, "swish": 1, "elu": 2, "relu": 3, "lrelu": 4}
+
+c_i, c_i64, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class Epilogue(ctypes.Structure):
+    """Mirror of ``idiff_epilogue`` (include/idiff_hip.h)."""
+    _fields_ = [("bias", c_p), ("rowbias", c_p), ("ld_rowbias", c_i64), ("rows_per_group", c_i), ("act", c_i),
+                ("residual", c_p), ("ld_residual", c_i64), ("out_scale", c_f), ("rowscale", c_p)]
+
+
+_SIGNATURES = {
+    "idiff_abi_version": (c_i, []),
+    "idiff_last_error": (ctypes.c_char_p, []),
+    "idiff_upfirdn2d_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 14 + [c_p]),
+    "idiff_fused_bias_act_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "idiff_gemm_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i,
+                             ctypes.POINTER(Epilogue), c_p]),
+    "idiff_conv2d_nhwc_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [ctypes.POINTER(Epilogue), c_p]),
+    "idiff_groupnorm_nsplit": (c_i, [c_i, c_i, c_i]),
+    "idiff_groupnorm_stats_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "idiff_groupnorm_apply_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "idiff_softmax_rows_f32": (c_i, [c_p, c_p, c_i64, c_i, c_f, c_p]),
+    "idiff_affine_act_f32": (c_i, [c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_i64, c_p]),
+    "idiff_add_scale_f32": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_p]),
+    "idiff_fourier_embed_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
+    "idiff_positional_embed_f32": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p]),
+    "idiff_concat_cols_f32": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i64, c_p]),
+    "idiff_nchw_to_nhwc_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "idiff_nhwc_to_nchw_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "idiff_resample2x_nhwc_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "idiff_perturb_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p]),
+    "idiff_spectrum_workspace_bytes": (c_i64, [c_i, c_i, c_i]),
+    "idiff_spectrum_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p]),
+    "idiff_colmean_f64": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "idiff_centered_gram_f64": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "idiff_symtridiag_f64": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "idiff_tridiag_eigvals_f64": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 with hipcc (works without a GPU)."""
+    out = subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh")], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("building libidiff_hip.so failed:\n" + out.stdout + out.stderr)
+    if verbose:
+        print(out.stdout.strip())
+    return _LIB_PATH
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is missing or stale."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(id-diff_amd has no CPU or PyTorch fallback).")
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here == header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if handle.idiff_abi_version() != 1:
+            raise RuntimeError("libidiff_hip.so ABI version mismatch; rebuild it")
+        _lib = handle
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().idiff_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name, dtype=torch.float32, contiguous=True):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{name}: expected a tensor on the MI355X (cuda device), got {t.device}; "
+                           "id-diff_amd has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def make_epilogue(bias=None, rowbias=None, rows_per_group=1, act=None, residual=None, out_scale=1.0,
+                  ld_rowbias=None, ld_residual=None, rowscale=None):
+    ep = Epilogue()
+    ep.bias = _ptr(bias)
+    ep.rowbias = _ptr(rowbias)
+    ep.ld_rowbias = (rowbias.stride(0) if ld_rowbias is None else ld_rowbias) if rowbias is not None else 0
+    ep.rows_per_group = int(rows_per_group)
+    ep.act = ACT[act]
+    ep.residual = _ptr(residual)
+    ep.ld_residual = (residual.shape[-1] if ld_residual is None else ld_residual) if residual is not None else 0
+    ep.out_scale = float(out_scale)
+    ep.rowscale = _ptr(rowscale)
+    return ep
+
+
+# ------------------------------------------------------------------------------------------- native ops
+def upfirdn2d_raw(x, k, out, major, in_h, in_w, minor, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
+    kh, kw = k.shape
+    _check(lib().idiff_upfirdn2d_f32(x.data_ptr(), k.data_ptr(), out.data_ptr(), major, in_h, in_w, minor, kh, kw,
+                                     up_x, up_y, down_x, down_y, px0, px1, py0, py1, _stream()), "idiff_upfirdn2d_f32")
+
+
+def upfirdn2d_out_size(in_size, up, down, pad0, pad1, k):
+    return (in_size * up + pad0 + pad1 - k) // down + 1
+
+
+def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
+    _dev(x, "input")
+    out = torch.empty_like(x)
+    has_b = bias is not None and bias.numel() > 0
+    has_r = ref is not None and ref.numel() > 0
+    if has_b:
+        _dev(bias, "bias")
+        if x.ndim < 2 or bias.numel() != x.shape[1]:
+            raise RuntimeError(f"bias has {bias.numel()} entries but input dim 1 is {tuple(x.shape)}")
+    if has_r:
+        _dev(ref, "refer")
+        if ref.shape != x.shape:
+            raise RuntimeError("refer must have the shape of input")
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    _check(lib().idiff_fused_bias_act_f32(x.data_ptr(), _ptr(bias if has_b else None), _ptr(ref if has_r else None),
+                                          out.data_ptr(), x.numel(), step_b, bias.numel() if has_b else 0, act, grad,
+                                          alpha, scale, _stream()), "idiff_fused_bias_act_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- contractions
+def gemm(a, bt, out=None, epilogue=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
+         batch=1, stride_a=0, stride_b=0, stride_c=0):
+    """out[b] = epilogue(a[b] @ bt[b].T); 2-D tensors by default, explicit geometry for batched views."""
+    explicit = M is not None  # strided views of larger buffers: the caller supplies the geometry
+    _dev(a, "a", contiguous=not explicit); _dev(bt, "bt", contiguous=not explicit)
+    if M is None:
+        M, K = a.shape
+        N = bt.shape[0]
+        if bt.shape[1] != K:
+            raise RuntimeError(f"gemm: inner dimensions differ: {tuple(a.shape)} x {tuple(bt.shape)}^T")
+        lda, ldb = a.stride(0), bt.stride(0)
+    if out is None:
+        out = torch.empty((M, N) if batch == 1 else (batch, M, N), device=a.device, dtype=torch.float32)
+        ldc = N
+        stride_c = M * N
+    elif ldc is None:
+        ldc = out.stride(-2)
+    _dev(out, "out", contiguous=not explicit)
+    ep = ctypes.byref(epilogue) if epilogue is not None else None
+    _check(lib().idiff_gemm_f32(a.data_ptr(), lda, stride_a, bt.data_ptr(), ldb, stride_b, out.data_ptr(), ldc, stride_c,
+                                M, N, K, batch, ep, _stream()), "idiff_gemm_f32")
+    return out
+
+
+def conv2d_nhwc(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue=None, pad_hi=None):
+    ep = ctypes.byref(epilogue) if epilogue is not None else None
+    _check(lib().idiff_conv2d_nhwc_f32(x.data_ptr(), wt.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, KH, KW, stride,
+                                       pad, pad if pad_hi is None else pad_hi, ep, _stream()), "idiff_conv2d_nhwc_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- norm / pointwise
+def groupnorm_nsplit(B, HW, C):
+    return lib().idiff_groupnorm_nsplit(B, HW, C)
+
+
+def groupnorm_stats(x, C, x2, C2, B, HW, G, eps, workspace, stats):
+    _check(lib().idiff_groupnorm_stats_f32(x.data_ptr(), C, _ptr(x2), C2, B, HW, G, eps, workspace.data_ptr(),
+                                           stats.data_ptr(), _stream()), "idiff_groupnorm_stats_f32")
+
+
+def groupnorm_apply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y):
+    _check(lib().idiff_groupnorm_apply_f32(x.data_ptr(), C, _ptr(x2), C2, B, HW, G, stats.data_ptr(), gamma.data_ptr(),
+                                           beta.data_ptr(), ACT[act], y.data_ptr(), _stream()),
+           "idiff_groupnorm_apply_f32")
+
+
+def softmax_rows(x, y, rows, cols, scale):
+    _check(lib().idiff_softmax_rows_f32(x.data_ptr(), y.data_ptr(), rows, cols, scale, _stream()),
+           "idiff_softmax_rows_f32")
+
+
+def affine_act(a, y, n, alpha=1.0, beta=0.0, act=None, rowscale=None, inner=0):
+    _check(lib().idiff_affine_act_f32(a.data_ptr(), y.data_ptr(), n, alpha, beta, ACT[act], _ptr(rowscale), inner,
+                                      _stream()), "idiff_affine_act_f32")
+
+
+def add_scale(a, b, y, n, scale):
+    _check(lib().idiff_add_scale_f32(a.data_ptr(), b.data_ptr(), y.data_ptr(), n, scale, _stream()),
+           "idiff_add_scale_f32")
+
+
+def fourier_embed(t, W, out, B, half):
+    _check(lib().idiff_fourier_embed_f32(t.data_ptr(), W.data_ptr(), out.data_ptr(), B, half, _stream()),
+           "idiff_fourier_embed_f32")
+
+
+def positional_embed(t, out, B, dim, max_positions=10000.0):
+    _check(lib().idiff_positional_embed_f32(t.data_ptr(), out.data_ptr(), B, dim, max_positions, _stream()),
+           "idiff_positional_embed_f32")
+
+
+def concat_cols(a, Ca, b, Cb, out, rows):
+    _check(lib().idiff_concat_cols_f32(a.data_ptr(), Ca, b.data_ptr(), Cb, out.data_ptr(), rows, _stream()),
+           "idiff_concat_cols_f32")
+
+
+def nchw_to_nhwc(x, y, B, C, HW, Cpad, alpha=1.0, beta=0.0):
+    _check(lib().idiff_nchw_to_nhwc_f32(x.data_ptr(), y.data_ptr(), B, C, HW, Cpad, alpha, beta, _stream()),
+           "idiff_nchw_to_nhwc_f32")
+
+
+def nhwc_to_nchw(x, y, B, C, HW, Cpad, rowscale=None):
+    _check(lib().idiff_nhwc_to_nchw_f32(x.data_ptr(), y.data_ptr(), B, C, HW, Cpad, _ptr(rowscale), _stream()),
+           "idiff_nhwc_to_nchw_f32")
+
+
+def perturb(x, z, std, mean_coeff, out, rows, D):
+    _check(lib().idiff_perturb_f32(x.data_ptr(), z.data_ptr(), std.data_ptr(), _ptr(mean_coeff), out.data_ptr(), rows, D,
+                                   _stream()), "idiff_perturb_f32")
+
+
+def resample2x_nhwc(x, y, B, H, W, C, up):
+    _check(lib().idiff_resample2x_nhwc_f32(x.data_ptr(), y.data_ptr(), B, H, W, C, int(up), _stream()),
+           "idiff_resample2x_nhwc_f32")
+
+
+# ------------------------------------------------------------------------------------------- spectrum
+def spectrum_workspace_bytes(P, M, D):
+    return lib().idiff_spectrum_workspace_bytes(P, M, D)
+
+
+def spectrum(S, workspace=None, return_eig=False):
+    """Singular values (descending, fp32) of the column-centred matrices S [P, M, D] or [M, D]."""
+    _dev(S, "scores")
+    squeeze = S.ndim == 2
+    if squeeze:
+        S = S.unsqueeze(0)
+    if S.ndim != 3:
+        raise RuntimeError("scores must be [M, D] or [P, M, D]")
+    P, M, D = S.shape
+    need = spectrum_workspace_bytes(P, M, D)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need + 7) // 8, dtype=torch.float64, device=S.device)
+    sv = torch.empty(P, D, dtype=torch.float32, device=S.device)
+    eig = torch.empty(P, D, dtype=torch.float64, device=S.device) if return_eig else None
+    _check(lib().idiff_spectrum_f32(S.data_ptr(), P, M, D, workspace.data_ptr(),
+                                    workspace.numel() * workspace.element_size(), sv.data_ptr(), _ptr(eig), _stream()),
+           "idiff_spectrum_f32")
+    if squeeze:
+        sv = sv[0]
+        eig = eig[0] if eig is not None else None
+    return (sv, eig) if return_eig else sv

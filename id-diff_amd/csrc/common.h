@@ -1,0 +1,58 @@
+// Shared host/device helpers for libidiff_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/idiff_hip.h"
+
+#define IDIFF_API extern "C" __attribute__((visibility("default")))
+
+namespace idiff {
+
+void set_error(const char *fmt, ...);
+
+inline int fail(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  set_error("%s", buf);
+  return IDIFF_EINVAL;
+}
+
+// Every launcher ends with this: reports a launch-time error without synchronising.
+inline int launch_status(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Memory-bound grids: enough workgroups to fill 256 CUs x 8 without paying for a huge grid.
+static inline int streaming_grid(int64_t work_items, int block) {
+  int64_t g = ceil_div64(work_items, block);
+  const int64_t cap = 256 * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case IDIFF_ACT_SILU: return v / (1.0f + expf(-v));
+    case IDIFF_ACT_ELU: return v > 0.f ? v : (expf(v) - 1.0f);  // exp(x)-1 as ATen's elu does
+    case IDIFF_ACT_RELU: return v > 0.f ? v : 0.f;
+    case IDIFF_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    default: return v;
+  }
+}
+
+}  // namespace idiff

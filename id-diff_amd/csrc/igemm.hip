@@ -1,0 +1,330 @@
+// Dense contractions of the score networks on the fp32 matrix cores of gfx950.
+//
+//   C[m, n] = epilogue( sum_k A[m, k] * Bt[n, k] )
+//
+// One kernel template serves every contraction on the hot path:
+//   LINEAR  A is a row-major [M, K] matrix (Linear layers, NIN / 1x1 convs on NHWC activations, the
+//           attention products Q K^T and P V with V held transposed), optionally batched by strides.
+//   CONV    A is gathered on the fly from an NHWC activation tensor: m = (b, oy, ox),
+//           k = (ky, kx, cin), A[m, k] = x[b, oy*stride + ky - pad, ox*stride + kx - pad, cin] or 0
+//           outside the image (implicit GEMM; im2col is never written to HBM).
+// Both operands are "K-contiguous panels": weights are packed once at load time as Bt[N][K]
+// (= [Cout][KH][KW][Cin] for convs, the native [out][in] layout for Linear).
+//
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak; there is no
+// TF32/xf32 on gfx950 and the parity target is the reference's fp32 CPU path).  Lane l feeds
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; since the order of the k-reduction is free, each
+// lane half takes FOUR consecutive k from one ds_read_b128 (half h supplies k = 8g + 4h + j to the j-th
+// MFMA of k-group g), so a wave issues (TM + TN) 16-byte LDS reads per 4*TM*TN MFMAs.
+//
+// Tile: BM x BN x 32 per workgroup, waves arranged WARPS_M x WARPS_N, each wave TM x TN MFMA tiles.
+// LDS panels are [rows][32 + 4] floats: the 16-byte pad makes the ds_read_b128 of 16 consecutive rows hit
+// 16 distinct 4-bank slots (conflict-free) and keeps every row 16-byte aligned for ds_write_b128.
+// Pipeline: global -> registers for k-tile t+1 is issued before the MFMAs of tile t (latency hides under
+// 64-cycle MFMAs), registers -> the other LDS buffer after them, one barrier per k-tile.
+// Workgroup ids are remapped so that consecutive M-tiles (which share conv halo rows and the weight
+// panel) land on the same XCD's L2.
+#include "common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDS_PITCH = BK + 4;
+
+struct IgemmParams {
+  const float *A;   // LINEAR: matrix; CONV: NHWC activations
+  const float *Bt;
+  float *C;
+  int64_t lda, ldb, ldc;
+  int64_t strideA, strideB, strideC;
+  int M, N, K;
+  int tiles_m, tiles_n;
+  // conv geometry
+  int H, W, Cin, OH, OW, KW, stride, pad;
+  idiff_epilogue ep;
+  int has_ep;
+};
+
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool VEC>
+__global__ void __launch_bounds__(WARPS_M *WARPS_N * 64)
+igemm_kernel(const IgemmParams p) {
+  constexpr int T = WARPS_M * WARPS_N * 64;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;  // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_PER_T = BM * (BK / 4) / T;  // float4 loads per thread per k-tile
+  constexpr int B_PER_T = BN * (BK / 4) / T;
+  static_assert(A_PER_T >= 1 && B_PER_T >= 1, "tile too small for the thread count");
+  static_assert(T % (BK / 4) == 0, "a thread keeps one k-column of float4s");
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *As = lds;                           // [2][BM][LDS_PITCH]
+  float *Bs = lds + 2 * BM * LDS_PITCH;      // [2][BN][LDS_PITCH]
+
+  // ---- XCD-aware, bijective block -> tile map (blocks b and b+8 share an XCD)
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  const int batch = blockIdx.y;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WARPS_N) * WTM, wn0 = (wave % WARPS_N) * WTN;
+
+  const float *Ab = p.A + (int64_t)batch * p.strideA;
+  const float *Bb = p.Bt + (int64_t)batch * p.strideB;
+
+  // ---- per-thread load coordinates: float4 column kc (fixed), rows tid/8 + i*(T/8)
+  const int kc = (tid & 7) * 4;
+  const int row_base = tid >> 3;
+  constexpr int ROW_STEP = T / 8;
+
+  // A rows
+  int64_t a_off[A_PER_T];  // LINEAR: row offset; CONV: pixel-plane base (b*H*W)
+  int a_iy[A_PER_T], a_ix[A_PER_T];
+  bool a_ok[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int m = m0 + row_base + i * ROW_STEP;
+    a_ok[i] = m < p.M;
+    if (CONV) {
+      const int mm = a_ok[i] ? m : 0;
+      const int ox = mm % p.OW;
+      const int t = mm / p.OW;
+      const int oy = t % p.OH;
+      const int b = t / p.OH;
+      a_off[i] = (int64_t)b * p.H * p.W;
+      a_iy[i] = oy * p.stride - p.pad;
+      a_ix[i] = ox * p.stride - p.pad;
+    } else {
+      a_off[i] = (int64_t)m * p.lda;
+      a_iy[i] = a_ix[i] = 0;
+    }
+  }
+  int64_t b_off[B_PER_T];
+  bool b_ok[B_PER_T];
+#pragma unroll
+  for (int i = 0; i < B_PER_T; ++i) {
+    const int n = n0 + row_base + i * ROW_STEP;
+    b_ok[i] = n < p.N;
+    b_off[i] = (int64_t)n * p.ldb;
+  }
+
+  float4 a_reg[A_PER_T], b_reg[B_PER_T];
+
+  auto load_scalar4 = [&](const float *base, int k, bool ok) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      if (k + 0 < p.K) v.x = base[0];
+      if (k + 1 < p.K) v.y = base[1];
+      if (k + 2 < p.K) v.z = base[2];
+      if (k + 3 < p.K) v.w = base[3];
+    }
+    return v;
+  };
+
+  auto fetch = [&](int kt) {
+    const int k = kt * BK + kc;
+    if (CONV) {
+      // k -> (tap, cin); Cin % 4 == 0 so a float4 never straddles a tap
+      const int tap = k / p.Cin, c = k - tap * p.Cin;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      const bool kok = k < p.K;
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) {
+        const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+        const bool ok = kok && a_ok[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        a_reg[i] = ok ? ldg4(Ab + (a_off[i] + (int64_t)iy * p.W + ix) * p.Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) {
+        if (VEC) a_reg[i] = (a_ok[i] && k < p.K) ? ldg4(Ab + a_off[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        else a_reg[i] = load_scalar4(Ab + a_off[i] + k, k, a_ok[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      if (VEC) b_reg[i] = (b_ok[i] && k < p.K) ? ldg4(Bb + b_off[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      else b_reg[i] = load_scalar4(Bb + b_off[i] + k, k, b_ok[i]);
+    }
+  };
+
+  auto stage = [&](int buf) {
+    float *a_dst = As + buf * BM * LDS_PITCH;
+    float *b_dst = Bs + buf * BN * LDS_PITCH;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i)
+      *reinterpret_cast<float4 *>(a_dst + (row_base + i * ROW_STEP) * LDS_PITCH + kc) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i)
+      *reinterpret_cast<float4 *>(b_dst + (row_base + i * ROW_STEP) * LDS_PITCH + kc) = b_reg[i];
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
+  const int nkt = (p.K + BK - 1) / BK;
+
+  fetch(0);
+  stage(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) fetch(kt + 1);
+    const float *a_src = As + buf * BM * LDS_PITCH + (wm0 + frag_row) * LDS_PITCH + frag_k;
+    const float *b_src = Bs + buf * BN * LDS_PITCH + (wn0 + frag_row) * LDS_PITCH + frag_k;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a_src + i * 32 * LDS_PITCH + g * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(b_src + j * 32 * LDS_PITCH + g * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nkt) stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float *Cb = p.C + (int64_t)batch * p.strideC;
+  const idiff_epilogue &ep = p.ep;
+  const int col_l = lane & 31, row_l = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn0 + j * 32 + col_l;
+    if (n >= p.N) continue;
+    const float bias = (p.has_ep && ep.bias) ? ep.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bias;
+        if (p.has_ep) {
+          if (ep.rowbias) v += ep.rowbias[(int64_t)(m / ep.rows_per_group) * ep.ld_rowbias + n];
+          v = idiff::act_apply(v, ep.act);
+          if (ep.residual) v += ep.residual[(int64_t)m * ep.ld_residual + n];
+          v *= ep.out_scale;
+          if (ep.rowscale) v *= ep.rowscale[m / ep.rows_per_group];
+        }
+        Cb[(int64_t)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool VEC>
+int launch_cfg(IgemmParams &p, int batch, hipStream_t st) {
+  p.tiles_m = idiff::ceil_div(p.M, BM);
+  p.tiles_n = idiff::ceil_div(p.N, BN);
+  constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(float);
+  auto kern = igemm_kernel<BM, BN, WARPS_M, WARPS_N, CONV, VEC>;
+  static bool attr_set = false;  // idempotent; a benign race sets it twice at worst
+  if (lds_bytes > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      idiff::set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds_bytes, st, p);
+  return idiff::launch_status(CONV ? "igemm_conv" : "igemm_linear");
+}
+
+template <bool CONV, bool VEC>
+int dispatch(IgemmParams &p, int batch, hipStream_t st) {
+  // Pick the largest tile that still yields >= ~2 workgroups per CU pair; small problems get small tiles.
+  const int64_t wg_big = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 128) * batch;
+  if (p.N > 64 && wg_big >= 256) return launch_cfg<128, 128, 2, 2, CONV, VEC>(p, batch, st);
+  const int64_t wg_mid = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 64) * batch;
+  if (wg_mid >= 256 || p.M >= 4096) return launch_cfg<128, 64, 2, 2, CONV, VEC>(p, batch, st);
+  return launch_cfg<64, 64, 2, 2, CONV, VEC>(p, batch, st);
+}
+
+void fill_epilogue(IgemmParams &p, const idiff_epilogue *ep) {
+  if (ep) {
+    p.ep = *ep;
+    p.has_ep = 1;
+    if (p.ep.rows_per_group <= 0) p.ep.rows_per_group = 1;
+  } else {
+    p.has_ep = 0;
+    p.ep.bias = nullptr; p.ep.rowbias = nullptr; p.ep.residual = nullptr;
+    p.ep.ld_rowbias = 0; p.ep.ld_residual = 0; p.ep.rows_per_group = 1; p.ep.act = 0; p.ep.out_scale = 1.f;
+    p.ep.rowscale = nullptr;
+  }
+}
+
+bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
+
+}  // namespace
+
+IDIFF_API int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt, int64_t ldb,
+                             int64_t strideB, float *C, int64_t ldc, int64_t strideC, int M, int N, int K,
+                             int batch, const idiff_epilogue *ep, void *stream) {
+  using namespace idiff;
+  if (M < 0 || N < 0 || K <= 0 || batch < 0) return fail("gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  if (M == 0 || N == 0 || batch == 0) return 0;
+  if (!A || !Bt || !C) return fail("gemm: null pointer");
+  if (lda < K || ldb < K || ldc < N) return fail("gemm: leading dimension smaller than the row length");
+  if (batch > 65535) return fail("gemm: batch %d exceeds grid.y", batch);
+  IgemmParams p = {};
+  p.A = A; p.Bt = Bt; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.strideA = strideA; p.strideB = strideB; p.strideC = strideC; p.M = M; p.N = N; p.K = K;
+  fill_epilogue(p, ep);
+  const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) && (strideB % 4 == 0) &&
+                   aligned16(A) && aligned16(Bt);
+  hipStream_t st = (hipStream_t)stream;
+  return vec ? dispatch<false, true>(p, batch, st) : dispatch<false, false>(p, batch, st);
+}
+
+IDIFF_API int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out, int B, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad_lo, int pad_hi,
+                                    const idiff_epilogue *ep, void *stream) {
+  using namespace idiff;
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_lo < 0 || pad_hi < 0)
+    return fail("conv2d: bad geometry");
+  if (Cin % 4 != 0) return fail("conv2d: Cin must be a multiple of 4 (pad the channels), got %d", Cin);
+  if (B == 0) return 0;
+  if (!x || !wt || !out) return fail("conv2d: null pointer");
+  if (!aligned16(x) || !aligned16(wt)) return fail("conv2d: x and wt must be 16-byte aligned");
+  const int OH = (H + pad_lo + pad_hi - KH) / stride + 1, OW = (W + pad_lo + pad_hi - KW) / stride + 1;
+  const int pad = pad_lo;
+  if (H + pad_lo + pad_hi < KH || W + pad_lo + pad_hi < KW || OH <= 0 || OW <= 0) return fail("conv2d: empty output");
+  const int64_t M64 = (int64_t)B * OH * OW;
+  if (M64 > 0x7fffffff) return fail("conv2d: B*OH*OW overflows int32");
+  IgemmParams p = {};
+  p.A = x; p.Bt = wt; p.C = out;
+  p.M = (int)M64; p.N = Cout; p.K = KH * KW * Cin;
+  p.lda = 0; p.ldb = p.K; p.ldc = Cout;
+  p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KW = KW; p.stride = stride; p.pad = pad;
+  fill_epilogue(p, ep);
+  return dispatch<true, true>(p, 1, (hipStream_t)stream);
+}

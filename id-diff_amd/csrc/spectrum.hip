@@ -1,0 +1,475 @@
+// Singular values of the centred score matrix on gfx950 (replaces the CPU torch.linalg.svd of
+// dim_reduction.py:193-198, whose U and V are discarded).
+//
+//   mean_j   = (1/M) sum_m S[m, j]                                    fp64, two-stage deterministic sum
+//   G        = sum_m (S[m, :] - mean)^T (S[m, :] - mean)              fp64 on v_mfma_f64_16x16x4_f64
+//   T        = Q^T G Q  tridiagonal (Householder reflections)         fp64
+//   lambda_i = eigenvalues of T by Sturm-sequence bisection           fp64, one thread per eigenvalue
+//   sigma_i  = sqrt(max(lambda_i, 0)), descending                     rounded once to fp32
+//
+// The fp32 entries of S are exact in fp64 and so are their pairwise products (24+24 < 53 bits), so G is
+// the exact Gram matrix up to fp64 summation error: squaring the condition number costs ~1e-16 * cond^2
+// relative, far inside the 1e-4 tolerance for the cliffs the ID rule looks for (cond ~ 1e2..1e4).
+#include "common.h"
+
+namespace {
+
+typedef double doublex4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ means
+constexpr int MEAN_SPLITS = 32;
+
+__global__ void __launch_bounds__(256)
+colsum_partial_kernel(const float *__restrict__ S, int M, int D, double *__restrict__ part /* [P][SPLITS][D] */) {
+  const int p = blockIdx.z, sp = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= D) return;
+  const int rows_per = (M + MEAN_SPLITS - 1) / MEAN_SPLITS;
+  const int lo = sp * rows_per, hi = min(M, lo + rows_per);
+  const float *s = S + (int64_t)p * M * D + col;
+  double acc = 0.0;
+  for (int m = lo; m < hi; ++m) acc += (double)s[(int64_t)m * D];
+  part[((int64_t)p * MEAN_SPLITS + sp) * D + col] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+colsum_final_kernel(const double *__restrict__ part, int M, int D, double *__restrict__ mean) {
+  const int p = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= D) return;
+  double acc = 0.0;
+  for (int sp = 0; sp < MEAN_SPLITS; ++sp) acc += part[((int64_t)p * MEAN_SPLITS + sp) * D + col];
+  mean[(int64_t)p * D + col] = acc / (double)M;
+}
+
+// ------------------------------------------------------------------------------------------------ Gram
+// Workgroup = 4 waves -> one 64 x 64 tile of G (only tiles with tj >= ti are computed, then mirrored).
+// Wave w owns the 32 x 32 quadrant (w>>1, w&1) as 2 x 2 MFMA tiles of 16 x 16.  A k-step is 4 rows of S:
+// lane l feeds A[i = l&15][k = l>>4] = S[m0 + k][i0 + i] - mean[i0 + i] and likewise B from the j panel
+// (v_mfma_f64_16x16x4_f64: C/D row = (l>>4) + 4*reg, col = l&15).
+constexpr int GT = 64;       // tile edge
+constexpr int GROWS = 32;    // rows of S staged per iteration
+constexpr int GPITCH = GT + 16;  // row offset = 16 banks: the 4 rows of a k-step never collide
+
+__global__ void __launch_bounds__(256)
+gram_kernel(const float *__restrict__ S, const double *__restrict__ mean, int M, int D, int tiles,
+            double *__restrict__ G) {
+  __shared__ float Si[GROWS * GPITCH];
+  __shared__ float Sj[GROWS * GPITCH];
+  // decode upper-triangular tile index
+  int t = blockIdx.x, ti = 0;
+  while (t >= tiles - ti) { t -= tiles - ti; ++ti; }
+  const int tj = ti + t;
+  const int p = blockIdx.y;
+  const float *Sp = S + (int64_t)p * M * D;
+  const double *mu = mean + (int64_t)p * D;
+  const int i0 = ti * GT, j0 = tj * GT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  const int fl = lane & 15, fk = lane >> 4;
+
+  double mi[2], mj[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int ci = i0 + wi + a * 16 + fl, cj = j0 + wj + a * 16 + fl;
+    mi[a] = ci < D ? mu[ci] : 0.0;
+    mj[a] = cj < D ? mu[cj] : 0.0;
+  }
+  doublex4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (doublex4){0.0, 0.0, 0.0, 0.0};
+
+  // staging map: 256 threads x 8 elements = 32 rows x 64 cols, consecutive threads -> consecutive columns
+  const int sc = tid & 63, sr = tid >> 6;  // rows sr, sr+4, ...
+  for (int m0 = 0; m0 < M; m0 += GROWS) {
+#pragma unroll
+    for (int r = 0; r < GROWS / 4; ++r) {
+      const int row = sr + r * 4, m = m0 + row;
+      const bool rok = m < M;
+      // out-of-range rows/cols are staged as 0 and masked again when the fragments are formed
+      const int ci = i0 + sc, cj = j0 + sc;
+      Si[row * GPITCH + sc] = (rok && ci < D) ? Sp[(int64_t)m * D + ci] : 0.f;
+      Sj[row * GPITCH + sc] = (rok && cj < D) ? Sp[(int64_t)m * D + cj] : 0.f;
+    }
+    __syncthreads();
+    const int rows_here = min(GROWS, M - m0);
+#pragma unroll
+    for (int ks = 0; ks < GROWS / 4; ++ks) {
+      const int row = ks * 4 + fk;
+      double a[2], b[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float va = Si[row * GPITCH + wi + q * 16 + fl];
+        const float vb = Sj[row * GPITCH + wj + q * 16 + fl];
+        const bool oka = row < rows_here && (i0 + wi + q * 16 + fl) < D;
+        const bool okb = row < rows_here && (j0 + wj + q * 16 + fl) < D;
+        a[q] = oka ? (double)va - mi[q] : 0.0;
+        b[q] = okb ? (double)vb - mj[q] : 0.0;
+      }
+#pragma unroll
+      for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+          acc[qa][qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qa], b[qb], acc[qa][qb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  double *Gp = G + (int64_t)p * D * D;
+#pragma unroll
+  for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wi + qa * 16 + fk + 4 * r;
+        const int gj = j0 + wj + qb * 16 + fl;
+        if (gi < D && gj < D) {
+          const double v = acc[qa][qb][r];
+          Gp[(int64_t)gi * D + gj] = v;
+          if (ti != tj) Gp[(int64_t)gj * D + gi] = v;
+        }
+      }
+}
+
+// diagonal tiles are computed in full by the kernel above (both triangles inside the tile come from the
+// same products in a different order); force exact symmetry afterwards so the Householder sweep may read
+// rows where the textbook reads columns.
+__global__ void __launch_bounds__(256)
+symmetrize_diag_tiles_kernel(double *__restrict__ G, int D) {
+  const int p = blockIdx.y, tile = blockIdx.x;
+  double *Gp = G + (int64_t)p * D * D;
+  for (int e = threadIdx.x; e < GT * GT; e += 256) {
+    const int a = e / GT, b = e % GT;
+    const int i = tile * GT + a, j = tile * GT + b;
+    if (a < b && i < D && j < D) Gp[(int64_t)j * D + i] = Gp[(int64_t)i * D + j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over a 256-thread workgroup; every thread gets the result.  `buf` holds >= 4 doubles.
+__device__ __forceinline__ double block_sum_d(double v, double *buf) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return buf[0] + buf[1] + buf[2] + buf[3];
+}
+
+// Householder reflector for x (length n, x[0] is the sub-diagonal entry): H = I - tau v v^T,
+// H x = alpha e_0, v = x - alpha e_0.  Returns tau = 0 when x[1:] is already zero.
+struct Reflector { double alpha, v0, tau; };
+__device__ __forceinline__ Reflector make_reflector(double x0, double tail_sq) {
+  Reflector h;
+  if (tail_sq == 0.0) { h.alpha = x0; h.v0 = 0.0; h.tau = 0.0; return h; }
+  const double norm = sqrt(x0 * x0 + tail_sq);
+  h.alpha = x0 > 0.0 ? -norm : norm;
+  h.v0 = x0 - h.alpha;
+  h.tau = 2.0 / (h.v0 * h.v0 + tail_sq);
+  return h;
+}
+
+// ------------------------------------------------------------------------------------------------ tridiag, large D
+// Step k works on the trailing block A22 = A[k+1:, k+1:] (n = D-k-1) with x = A[k, k+1:] (row == column).
+//   symv  : every workgroup rebuilds the reflector from x (one pass over <= D doubles), then
+//           p_i = tau * sum_j A22[i][j] v_j for its rows (one wave per row, coalesced along j).
+//           Workgroup 0 also emits v, tau, diag[k], offdiag[k].
+//   rank2 : every workgroup rebuilds K = (tau/2) p.v, w = p - K v on the fly and applies
+//           A22 -= v w^T + w v^T to its tile (both triangles kept, so rows stay readable as columns).
+__global__ void __launch_bounds__(256)
+tridiag_symv_kernel(const double *__restrict__ A, int D, int k, double *__restrict__ v, double *__restrict__ pvec,
+                    double *__restrict__ diag, double *__restrict__ offd, double *__restrict__ tau_out) {
+  __shared__ double red[4];
+  extern __shared__ double vs[];  // v for this step, length n
+  const int n = D - k - 1;
+  const double *x = A + (int64_t)k * D + (k + 1);
+  double part = 0.0;
+  for (int j = 1 + threadIdx.x; j < n; j += 256) { const double t = x[j]; part += t * t; }
+  const double tail_sq = block_sum_d(part, red);
+  const Reflector h = make_reflector(x[0], tail_sq);
+  for (int j = threadIdx.x; j < n; j += 256) vs[j] = j == 0 ? h.v0 : x[j];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int j = threadIdx.x; j < n; j += 256) v[j] = vs[j];
+    if (threadIdx.x == 0) { diag[k] = A[(int64_t)k * D + k]; offd[k] = h.alpha; *tau_out = h.tau; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+    const double *row = A + (int64_t)(k + 1 + i) * D + (k + 1);
+    double acc = 0.0;
+    for (int j = lane; j < n; j += 64) acc += row[j] * vs[j];
+    acc = wave_sum_d(acc);
+    if (lane == 0) pvec[i] = h.tau * acc;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+tridiag_rank2_kernel(double *__restrict__ A, int D, int k, const double *__restrict__ v,
+                     const double *__restrict__ pvec, const double *__restrict__ tau_in) {
+  __shared__ double red[4];
+  const int n = D - k - 1;
+  const double tau = *tau_in;
+  if (tau == 0.0) return;
+  double part = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) part += pvec[j] * v[j];
+  const double K = 0.5 * tau * block_sum_d(part, red);
+  // tile: 16 rows x all columns per workgroup iteration, threads along columns
+  for (int i0 = blockIdx.x * 16; i0 < n; i0 += gridDim.x * 16) {
+    const int rows = min(16, n - i0);
+    for (int j = threadIdx.x; j < n; j += 256) {
+      const double vj = v[j], wj = pvec[j] - K * vj;
+      for (int r = 0; r < rows; ++r) {
+        const int i = i0 + r;
+        const double vi = v[i], wi = pvec[i] - K * vi;
+        A[(int64_t)(k + 1 + i) * D + (k + 1 + j)] -= vi * wj + wi * vj;
+      }
+    }
+  }
+}
+
+__global__ void tridiag_tail_kernel(const double *__restrict__ A, int D, double *__restrict__ diag,
+                                    double *__restrict__ offd) {
+  // last 2 x 2 block: nothing left to reflect
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (D >= 2) {
+    diag[D - 2] = A[(int64_t)(D - 2) * D + (D - 2)];
+    offd[D - 2] = A[(int64_t)(D - 2) * D + (D - 1)];
+  }
+  diag[D - 1] = A[(int64_t)(D - 1) * D + (D - 1)];
+}
+
+// ------------------------------------------------------------------------------------------------ tridiag, D <= 128 in LDS
+// One workgroup per matrix; the whole matrix lives in LDS (pitch D+1 doubles).  Used for the batched
+// k-sphere workload (P matrices of 100 x 100).
+__global__ void __launch_bounds__(256)
+tridiag_small_kernel(const double *__restrict__ G, int D, double *__restrict__ diag, double *__restrict__ offd) {
+  extern __shared__ double sm[];
+  const int pitch = D + 1;
+  double *A = sm;                 // [D][pitch]
+  double *v = sm + D * pitch;     // [D]
+  double *w = v + D;              // [D]
+  double *red = w + D;            // [4]
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const double *Gp = G + (int64_t)p * D * D;
+  for (int e = tid; e < D * D; e += 256) A[(e / D) * pitch + (e % D)] = Gp[e];
+  __syncthreads();
+  double *dg = diag + (int64_t)p * D, *od = offd + (int64_t)p * D;
+  for (int k = 0; k + 2 < D; ++k) {
+    const int n = D - k - 1;
+    const double *x = A + k * pitch + (k + 1);
+    double part = 0.0;
+    for (int j = 1 + tid; j < n; j += 256) part += x[j] * x[j];
+    const double tail_sq = block_sum_d(part, red);
+    const Reflector h = make_reflector(x[0], tail_sq);
+    if (tid == 0) { dg[k] = A[k * pitch + k]; od[k] = h.alpha; }
+    if (h.tau == 0.0) continue;  // uniform across the workgroup
+    for (int j = tid; j < n; j += 256) v[j] = j == 0 ? h.v0 : x[j];
+    __syncthreads();
+    // p = tau * A22 v : two threads per row
+    {
+      const int row = tid >> 1, half = tid & 1;
+      double acc = 0.0;
+      if (row < n) {
+        const double *ar = A + (k + 1 + row) * pitch + (k + 1);
+        for (int j = half; j < n; j += 2) acc += ar[j] * v[j];
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      if (row < n && half == 0) w[row] = h.tau * acc;
+    }
+    __syncthreads();
+    double pv = 0.0;
+    for (int j = tid; j < n; j += 256) pv += w[j] * v[j];
+    const double K = 0.5 * h.tau * block_sum_d(pv, red);
+    for (int j = tid; j < n; j += 256) w[j] -= K * v[j];
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {
+      const int i = e / n, j = e - i * n;
+      A[(k + 1 + i) * pitch + (k + 1 + j)] -= v[i] * w[j] + w[i] * v[j];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (D >= 2) { dg[D - 2] = A[(D - 2) * pitch + (D - 2)]; od[D - 2] = A[(D - 2) * pitch + (D - 1)]; }
+    dg[D - 1] = A[(D - 1) * pitch + (D - 1)];
+    if (D >= 1) od[D - 1] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ bisection
+// Thread j of matrix p brackets the j-th smallest eigenvalue of the symmetric tridiagonal (d, e) with the
+// Sturm count  #{eigenvalues < x} = #{negative q_i},  q_0 = d_0 - x,  q_i = d_i - x - e_{i-1}^2 / q_{i-1}.
+__global__ void __launch_bounds__(256)
+bisect_kernel(const double *__restrict__ diag, const double *__restrict__ offd, int D, double *__restrict__ eig,
+              float *__restrict__ sv, int use_lds) {
+  extern __shared__ double sh[];  // [2*D] when use_lds: d, e^2
+  __shared__ double red[8];
+  const int p = blockIdx.y;
+  const double *d = diag + (int64_t)p * D, *e = offd + (int64_t)p * D;
+  const int tid = threadIdx.x;
+  // Gershgorin interval and the pivot floor
+  double lo = INFINITY, hi = -INFINITY;
+  for (int i = tid; i < D; i += 256) {
+    const double r = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < D ? fabs(e[i]) : 0.0);
+    lo = fmin(lo, d[i] - r);
+    hi = fmax(hi, d[i] + r);
+    if (use_lds) { sh[i] = d[i]; sh[D + i] = i + 1 < D ? e[i] * e[i] : 0.0; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+  if ((tid & 63) == 0) { red[tid >> 6] = lo; red[4 + (tid >> 6)] = hi; }
+  __syncthreads();
+  lo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+  hi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  const double span = fmax(fabs(lo), fabs(hi));
+  const double pivmin = fmax(1.0, span * span) * 1e-292;  // floor for a vanishing pivot q_i
+  lo -= span * 2.3e-16 * (double)D + pivmin;              // Gershgorin bounds are exact up to rounding
+  hi += span * 2.3e-16 * (double)D + pivmin;
+  const int j = blockIdx.x * 256 + tid;
+  if (j >= D) return;
+  const double *dd = use_lds ? sh : d;
+  const double *ee = use_lds ? sh + D : nullptr;
+  double a = lo, b = hi;
+  for (int it = 0; it < 110; ++it) {
+    const double mid = 0.5 * (a + b);
+    if (mid <= a || mid >= b) break;
+    int count = 0;
+    double q = dd[0] - mid;
+    if (fabs(q) < pivmin) q = -pivmin;
+    count += q < 0.0;
+    for (int i = 1; i < D; ++i) {
+      const double e2 = use_lds ? ee[i - 1] : e[i - 1] * e[i - 1];
+      q = dd[i] - mid - e2 / q;
+      if (fabs(q) < pivmin) q = -pivmin;
+      count += q < 0.0;
+    }
+    if (count > j) b = mid; else a = mid;
+    if (b - a <= 4.4e-16 * fmax(fabs(a), fabs(b))) break;
+  }
+  const double lam = 0.5 * (a + b);
+  if (eig) eig[(int64_t)p * D + j] = lam;
+  if (sv) sv[(int64_t)p * D + (D - 1 - j)] = (float)sqrt(fmax(lam, 0.0));
+}
+
+constexpr int SMALL_D_MAX = 128;
+
+size_t small_lds_bytes(int D) { return ((size_t)D * (D + 1) + 2 * D + 8) * sizeof(double); }
+
+int bisect_launch(const double *diag, const double *offd, int P, int D, double *eig, float *sv, hipStream_t st) {
+  const int use_lds = D <= 8192;
+  const size_t lds = use_lds ? (size_t)2 * D * sizeof(double) : 0;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (e != hipSuccess) { idiff::set_error("bisect: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(bisect_kernel, dim3(idiff::ceil_div(D, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv, use_lds);
+  return idiff::launch_status("bisect");
+}
+
+}  // namespace
+
+using namespace idiff;
+
+IDIFF_API int idiff_colmean_f64(const float *S, int P, int M, int D, double *mean, double *scratch, void *stream) {
+  if (!S || !mean || !scratch || P <= 0 || M <= 0 || D <= 0) return fail("colmean: bad arguments");
+  if (P > 65535) return fail("colmean: P too large");
+  double *part = scratch;  // [P][MEAN_SPLITS][D]
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(D, 256), MEAN_SPLITS, P), dim3(256), 0, st, S, M, D, part);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(D, 256), P), dim3(256), 0, st, part, M, D, mean);
+  return launch_status("colmean");
+}
+
+IDIFF_API int idiff_centered_gram_f64(const float *S, const double *mean, int P, int M, int D, double *G, void *stream) {
+  if (!S || !mean || !G || P <= 0 || M <= 0 || D <= 0) return fail("centered_gram: bad arguments");
+  if (P > 65535) return fail("centered_gram: P too large");
+  const int tiles = ceil_div(D, GT);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gram_kernel, dim3(tiles * (tiles + 1) / 2, P), dim3(256), 0, st, S, mean, M, D, tiles, G);
+  hipLaunchKernelGGL(symmetrize_diag_tiles_kernel, dim3(tiles, P), dim3(256), 0, st, G, D);
+  return launch_status("centered_gram");
+}
+
+IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double *offdiag, double *scratch, void *stream) {
+  if (!G || !diag || !offdiag || P <= 0 || D <= 0) return fail("symtridiag: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (D <= SMALL_D_MAX) {
+    const size_t lds = small_lds_bytes(D);
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_small_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(SMALL_D_MAX));
+      if (e != hipSuccess) { set_error("symtridiag: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(tridiag_small_kernel, dim3(P), dim3(256), lds, st, G, D, diag, offdiag);
+    return launch_status("tridiag_small");
+  }
+  if (!scratch) return fail("symtridiag: scratch (2*D+8 doubles) required for D > %d", SMALL_D_MAX);
+  if ((size_t)D * sizeof(double) > 60 * 1024) {
+    static bool attr_set2 = false;
+    if (!attr_set2) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_symv_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      if (e != hipSuccess) { set_error("symtridiag: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+      attr_set2 = true;
+    }
+    if ((size_t)D * sizeof(double) > 160 * 1024 - 256) return fail("symtridiag: D=%d exceeds the LDS-resident reflector", D);
+  }
+  double *v = scratch, *pvec = scratch + D, *tau = scratch + 2 * D;
+  for (int p = 0; p < P; ++p) {
+    double *A = G + (int64_t)p * D * D;
+    double *dg = diag + (int64_t)p * D, *od = offdiag + (int64_t)p * D;
+    for (int k = 0; k + 2 < D; ++k) {
+      const int n = D - k - 1;
+      const int g1 = max(1, min(ceil_div(n, 4), 1024));
+      hipLaunchKernelGGL(tridiag_symv_kernel, dim3(g1), dim3(256), (size_t)n * sizeof(double), st, A, D, k, v, pvec, dg, od, tau);
+      const int g2 = max(1, min(ceil_div(n, 16), 1024));
+      hipLaunchKernelGGL(tridiag_rank2_kernel, dim3(g2), dim3(256), 0, st, A, D, k, v, pvec, tau);
+    }
+    hipLaunchKernelGGL(tridiag_tail_kernel, dim3(1), dim3(64), 0, st, A, D, dg, od);
+  }
+  return launch_status("symtridiag");
+}
+
+IDIFF_API int idiff_tridiag_eigvals_f64(const double *diag, const double *offdiag, int P, int D, double *eig, void *stream) {
+  if (!diag || !offdiag || !eig || P <= 0 || D <= 0) return fail("tridiag_eigvals: bad arguments");
+  if (P > 65535) return fail("tridiag_eigvals: P too large");
+  return bisect_launch(diag, offdiag, P, D, eig, nullptr, (hipStream_t)stream);
+}
+
+// workspace layout (doubles): mean[P*D] | colsum partials[P*32*D] | G[P*D*D] | diag[P*D] | offd[P*D] | scratch[2*D+8]
+IDIFF_API int64_t idiff_spectrum_workspace_bytes(int P, int M, int D) {
+  (void)M;
+  if (P <= 0 || D <= 0) return 0;
+  const int64_t n = (int64_t)P * D * (1 + MEAN_SPLITS) + (int64_t)P * D * D + 2 * (int64_t)P * D + 2 * (int64_t)D + 8;
+  return n * (int64_t)sizeof(double);
+}
+
+IDIFF_API int idiff_spectrum_f32(const float *S, int P, int M, int D, void *workspace, int64_t workspace_bytes, float *sv,
+                                 double *eig_out, void *stream) {
+  if (!S || !workspace || !sv || P <= 0 || M <= 0 || D <= 0) return fail("spectrum: bad arguments");
+  if (M < D) return fail("spectrum: needs M >= D (got %d x %d)", M, D);
+  if (P > 65535) return fail("spectrum: P too large");
+  if (workspace_bytes < idiff_spectrum_workspace_bytes(P, M, D)) return fail("spectrum: workspace too small");
+  if (((uintptr_t)workspace & 7) != 0) return fail("spectrum: workspace must be 8-byte aligned");
+  double *mean = (double *)workspace;
+  double *G = mean + (int64_t)P * D * (1 + MEAN_SPLITS);
+  double *diag = G + (int64_t)P * D * D;
+  double *offd = diag + (int64_t)P * D;
+  double *scratch = offd + (int64_t)P * D;
+  int rc;
+  if ((rc = idiff_colmean_f64(S, P, M, D, mean, mean + (int64_t)P * D, stream))) return rc;
+  if ((rc = idiff_centered_gram_f64(S, mean, P, M, D, G, stream))) return rc;
+  if ((rc = idiff_symtridiag_f64(G, P, D, diag, offd, scratch, stream))) return rc;
+  return bisect_launch(diag, offd, P, D, eig_out, sv, (hipStream_t)stream);
+}

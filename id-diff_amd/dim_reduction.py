@@ -1,0 +1,195 @@
+"""ID driver: score matrix -> centred spectrum, per data point (drop-in for /root/reference/dim_reduction.py).
+
+``get_manifold_dimension(config, name=None, return_svd=False)`` keeps the reference's contract (:116-215):
+same config keys, same number of processed points (``idx + 1 >= num_datapoints`` stops one short, :159-164),
+same per-point row count ``M = (num_batches - 1) * B + extra`` with ``ambient_dim = prod(x.shape[1:])`` of ONE
+un-batched sample (:166-171), same output ``{'singular_values': [[...], ...]}`` returned or pickled to
+``<log_path>/<log_name>/svd/<name>.pkl`` (:206-211).
+
+What is different, by design for MI355X:
+* nothing leaves the GPU inside the loop: the reference moves every score batch to the host (:183) and runs a
+  full CPU SVD with U and V (:197); here rows are written straight into the device-resident S [M, D] and the
+  spectrum comes from the fp64 Gram -> tridiagonal -> bisection kernels (csrc/spectrum.hip);
+* rows that the reference computes and throws away (the tail of the last batch, :185-188) are not computed;
+* score evaluations run ``inflight`` rows at a time (default: as many of the point's rows as fit the
+  ``dim_estimation.inflight_rows`` budget) instead of B -- every row is an independent sample, GroupNorm is
+  per-sample and the model is in eval mode, so the batch boundary is not observable;
+* noise comes from a per-point ``torch.Generator`` seeded ``seed + point_index`` so results do not depend on
+  how points are distributed over GPUs; points are sharded round-robin over the ranks of the process group and
+  the spectra are combined by one all-gather (parallel.py).
+"""
+import math
+import os
+import pickle
+from pathlib import Path
+
+import torch
+
+from . import _lib, parallel
+from .lightning_data_modules.utils import create_lightning_datamodule
+from .lightning_modules.utils import create_lightning_module
+from .models import utils as mutils
+
+
+def batching(sample_shape, batchsize):
+    """(num_batches, extra_in_last_batch, rows_in_S) of dim_reduction.py:166-171."""
+    ambient_dim = math.prod(sample_shape[1:])
+    num_batches = (ambient_dim // batchsize + 1) * 4
+    extra = ambient_dim - (ambient_dim // batchsize) * batchsize
+    return num_batches, extra, (num_batches - 1) * batchsize + extra
+
+
+def _num_datapoints(config):
+    # dotted hasattr, as the reference does (dim_reduction.py:144-147)
+    if hasattr(config, 'dim_estimation.num_datapoints'):
+        return config.dim_estimation.num_datapoints
+    elif hasattr(config, 'logging.svd_points'):
+        return config.logging.svd_points
+    raise NameError("num_datapoints: neither dim_estimation.num_datapoints nor logging.svd_points is set")
+
+
+class ScoreMatrixBuilder:
+    """Produces S for one point with all work on the device."""
+
+    def __init__(self, score_fn, sde, sampling_eps, device, inflight_rows=None):
+        self.score_fn, self.sde, self.eps, self.device = score_fn, sde, sampling_eps, device
+        self.inflight_rows = inflight_rows
+
+    def rows_per_launch(self, rows, sample_numel):
+        if self.inflight_rows:
+            return max(1, min(rows, int(self.inflight_rows)))
+        # default: keep the activations of one launch within a few GB; 512 image rows or all vector rows
+        return rows if sample_numel <= 4096 and rows <= 65536 else min(rows, 512)
+
+    def build(self, x, batchsize, t=None, noise=None, generator=None):
+        """x: one sample on the device; returns S [M, D] fp32 (rows in the reference's order)."""
+        _, _, rows = batching(tuple(x.shape), batchsize)
+        D = x.numel()
+        t = self.eps if t is None else t
+        S = torch.empty(rows, D, device=self.device, dtype=torch.float32)
+        step = self.rows_per_launch(rows, D)
+        xf = x.reshape(-1).contiguous()
+        for lo in range(0, rows, step):
+            n = min(step, rows - lo)
+            vec_t = torch.full((n,), float(t), device=self.device, dtype=torch.float32)
+            mean_unit, std = self.sde.marginal_prob(torch.ones((), device=self.device), vec_t)
+            coeff = None if mean_unit.ndim == 0 else mean_unit.reshape(-1).contiguous()
+            if noise is not None:
+                z = noise[lo:lo + n].reshape(n, D).contiguous()
+            else:
+                z = torch.randn(n, D, device=self.device, dtype=torch.float32, generator=generator)
+            batch = torch.empty(n, D, device=self.device, dtype=torch.float32)
+            _lib.perturb(xf, z, std.contiguous(), coeff, batch, n, D)
+            score = self.score_fn(batch.view(n, *x.shape), vec_t)
+            S[lo:lo + n].copy_(score.reshape(n, D))
+        return S
+
+
+def setup_model(config):
+    """Steps :123-141 of the reference: data module, module + checkpoint, SDE, device, score_fn."""
+    DataModule = create_lightning_datamodule(config)
+    DataModule.setup()
+    pl_module = create_lightning_module(config)
+    pl_module = pl_module.load_from_checkpoint(config.model.checkpoint_path)
+    pl_module.configure_sde(config)
+    device = torch.device(config.device)
+    if device.type != "cuda":
+        raise RuntimeError(f"config.device is {device}: id-diff_amd runs the manifold_dimension path on the "
+                           "MI355X only (the CPU restatement lives in oracle/ and is test infrastructure)")
+    pl_module = pl_module.to(device)
+    pl_module.eval()
+    score_fn = mutils.get_score_fn(pl_module.sde, pl_module.score_model, conditional=False, train=False, continuous=True)
+    return DataModule, pl_module, score_fn, device
+
+
+def collect_points(loader, num_datapoints):
+    """The points the reference's double loop would visit, in order (dim_reduction.py:154-164)."""
+    pts, idx = [], 0
+    for orig_batch in loader:
+        if isinstance(orig_batch, (list, tuple)):
+            orig_batch = orig_batch[0]
+        batchsize = orig_batch.size(0)
+        if idx + 1 >= num_datapoints:
+            break
+        for x in orig_batch:
+            if idx + 1 >= num_datapoints:
+                break
+            pts.append((x, batchsize))
+            idx += 1
+    return pts
+
+
+def get_manifold_dimension(config, name=None, return_svd=False):
+    log_path, log_name = config.logging.log_path, config.logging.log_name
+    save_path = os.path.join(log_path, log_name, 'svd')
+    rank, world = parallel.rank_world()
+    if rank == 0 and not return_svd:
+        Path(save_path).mkdir(parents=True, exist_ok=True)
+
+    seed = int(config.get('seed', 42))
+    torch.manual_seed(seed)  # same data split / loader order on every rank
+    DataModule, pl_module, score_fn, device = setup_model(config)
+    num_datapoints = _num_datapoints(config)
+    points = collect_points(DataModule.train_dataloader(), num_datapoints)
+
+    builder = ScoreMatrixBuilder(score_fn, pl_module.sde, pl_module.sampling_eps, device,
+                                 config.get('dim_estimation.inflight_rows', None))
+    mine = parallel.my_points(len(points), rank, world)
+    local, n_sv = [], None
+    with torch.no_grad():
+        for p in mine:
+            x, batchsize = points[p]
+            gen = torch.Generator(device=device).manual_seed(seed + 1000003 * (p + 1))
+            S = builder.build(x.to(device), batchsize, generator=gen)
+            local.append(_lib.spectrum(S))
+            n_sv = local[-1].numel()
+    if n_sv is None:  # a rank without points still takes part in the exchange
+        x, batchsize = points[0]
+        n_sv = min(batching(tuple(x.shape), batchsize)[2], x.numel())
+    local = torch.stack(local) if local else torch.empty(0, n_sv, device=device)
+    spectra = parallel.gather_spectra(local, len(points), n_sv, device)
+    info = {'singular_values': [s.tolist() for s in spectra.cpu()]}
+    if return_svd:
+        return info
+    if rank == 0:
+        with open(os.path.join(save_path, f'{name}.pkl'), 'wb') as f:
+            pickle.dump(info, f)
+
+
+def get_conditional_manifold_dimension(config, name=None):
+    """dim_reduction.py:12-114: the same estimator at 12 noise levels linspace(sampling_eps, 0.3, 12) on the
+    label==1 points of the validation loader; writes images.pkl / labels_svd.pkl / labels.pkl per level."""
+    log_path, log_name = config.logging.log_path, config.logging.log_name
+    config.data.return_labels = True
+    seed = int(config.get('seed', 42))
+    torch.manual_seed(seed)
+    DataModule, pl_module, score_fn, device = setup_model(config)
+    num_datapoints = config.get('dim_estimation.num_datapoints', 26)
+    builder = ScoreMatrixBuilder(score_fn, pl_module.sde, pl_module.sampling_eps, device,
+                                 config.get('dim_estimation.inflight_rows', None))
+    times = torch.linspace(pl_module.sampling_eps, 0.3, 12)
+    for t_slice in times:
+        t_save_path = os.path.join(log_path, log_name, 'svd', '%.3f' % t_slice.item())
+        Path(t_save_path).mkdir(parents=True, exist_ok=True)
+        singular_values, labels, imgs, idx = [], [], [], 0
+        with torch.no_grad():
+            for orig_batch, orig_labels in DataModule.val_dataloader():
+                batchsize = orig_batch.size(0)
+                if idx + 1 >= num_datapoints:
+                    break
+                for x, y in zip(orig_batch, orig_labels):
+                    if y.item() != 1:
+                        continue
+                    if idx + 1 >= num_datapoints:
+                        break
+                    imgs.append(x.permute(1, 2, 0))
+                    gen = torch.Generator(device=device).manual_seed(seed + 1000003 * (idx + 1))
+                    S = builder.build(x.to(device), batchsize, t=float(t_slice), generator=gen)
+                    singular_values.append(_lib.spectrum(S).tolist())
+                    labels.append(y.item())
+                    idx += 1
+        for fname, payload in (('images.pkl', {'images': torch.stack(imgs).numpy() if imgs else []}),
+                               ('labels_svd.pkl', {'singular_values': singular_values}),
+                               ('labels.pkl', {'labels': labels})):
+            with open(os.path.join(t_save_path, fname), 'wb') as f:
+                pickle.dump(payload, f)

@@ -1,0 +1,60 @@
+"""CLI drop-in for ``python main.py --config <cfg.py|cfg.pkl> --mode manifold_dimension [--checkpoint_path ...]``
+(/root/reference/main.py:17-71; absl is not installable here, argparse accepts the same flags incl. ``--flag=value``).
+
+Run it from the repo root as ``python id-diff_amd/main.py ...`` or, for several GPUs of one node,
+``python -m torch.distributed.run --nproc-per-node N id-diff_amd/main.py ...``.
+"""
+import argparse
+import os
+import pickle
+import sys
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import id_diff_amd  # noqa: F401
+    __package__ = "id_diff_amd"
+
+from id_diff_amd import parallel, run_lib  # noqa: E402
+from id_diff_amd.configs.utils import read_config  # noqa: E402
+
+_HOT_MODES = ('manifold_dimension', 'conditional_manifold_dimension')
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--config", required=True, help="Training configuration path (.py or .pkl).")
+    ap.add_argument("--checkpoint_path", default=None)
+    ap.add_argument("--data_path", default=None)
+    ap.add_argument("--log_path", default="./")
+    ap.add_argument("--mode", required=True)
+    ap.add_argument("--eval_folder", default="eval")
+    ap.add_argument("--debug", action="store_true")
+    ap.add_argument("--log_name", default=None)
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    flags = parse(argv)
+    if flags.config.endswith('pkl'):
+        with open(flags.config, 'rb') as f:
+            config = pickle.load(f)
+    elif flags.config.endswith('py'):
+        config = read_config(flags.config)
+    else:
+        raise RuntimeError('Unknown config extension. Provide a path to .py or .pkl file.')
+    if flags.checkpoint_path is not None:
+        config.model.checkpoint_path = flags.checkpoint_path
+    if flags.mode not in _HOT_MODES:
+        raise SystemExit(f"mode {flags.mode!r} is outside the scope of id-diff_amd (the MI355X build covers "
+                         f"{', '.join(_HOT_MODES)}); use the reference for training / sampling / evaluation")
+    rank, world, local_rank = parallel.init_from_env()
+    if world > 1:
+        config.device = f"cuda:{local_rank}"
+    if flags.mode == 'manifold_dimension':
+        run_lib.get_manifold_dimension(config, name=flags.log_name)
+    else:
+        run_lib.get_conditional_manifold_dimension(config, name=flags.log_name)
+
+
+if __name__ == "__main__":
+    main()

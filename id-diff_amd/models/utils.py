@@ -1,0 +1,67 @@
+"""Model registry and the score-function wrapper (drop-in for /root/reference/models/utils.py).
+
+``get_score_fn(sde, model, conditional=False, train=False, continuous=True)`` returns ``score_fn(x, t)``
+with the reference's semantics for the unconditional continuous branch (models/utils.py:236-282):
+
+    labels = t * (sde.N - 1);  out = model.eval()(x, labels);  std = sde.marginal_prob(0, t)[1]
+    score  = -out / std[:, None, ...]
+
+The HIP models fuse the final ``-1/std`` scaling into their last kernel (``forward(..., out_rowscale=)``),
+so the division never costs a separate pass over HBM.
+"""
+import torch
+
+_MODELS = {}
+
+
+def register_model(cls=None, *, name=None):
+    """Decorator registering a model class under ``name`` (models/utils.py:27-43)."""
+
+    def _register(cls):
+        local_name = cls.__name__ if name is None else name
+        if local_name in _MODELS:
+            raise ValueError(f'Already registered model with name: {local_name}')
+        _MODELS[local_name] = cls
+        return cls
+
+    return _register if cls is None else _register(cls)
+
+
+def get_model(name):
+    return _MODELS[name]
+
+
+def create_model(config):
+    """models/utils.py:114-120."""
+    return get_model(config.model.name)(config)
+
+
+def get_model_fn(model, train=False):
+    """models/utils.py:123-152; the HIP models are inference-only, so ``train=True`` is refused."""
+    if train:
+        raise NotImplementedError("id-diff_amd models are forward-only (manifold_dimension path)")
+
+    def model_fn(x, labels):
+        model.eval()
+        return model(x, labels)
+
+    return model_fn
+
+
+def get_score_fn(sde, model, conditional=False, train=False, continuous=True):
+    from .. import sde_lib
+    if conditional:
+        raise NotImplementedError("conditional score estimators are outside the manifold_dimension path")
+    if not continuous:
+        raise NotImplementedError("only continuously-trained models are on the manifold_dimension path")
+    if not isinstance(sde, (sde_lib.VESDE, sde_lib.VPSDE)):
+        raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+    get_model_fn(model, train=train)
+
+    def score_fn(x, t):
+        labels = t * (sde.N - 1)
+        std = sde.marginal_prob(torch.zeros((), device=t.device), t)[1]
+        model.eval()
+        return model(x, labels, out_rowscale=-1.0 / std)
+
+    return score_fn

@@ -1,0 +1,64 @@
+"""Sharding of data points over the GPUs of one node and the single exchange step.
+
+One process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for the
+tests).  Data points are independent (dim_reduction.py:162-202 appends independent lists), so point ``p`` goes
+to rank ``p % world`` and the only collective on the path is one all-gather of the per-rank singular spectra
+(``[points_per_rank, n_sv]`` fp32, a few MB at most: latency-bound on the xGMI mesh).  The reference has no
+multi-device path; this file is new work scoped by SURVEY.md 8(e).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* if they are set."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, 0
+    rank = int(os.environ["RANK"])
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def my_points(num_points, rank, world):
+    """Indices of the points this rank owns: round-robin, so results do not depend on the world size."""
+    return list(range(rank, num_points, world))
+
+
+def gather_spectra(local, num_points, n_sv, device):
+    """All-gather per-rank spectra into point order.
+
+    ``local``: [len(my_points), n_sv] fp32 on ``device``.  Ranks may own one point fewer than rank 0; rows are
+    padded to ``ceil(num_points / world)`` so a single fixed-size all-gather suffices.
+    """
+    rank, world = rank_world()
+    if world == 1:
+        return local
+    per = (num_points + world - 1) // world
+    send = torch.zeros(per, n_sv, dtype=torch.float32, device=device)
+    if local.numel():
+        send[: local.shape[0]] = local
+    recv = torch.empty(world * per, n_sv, dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    recv = recv.view(world, per, n_sv)
+    out = torch.empty(num_points, n_sv, dtype=torch.float32, device=device)
+    for r in range(world):
+        idx = my_points(num_points, r, world)
+        if idx:
+            out[idx] = recv[r, : len(idx)]
+    return out

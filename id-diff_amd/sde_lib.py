@@ -1,0 +1,52 @@
+"""SDE perturbation kernels used by the manifold_dimension path (host-side scalars + tiny device vectors).
+
+Mirrors /root/reference/sde_lib.py: ``VESDE`` (:316-347) and ``VPSDE`` (:222-252), ``marginal_prob`` only --
+the reverse SDE, discretisation and priors belong to sampling/training and are out of scope.
+The per-sample std vector has B entries; it is produced with torch elementwise ops on the device the time
+vector lives on (plumbing, a few hundred bytes) and consumed by the fused HIP kernels.
+"""
+import torch
+
+
+class SDE:
+    def __init__(self, N):
+        self.N = N
+
+    @property
+    def T(self):
+        return 1
+
+
+class VESDE(SDE):
+    def __init__(self, sigma_min=0.01, sigma_max=50, N=1000, data_mean=None):
+        super().__init__(N)
+        self.sigma_min, self.sigma_max = sigma_min, sigma_max
+        self.diffused_mean = data_mean
+
+    def marginal_prob(self, x, t):
+        lo = torch.tensor(self.sigma_min).type_as(t)
+        hi = torch.tensor(self.sigma_max).type_as(t)
+        return x, lo * (hi / lo) ** t
+
+
+class VPSDE(SDE):
+    def __init__(self, beta_min=0.1, beta_max=20, N=1000):
+        super().__init__(N)
+        self.beta_0, self.beta_1 = beta_min, beta_max
+
+    def marginal_prob(self, x, t):
+        log_mean_coeff = -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        mean = torch.exp(log_mean_coeff).reshape((-1,) + (1,) * (x.ndim - 1)) * x
+        return mean, torch.sqrt(1. - torch.exp(2. * log_mean_coeff))
+
+
+def configure_sde(config):
+    """(sde, sampling_eps) exactly as BaseSdeGenerativeModel.configure_sde (lightning_modules/BaseSdeGenerativeModel.py:27-47)."""
+    kind = config.training.sde.lower()
+    if kind == "vesde":
+        if config.data.get("use_data_mean", False):
+            raise NotImplementedError("data.use_data_mean needs the authors' datasets_mean/*.pt files")
+        return VESDE(sigma_min=config.model.sigma_min, sigma_max=config.model.sigma_max, N=config.model.num_scales), 1e-5
+    if kind == "vpsde":
+        return VPSDE(beta_min=config.model.beta_min, beta_max=config.model.beta_max, N=config.model.num_scales), 1e-3
+    raise NotImplementedError(f"SDE {config.training.sde} unknown.")

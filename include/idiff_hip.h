@@ -1,0 +1,166 @@
+/*
+ * idiff_hip.h -- C ABI of libidiff_hip.so, the gfx950 (MI355X) kernels behind the
+ * manifold_dimension hot path of GBATZOLIS/ID-diff.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer (HBM) unless named h_*; the library never
+ *     allocates, frees or synchronises: the caller owns all buffers and passes the
+ *     hipStream_t (as void*) the work is enqueued on.  Re-entrant, no global state.
+ *   - Return value: 0 on success, otherwise a hipError_t (launch failure) or
+ *     IDIFF_EINVAL (1001) for an argument the kernels cannot take; idiff_last_error()
+ *     gives a thread-local message.
+ *   - "Replaces" names the reference interface (file:line under GBATZOLIS/ID-diff)
+ *     that the entry point stands in for.
+ */
+#ifndef IDIFF_HIP_H
+#define IDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDIFF_EINVAL 1001
+#define IDIFF_ABI_VERSION 1
+
+int idiff_abi_version(void);
+const char *idiff_last_error(void);
+
+/* ------------------------------------------------------------------ native ops (op/) */
+
+/* Replaces the pybind entry `upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+ * pad_y0, pad_y1)` of op/upfirdn2d.cpp:12-19 (host op op/upfirdn2d_kernel.cu:209-369).
+ * x is [major, in_h, in_w, minor] fp32 contiguous, k is [kh, kw] fp32 (NOT flipped: the op is a true
+ * convolution, the kernel flips), out is [major, out_h, out_w, minor] with
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kh)/down_y + 1 (op/upfirdn2d_kernel.cu:237-240).
+ * minor = 1 is the NCHW view the reference uses (op/upfirdn2d.py:99); minor = C serves NHWC activations. */
+int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, int major, int in_h, int in_w, int minor,
+                        int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                        int pad_y0, int pad_y1, void *stream);
+
+/* Replaces `fused_bias_act(input, bias, refer, act, grad, alpha, scale)` of op/fused_bias_act.cpp:11-17
+ * (kernel op/fused_bias_act_kernel.cu:18-49).  out[i] = f(x[i] + b[(i/step_b) % size_b]) * scale with
+ * act*10+grad in {10,11: identity; 12,32: 0; 30: x>0?x:x*alpha; 31: ref>0?x:x*alpha}.  b may be NULL
+ * (size_b = 0), ref may be NULL unless grad = 1. */
+int idiff_fused_bias_act_f32(const float *x, const float *b, const float *ref, float *out, int64_t n,
+                             int step_b, int size_b, int act, int grad, float alpha, float scale, void *stream);
+
+/* ------------------------------------------------------------------ dense contractions (fp32 MFMA) */
+
+/* Activation codes shared by the epilogues below. */
+#define IDIFF_ACT_NONE 0
+#define IDIFF_ACT_SILU 1
+#define IDIFF_ACT_ELU 2
+#define IDIFF_ACT_RELU 3
+#define IDIFF_ACT_LRELU 4 /* slope 0.2, models/layers.py:36 */
+
+/* Epilogue applied by idiff_gemm_f32 / idiff_conv2d_nhwc_f32 to every accumulator element (m, n):
+ *   v = acc + bias[n] + rowbias[(m / rows_per_group) * ld_rowbias + n]
+ *   v = act(v)
+ *   v = (v + residual[m * ld_residual + n]) * out_scale          (residual optional)
+ *   v = v * rowscale[m / rows_per_group]                          (optional, e.g. -1/std[b]: models/utils.py:266-267)
+ *   out[m * ldc + n] = v
+ * NULL pointers drop the corresponding term.  This is what lets one launch produce
+ * `Conv_0(h) + Dense_0(act(temb))[:, :, None, None]` (models/layerspp.py:256-259) or
+ * `(x + Conv_1(h)) / sqrt(2)` (:262-273) without extra passes over HBM. */
+typedef struct idiff_epilogue {
+  const float *bias;      /* [N] or NULL */
+  const float *rowbias;   /* [M / rows_per_group, ld_rowbias] or NULL */
+  int64_t ld_rowbias;
+  int rows_per_group;     /* e.g. H*W for a per-sample time-embedding bias */
+  int act;                /* IDIFF_ACT_* */
+  const float *residual;  /* [M, ld_residual] or NULL */
+  int64_t ld_residual;
+  float out_scale;        /* 1.0f for none */
+  const float *rowscale;  /* [M / rows_per_group] or NULL */
+} idiff_epilogue;
+
+/* Batched C[b] = epilogue(A[b] (M x K, row-major, lda) * Bt[b]^T (Bt is N x K, row-major, ldb)).
+ * Replaces torch.nn.Linear (models/fcn.py:18-28), NIN / 1x1 conv contractions (models/layers.py:555-564),
+ * and the two attention einsums of models/layerspp.py:82-86.  Exact fp32 (v_mfma_f32_32x32x2_f32).
+ * batch strides are in elements; a stride of 0 broadcasts that operand.  The epilogue pointers are
+ * shared by all batch entries. */
+int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt, int64_t ldb, int64_t strideB,
+                   float *C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch,
+                   const idiff_epilogue *ep, void *stream);
+
+/* 2-D convolution, NHWC activations: x [B, H, W, Cin] (Cin % 4 == 0), weights packed as
+ * wt [Cout, KH, KW, Cin] (= the reference's [Cout, Cin, KH, KW] nn.Conv2d weight permuted once at load),
+ * out [B, OH, OW, Cout] with OH = (H + pad_lo + pad_hi - KH)/stride + 1 (pad_lo on top/left, pad_hi on
+ * bottom/right: the non-FIR Downsample pads (0, 1), models/layerspp.py:153-155).  Implicit GEMM with M = B*OH*OW,
+ * N = Cout, K = KH*KW*Cin on the same MFMA core as idiff_gemm_f32; zero padding.
+ * Replaces F.conv2d behind ddpm_conv3x3 / ddpm_conv1x1 (models/layers.py:100-132) and the stride-2 VALID
+ * conv of conv_downsample_2d (models/up_or_down_sampling.py:178).  rows_per_group in the epilogue counts
+ * OUTPUT pixels (OH*OW for a per-sample bias). */
+int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out, int B, int H, int W, int Cin, int Cout,
+                          int KH, int KW, int stride, int pad_lo, int pad_hi, const idiff_epilogue *ep, void *stream);
+
+/* ------------------------------------------------------------------ normalisation / pointwise (HBM-bound) */
+
+/* GroupNorm statistics over NHWC x [B, HW, C] with G groups: stats[b, g] = {mean, rstd}, biased variance,
+ * rstd = 1/sqrt(var + eps) (torch.nn.GroupNorm as used at models/layerspp.py:219,231).  fp64 accumulation.
+ * `x2`/`C2` describe an optional second source whose channels are appended to x's (the skip tensor of
+ * torch.cat([h, hs.pop()], 1), models/ncsnpp.py:324) so the concatenation is never materialised for the norm;
+ * groups must not straddle the two sources.  workspace: >= B * nsplit * (C + C2) * 2 doubles, nsplit as
+ * returned by idiff_groupnorm_nsplit. */
+int idiff_groupnorm_nsplit(int B, int HW, int C);
+int idiff_groupnorm_stats_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G, float eps,
+                              double *workspace, float *stats, void *stream);
+/* y[b, p, c] = act((x - mean) * rstd * gamma[c] + beta[c]); writes channel-concatenated output [B, HW, C+C2]. */
+int idiff_groupnorm_apply_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G,
+                              const float *stats, const float *gamma, const float *beta, int act, float *y,
+                              void *stream);
+
+/* Row softmax of x [rows, cols] scaled by `scale` before the exponent (layerspp.py:82-84). In place allowed. */
+int idiff_softmax_rows_f32(const float *x, float *y, int64_t rows, int cols, float scale, void *stream);
+
+/* y = act(a * alpha + beta_const) elementwise; covers `2*x - 1` (models/ncsnpp.py:264-266), SiLU/ELU of the
+ * time embedding, and -out/std when `rowscale` ([n / inner]) is given: y = act(...) * rowscale[i / inner]. */
+int idiff_affine_act_f32(const float *a, float *y, int64_t n, float alpha, float beta_const, int act,
+                         const float *rowscale, int64_t inner, void *stream);
+/* y = (a + b) * scale (skip-rescale adds, models/ncsnpp.py:303-307). */
+int idiff_add_scale_f32(const float *a, const float *b, float *y, int64_t n, float scale, void *stream);
+/* Gaussian Fourier features: out[b] = [sin(2*pi*t[b]*W), cos(2*pi*t[b]*W)] (models/layerspp.py:39-41). */
+int idiff_fourier_embed_f32(const float *t, const float *W, float *out, int B, int half, void *stream);
+/* Sinusoidal positional embedding (models/layers.py:524-538), dim even. */
+int idiff_positional_embed_f32(const float *t, float *out, int B, int dim, float max_positions, void *stream);
+/* out[r, :] = cat(a[r, :Ca], b[r, :Cb]) for r < rows (channel concat of NHWC tensors / fcn's cat([x, t])). */
+int idiff_concat_cols_f32(const float *a, int Ca, const float *b, int Cb, float *out, int64_t rows, void *stream);
+/* Layout changes at the model boundary: NCHW [B, C, HW] <-> NHWC [B, HW, Cpad] (zero-filled pad channels),
+ * with an optional affine on the way in (alpha * x + beta) and a per-sample scale on the way out. */
+int idiff_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int HW, int Cpad, float alpha, float beta,
+                           void *stream);
+int idiff_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int HW, int Cpad, const float *rowscale,
+                           void *stream);
+/* Perturbation of one data point into `rows` noisy copies (dim_reduction.py:178-182):
+ * out[r, :] = mean_coeff[r] * x[:] + std[r] * z[r, :]; mean_coeff NULL means 1 (VE SDE, sde_lib.py:346). */
+int idiff_perturb_f32(const float *x, const float *z, const float *std_, const float *mean_coeff, float *out,
+                      int64_t rows, int64_t D, void *stream);
+/* Nearest x2 upsample / 2x2 mean downsample of NHWC tensors (naive_upsample_2d / naive_downsample_2d,
+ * models/up_or_down_sampling.py:59-69; BeatGANs Upsample/Downsample, models/BeatGANsblocks.py:335-396). */
+int idiff_resample2x_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, int up, void *stream);
+
+/* ------------------------------------------------------------------ spectrum of the centred score matrix */
+
+/* Replaces `scores - scores.mean(0)` + `torch.linalg.svd(...)` of dim_reduction.py:193-198 for a batch of P
+ * score matrices S[p] (M x D fp32, row-major, contiguous): singular values, descending, min(M, D) of them
+ * (M >= D required).  Method: fp64 column means -> fp64 Gram of the centred columns on v_mfma_f64_16x16x4 ->
+ * Householder tridiagonalisation (fp64) -> Sturm bisection -> sqrt.  Products of fp32 inputs are exact in
+ * fp64, so the squared condition number costs nothing at the 1e-4 tolerance.
+ * workspace: idiff_spectrum_workspace_bytes(P, M, D) bytes; sv: [P, D] fp32.
+ * `eig_out` (optional, [P, D] fp64) receives the Gram eigenvalues (ascending) for diagnosis. */
+int64_t idiff_spectrum_workspace_bytes(int P, int M, int D);
+int idiff_spectrum_f32(const float *S, int P, int M, int D, void *workspace, int64_t workspace_bytes, float *sv,
+                       double *eig_out, void *stream);
+/* The stages, exported for the parity tests and the profiler. */
+/* scratch: P * 32 * D doubles (deterministic two-stage column sums). */
+int idiff_colmean_f64(const float *S, int P, int M, int D, double *mean, double *scratch, void *stream);
+int idiff_centered_gram_f64(const float *S, const double *mean, int P, int M, int D, double *G, void *stream);
+int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double *offdiag, double *scratch, void *stream);
+int idiff_tridiag_eigvals_f64(const double *diag, const double *offdiag, int P, int D, double *eig, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDIFF_HIP_H */

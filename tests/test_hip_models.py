@@ -1,0 +1,160 @@
+"""GPU parity of the score networks and of the whole ID pipeline against the oracle / the reference's golden outputs."""
+import numpy as np
+import pytest
+import torch
+
+import id_diff_amd
+from helpers import fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden, rel_err
+from id_diff_amd import _lib, dim_reduction, plot_utils, sde_lib
+from id_diff_amd.configs.utils import read_config
+from id_diff_amd.models import utils as mutils
+from oracle import dim as odim, ksphere as oks, models as omodels, sde as osde
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+# fp32 networks evaluated with a different (but exact-fp32) summation order than ATen's CPU kernels
+NET_RTOL = 2e-5
+
+
+def test_fcn_tiny_golden(golden):
+    z = golden("fcn_tiny.npz")
+    model = mutils.create_model(fcn_config(hidden_nodes=64))
+    model.load_state_dict(state_dict_from_golden(z))
+    model.to(DEV)
+    score_fn = mutils.get_score_fn(sde_lib.VESDE(1e-2, 4, 1000), model, conditional=False, train=False, continuous=True)
+    y = score_fn(torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV))
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+
+
+def test_fcn_full_size_golden(golden):
+    z = golden("fcn_full_seed0.npz")
+    torch.manual_seed(0)
+    model = mutils.create_model(fcn_config(hidden_nodes=2048))   # same nn.Linear construction order as the reference
+    sums = np.array([float(v.double().abs().sum()) for v in model.state_dict().values()])
+    np.testing.assert_allclose(sums, z["weight_abs_sums"], rtol=1e-12)
+    model.to(DEV)
+    score_fn = mutils.get_score_fn(sde_lib.VESDE(1e-2, 4, 1000), model)
+    y = score_fn(torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV))
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+
+
+@pytest.mark.parametrize("variant", ["bench_init0", "bench_init1", "ddpm_outskip", "biggan_nofir", "biggan_outskip_sum"])
+def test_ncsnpp_golden(golden, variant):
+    z = golden(f"ncsnpp_{variant}.npz")
+    model = mutils.create_model(ncsnpp_config(**overrides_from_golden(z)))
+    model.load_state_dict(state_dict_from_golden(z))
+    model.to(DEV)
+    x, t = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV)
+    raw = model(x, t * 999)
+    assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
+    y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x, t)
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+
+
+def test_ncsnpp_benchmark_width_vs_oracle():
+    """nf=128 benchmark architecture with every branch active, B=4."""
+    cfg = read_config('configs/dimension_estimation/paper/image_data/cifar_shaped/ncsnpp.py')
+    cfg.model.init_scale = 1.0
+    torch.manual_seed(0)
+    ref_model = omodels.create_model(cfg)
+    model = mutils.create_model(cfg)
+    model.load_state_dict(ref_model.state_dict())
+    model.to(DEV)
+    g = torch.Generator().manual_seed(1)
+    x, t = torch.rand(4, 3, 32, 32, generator=g), torch.tensor([1e-5, 1e-5, 0.1, 0.5])
+    with torch.no_grad():
+        ref = osde.get_score_fn(osde.VESDE(0.01, 50, 1000), ref_model)(x, t)
+    y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x.to(DEV), t.to(DEV))
+    assert rel_err(y.cpu(), ref) < NET_RTOL
+
+
+def test_batch_size_is_not_observable():
+    """Rows are independent samples: evaluating 5 rows at once or one by one gives the same scores (design premise
+    of the inflight batching in dim_reduction.py)."""
+    z_cfg = ncsnpp_config(**{"model.init_scale": 1.0})
+    torch.manual_seed(3)
+    model = mutils.create_model(z_cfg).to(DEV)
+    x, t = torch.rand(5, 3, 32, 32, device=DEV), torch.full((5,), 1e-5 * 999, device=DEV)
+    full = model(x, t)
+    for i in range(5):
+        assert rel_err(model(x[i:i + 1].contiguous(), t[i:i + 1].contiguous()).cpu(), full[i:i + 1].cpu()) < 1e-5
+
+
+def _pipeline_pair(score_fn_hip, score_fn_cpu, sde_hip, sde_cpu, x, batchsize, eps):
+    num_batches, _, rows = odim.batching(tuple(x.shape), batchsize)
+    g = torch.Generator().manual_seed(7)
+    noise = torch.randn(num_batches, batchsize, *x.shape, generator=g)
+    S_ref = odim.score_matrix(score_fn_cpu, sde_cpu, x, batchsize, eps, noise=noise)
+    builder = dim_reduction.ScoreMatrixBuilder(score_fn_hip, sde_hip, eps, torch.device(DEV))
+    flat_noise = noise.reshape(num_batches * batchsize, *x.shape)[:rows].to(DEV)
+    S = builder.build(x.to(DEV), batchsize, noise=flat_noise)
+    return S, S_ref
+
+
+def test_score_matrix_and_spectrum_fcn_vs_oracle():
+    """BASELINE config 2 recipe (50-sphere, fcn 2048x5, B=500 -> S 1501x100) end to end on identical noise."""
+    torch.manual_seed(0)
+    cfg = fcn_config(hidden_nodes=2048)
+    ref_model = omodels.create_model(cfg)
+    model = mutils.create_model(cfg)
+    model.load_state_dict(ref_model.state_dict())
+    model.to(DEV)
+    torch.manual_seed(42)
+    x = oks.ksphere_data(4, 100, 50)[1]
+    sde_c, sde_h = osde.VESDE(1e-2, 4, 1000), sde_lib.VESDE(1e-2, 4, 1000)
+    S, S_ref = _pipeline_pair(mutils.get_score_fn(sde_h, model), osde.get_score_fn(sde_c, ref_model), sde_h, sde_c, x, 500, 1e-5)
+    assert S.shape == (1501, 100) and rel_err(S.cpu(), S_ref) < NET_RTOL
+    sv = _lib.spectrum(S).cpu()
+    ref = odim.spectrum(S_ref)
+    np.testing.assert_allclose(sv.numpy(), ref.numpy(), rtol=1e-4)
+    assert plot_utils.estimate_dim(sv.tolist()) == odim.estimate_dim(ref.tolist())
+
+
+def test_score_matrix_and_spectrum_ncsnpp_small_vs_oracle():
+    """Image recipe at reduced width (nf=8) and B=32 -> S 1056... rows x 3072 cols needs M >= D, so use 16x16 images."""
+    cfg = ncsnpp_config(**{"model.init_scale": 1.0, "model.attn_resolutions": (8,), "data.image_size": 16,
+                           "data.effective_image_size": 16, "data.shape": [3, 16, 16], "model.num_res_blocks": 1})
+    torch.manual_seed(0)
+    ref_model = omodels.create_model(cfg)
+    model = mutils.create_model(cfg)
+    model.load_state_dict(ref_model.state_dict())
+    model.to(DEV)
+    x = torch.rand(3, 16, 16, generator=torch.Generator().manual_seed(1))
+    sde_c, sde_h = osde.VESDE(0.01, 50, 1000), sde_lib.VESDE(0.01, 50, 1000)
+    S, S_ref = _pipeline_pair(mutils.get_score_fn(sde_h, model), osde.get_score_fn(sde_c, ref_model), sde_h, sde_c, x, 100, 1e-5)
+    assert S.shape == (1156, 768) and rel_err(S.cpu(), S_ref) < 5e-5   # (256//100+1)*4=12 batches, extra 56
+    sv = _lib.spectrum(S).cpu()
+    ref64 = odim.spectrum_f64(S_ref)
+    keep = ref64 > 2e-5 * ref64[0]
+    np.testing.assert_allclose(sv.numpy()[keep], odim.spectrum(S_ref).numpy()[keep], rtol=1e-4)
+
+
+@pytest.mark.parametrize("k", [10, 50])
+def test_id_recovered_on_ksphere_end_to_end(k, tmp_path):
+    """North-star acceptance: the drop-in driver on the GPU recovers ID = k on the k-sphere in R^100."""
+    cfg = read_config(f'configs/dimension_estimation/paper/euclidean_data/ksphere/{k}dim.py')
+    cfg.model.name = 'ksphere_exact'
+    cfg.data.data_samples = 2000
+    cfg.device = DEV
+    cfg.logging.log_path = str(tmp_path)
+    svd = dim_reduction.get_manifold_dimension(cfg, return_svd=True)
+    assert len(svd['singular_values']) == 4 and len(svd['singular_values'][0]) == 100   # svd_points=5 -> 4 points
+    assert plot_utils.plot_dims(svd)[1] == [k] * 4
+    # pickle layout of the non-returning form (dim_reduction.py:206-211)
+    dim_reduction.get_manifold_dimension(cfg, name='svd_test')
+    import pickle, os
+    with open(os.path.join(str(tmp_path), cfg.logging.log_name, 'svd', 'svd_test.pkl'), 'rb') as f:
+        again = pickle.load(f)
+    assert again['singular_values'] == svd['singular_values']          # per-point seeds: reproducible
+
+
+def test_exact_score_vs_oracle():
+    cfg = read_config('configs/dimension_estimation/paper/euclidean_data/ksphere/10dim.py')
+    cfg.model.name = 'ksphere_exact'
+    model = mutils.create_model(cfg).to(DEV)
+    torch.manual_seed(42)
+    x = oks.ksphere_data(64, 100, 10) + 0.01 * torch.randn(64, 100)
+    t = torch.full((64,), 1e-5)
+    ref = osde.get_score_fn(osde.VESDE(1e-2, 4, 1000), oks.KSphereExact(100, 10, 1e-2, 4))(x, t)
+    y = mutils.get_score_fn(sde_lib.VESDE(1e-2, 4, 1000), model)(x.to(DEV), t.to(DEV))
+    assert rel_err(y.cpu(), ref) < 1e-4

@@ -1,0 +1,235 @@
+"""GPU parity of the HIP kernels against the CPU oracle, through the C-ABI (python -m pytest -m gpu)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import id_diff_amd
+from helpers import rel_err
+from id_diff_amd import _lib, op
+from oracle import ops as oops, dim as odim
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_native_library_is_the_one_in_tree():
+    import os
+    assert os.path.samefile(_lib.library_path(), os.path.join(os.path.dirname(id_diff_amd.__file__), "csrc", "libidiff_hip.so"))
+    assert _lib.lib().idiff_abi_version() == 1
+
+
+# ------------------------------------------------------------------ upfirdn2d
+def test_upfirdn2d_golden(golden):
+    z = golden("upfirdn2d.npz")
+    for i in range(int(z["n_cases"])):
+        up, down, p0, p1 = (int(v) for v in z[f"c{i}::params"])
+        y = op.upfirdn2d(torch.from_numpy(z[f"c{i}::x"]).to(DEV), torch.from_numpy(z[f"c{i}::k"]).to(DEV), up=up,
+                         down=down, pad=(p0, p1))
+        ref = torch.from_numpy(z[f"c{i}::y"])
+        assert y.shape == ref.shape, i
+        torch.testing.assert_close(y.cpu(), ref, rtol=1e-5, atol=1e-6, msg=f"case {i}")
+    from id_diff_amd.op.upfirdn2d import upfirdn2d_xy
+    ux, uy, dx, dy, px0, px1, py0, py1 = (int(v) for v in z["xy::params"])
+    y = upfirdn2d_xy(torch.from_numpy(z["xy::x"]).to(DEV), torch.from_numpy(z["xy::k"]).to(DEV), ux, uy, dx, dy, px0,
+                     px1, py0, py1)
+    torch.testing.assert_close(y.cpu(), torch.from_numpy(z["xy::y"]), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,up,down,pad", [
+    ((128, 128, 32, 32), 1, 2, (1, 1)),   # ncsnpp downsample_2d at BASELINE size
+    ((128, 256, 16, 16), 2, 1, (2, 1)),   # upsample_2d
+    ((128, 3, 32, 32), 1, 1, (2, 2)),     # FIR before the stride-2 conv
+    ((3, 5, 70, 130), 1, 2, (1, 1)),      # several tiles per plane, ragged edges
+    ((2, 3, 37, 129), 2, 3, (3, 0)),
+])
+def test_upfirdn2d_nchw_vs_oracle(shape, up, down, pad):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(*shape, generator=g)
+    k = torch.randn(4, 4, generator=g)
+    ref = oops.upfirdn2d(x, k, up=up, down=down, pad=pad)
+    y = op.upfirdn2d(x.to(DEV), k.to(DEV), up=up, down=down, pad=pad)
+    assert rel_err(y.cpu(), ref) < 1e-6
+
+
+@pytest.mark.parametrize("C", [4, 8, 128, 3])
+@pytest.mark.parametrize("mode", [(1, 2, 1, 1), (2, 1, 2, 1), (1, 1, 2, 2)])
+def test_upfirdn2d_nhwc_minor(C, mode):
+    """minor = C path (NHWC activations) against the NCHW oracle."""
+    up, down, p0, p1 = mode
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, C, 12, 10, generator=g)
+    k = torch.randn(4, 4, generator=g)
+    ref = oops.upfirdn2d(x, k, up=up, down=down, pad=(p0, p1))
+    xh = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    oh, ow = ref.shape[2:]
+    out = torch.empty(3, oh, ow, C, device=DEV)
+    _lib.upfirdn2d_raw(xh, k.to(DEV), out, 3, 12, 10, C, up, up, down, down, p0, p1, p0, p1)
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 1e-6
+
+
+def test_upfirdn2d_properties_full_size():
+    """Size-independent checks at BASELINE size: linearity and the constant-image gain of the normalised FIR."""
+    k = torch.tensor(np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0, dtype=torch.float32, device=DEV)
+    a = torch.randn(128, 128, 32, 32, device=DEV)
+    b = torch.randn(128, 128, 32, 32, device=DEV)
+    f = lambda t: op.upfirdn2d(t, k, down=2, pad=(1, 1))
+    torch.testing.assert_close(f(a + 2 * b), f(a) + 2 * f(b), rtol=1e-4, atol=1e-5)
+    ones = torch.ones(2, 2, 32, 32, device=DEV)
+    assert torch.allclose(f(ones)[:, :, 1:-1, 1:-1], torch.ones(2, 2, 14, 14, device=DEV), atol=1e-6)
+    up = op.upfirdn2d(ones, k * 4, up=2, pad=(2, 1))
+    assert up.shape == (2, 2, 64, 64) and torch.allclose(up[:, :, 2:-2, 2:-2], torch.ones(2, 2, 60, 60, device=DEV), atol=1e-6)
+
+
+def test_upfirdn2d_errors():
+    with pytest.raises(RuntimeError):
+        op.upfirdn2d(torch.zeros(1, 1, 2, 2, device=DEV), torch.ones(5, 5, device=DEV))      # kernel > padded input
+    with pytest.raises(RuntimeError):
+        op.upfirdn2d(torch.zeros(1, 2, 2, device=DEV), torch.ones(2, 2, device=DEV))          # not 4-D
+
+
+# ------------------------------------------------------------------ fused_bias_act
+def test_fused_leaky_relu_golden(golden):
+    z = golden("fused_act.npz")
+    for i in range(int(z["n_cases"])):
+        x, b = torch.from_numpy(z[f"c{i}::x"]).to(DEV), torch.from_numpy(z[f"c{i}::b"]).to(DEV)
+        torch.testing.assert_close(op.fused_leaky_relu(x, b).cpu(), torch.from_numpy(z[f"c{i}::y_default"]), rtol=1e-6, atol=1e-7)
+        # GPU branch honours negative_slope (the reference's CUDA kernel does; its CPU branch does not)
+        y = op.fused_leaky_relu(x, b, negative_slope=0.05, scale=1.25).cpu()
+        ref = oops.fused_bias_act_ref(x.cpu(), b.cpu(), None, 3, 0, 0.05, 1.25)
+        torch.testing.assert_close(y, ref, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 32, 32), (128, 256, 4, 4), (7, 5, 3), (4, 6)])
+@pytest.mark.parametrize("act,grad", [(3, 0), (3, 1), (3, 2), (1, 0), (1, 1), (1, 2)])
+def test_fused_bias_act_modes(shape, act, grad):
+    from id_diff_amd.op.fused_act import fused_bias_act
+    g = torch.Generator().manual_seed(3)
+    x, b, r = torch.randn(*shape, generator=g), torch.randn(shape[1], generator=g), torch.randn(*shape, generator=g)
+    ref = oops.fused_bias_act_ref(x, b, r, act, grad, 0.2, 2 ** 0.5)
+    y = fused_bias_act(x.to(DEV), b.to(DEV), r.to(DEV), act, grad, 0.2, 2 ** 0.5)
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-6, atol=1e-7)
+    y0 = fused_bias_act(x.to(DEV), x.new_empty(0).to(DEV), r.to(DEV), act, grad, 0.2, 1.0)   # empty bias, as backward passes it
+    torch.testing.assert_close(y0.cpu(), oops.fused_bias_act_ref(x, None, r, act, grad, 0.2, 1.0), rtol=1e-6, atol=1e-7)
+
+
+def test_fused_module_and_empty_input():
+    m = op.FusedLeakyReLU(6).to(DEV)
+    x = torch.randn(2, 6, 5, device=DEV)
+    torch.testing.assert_close(m(x).cpu(), F.leaky_relu(x.cpu(), 0.2) * 2 ** 0.5, rtol=1e-6, atol=1e-7)
+    assert op.fused_leaky_relu(torch.zeros(0, 6, 5, device=DEV), m.bias.detach()).shape == (0, 6, 5)
+
+
+# ------------------------------------------------------------------ gemm / conv
+@pytest.mark.parametrize("M,N,K", [(500, 2048, 104), (2000, 2048, 2048), (128, 512, 256), (37, 100, 2048),
+                                   (1, 7, 5), (300, 65, 101), (4096, 128, 1152)])
+@pytest.mark.parametrize("act", [None, "elu", "silu"])
+def test_gemm_vs_cpu(M, N, K, act):
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    ref = a.double() @ w.double().T + b.double()
+    ref = {None: lambda v: v, "elu": F.elu, "silu": F.silu}[act](ref)
+    y = _lib.gemm(a.to(DEV), w.to(DEV), epilogue=_lib.make_epilogue(bias=b.to(DEV), act=act))
+    assert rel_err(y.cpu(), ref) < 2e-6   # fp32 fmaf chain vs fp64
+
+
+def test_gemm_epilogue_terms():
+    g = torch.Generator().manual_seed(5)
+    M, N, K, grp = 96, 40, 64, 32
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    rb, res, rsc = torch.randn(M // grp, N, generator=g), torch.randn(M, N, generator=g), torch.rand(M // grp, generator=g) + .5
+    ref = ((a @ w.T + rb.repeat_interleave(grp, 0)) + res) * 0.5 * rsc.repeat_interleave(grp)[:, None]
+    y = _lib.gemm(a.to(DEV), w.to(DEV), epilogue=_lib.make_epilogue(rowbias=rb.to(DEV), rows_per_group=grp,
+                                                                    residual=res.to(DEV), out_scale=0.5, rowscale=rsc.to(DEV)))
+    assert rel_err(y.cpu(), ref) < 2e-6
+
+
+def test_gemm_batched_strided():
+    g = torch.Generator().manual_seed(6)
+    B, HW, C = 3, 64, 16
+    qk = torch.randn(B * HW, 2 * C, generator=g)
+    ref = torch.einsum("bqc,bkc->bqk", qk[:, :C].reshape(B, HW, C), qk[:, C:].reshape(B, HW, C))
+    d = qk.to(DEV)
+    out = torch.empty(B, HW, HW, device=DEV)
+    _lib.gemm(d, d[:, C:], out=out, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B, stride_a=HW * 2 * C,
+              stride_b=HW * 2 * C, stride_c=HW * HW)
+    assert rel_err(out.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad,pad_hi", [
+    (4, 32, 32, 128, 128, 3, 1, 1, None), (2, 16, 16, 256, 256, 3, 1, 1, None), (3, 8, 8, 24, 16, 3, 1, 1, None),
+    (2, 34, 34, 8, 16, 3, 2, 0, None),    # stride-2 VALID conv behind the FIR (conv_downsample_2d)
+    (2, 9, 7, 8, 12, 3, 2, 0, 1),         # F.pad(0,1,0,1) + stride 2
+    (2, 32, 32, 4, 128, 3, 1, 1, None),   # stem (3 -> 4 padded channels)
+    (2, 32, 32, 128, 3, 3, 1, 1, None),   # head
+    (5, 4, 4, 512, 256, 1, 1, 0, None),   # 1x1
+])
+def test_conv2d_nhwc_vs_cpu(B, H, W, Cin, Cout, k, stride, pad, pad_hi):
+    g = torch.Generator().manual_seed(B * H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xp = F.pad(x, (pad, pad if pad_hi is None else pad_hi, pad, pad if pad_hi is None else pad_hi))
+    ref = F.conv2d(xp.double(), w.double(), b.double(), stride=stride)
+    OH, OW = ref.shape[2:]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wt = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.empty(B, OH, OW, Cout, device=DEV)
+    _lib.conv2d_nhwc(xd, wt, out, B, H, W, Cin, Cout, k, k, stride, pad, epilogue=_lib.make_epilogue(bias=b.to(DEV)), pad_hi=pad_hi)
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 2e-6
+
+
+# ------------------------------------------------------------------ norm / pointwise
+@pytest.mark.parametrize("B,HW,C,C2,G", [(4, 1024, 128, 0, 32), (3, 256, 256, 128, 32), (2, 64, 8, 0, 2), (2, 16, 24, 0, 6),
+                                         (5, 1024, 16, 8, 6)])
+@pytest.mark.parametrize("act", [None, "silu"])
+def test_groupnorm_vs_cpu(B, HW, C, C2, G, act):
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(B, HW, C, generator=g) * 2 + 0.7
+    x2 = torch.randn(B, HW, C2, generator=g) if C2 else None
+    gamma, beta = torch.randn(C + C2, generator=g), torch.randn(C + C2, generator=g)
+    full = x if x2 is None else torch.cat([x, x2], -1)
+    ref = F.group_norm(full.permute(0, 2, 1).double(), G, gamma.double(), beta.double(), eps=1e-6).permute(0, 2, 1)
+    if act:
+        ref = F.silu(ref)
+    nsplit = _lib.groupnorm_nsplit(B, HW, C + C2)
+    ws = torch.empty(B * nsplit * (C + C2) * 2, device=DEV, dtype=torch.float64)
+    stats = torch.empty(B * G * 2, device=DEV)
+    xd, x2d = x.to(DEV), (x2.to(DEV) if x2 is not None else None)
+    _lib.groupnorm_stats(xd, C, x2d, C2, B, HW, G, 1e-6, ws, stats)
+    y = torch.empty(B, HW, C + C2, device=DEV)
+    _lib.groupnorm_apply(xd, C, x2d, C2, B, HW, G, stats, gamma.to(DEV), beta.to(DEV), act, y)
+    assert rel_err(y.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("rows,cols", [(1000, 256), (64, 16), (10, 1024), (5, 1500), (3, 1)])
+def test_softmax_rows(rows, cols):
+    x = torch.randn(rows, cols, generator=torch.Generator().manual_seed(cols)) * 5
+    d = x.to(DEV)
+    _lib.softmax_rows(d, d, rows, cols, 0.25)
+    assert rel_err(d.cpu(), F.softmax(x.double() * 0.25, -1)) < 2e-6
+
+
+def test_pointwise_and_layout():
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(3, 3, 8, 8, generator=g)
+    y = torch.empty(3, 64, 4, device=DEV)
+    _lib.nchw_to_nhwc(x.to(DEV), y, 3, 3, 64, 4, 2.0, -1.0)
+    ref = torch.cat([(2 * x - 1).reshape(3, 3, 64).permute(0, 2, 1), torch.zeros(3, 64, 1)], -1)
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-6, atol=1e-7)
+    back = torch.empty(3, 3, 8, 8, device=DEV)
+    rsc = torch.tensor([1.0, -2.0, 0.5], device=DEV)
+    _lib.nhwc_to_nchw(y, back, 3, 3, 64, 4, rsc)
+    torch.testing.assert_close(back.cpu(), (2 * x - 1) * rsc.cpu()[:, None, None, None], rtol=1e-6, atol=1e-7)
+    t = torch.tensor([1e-5 * 999, 0.2 * 999, 0.9 * 999])
+    W = torch.randn(16, generator=g) * 16
+    out = torch.empty(3, 32, device=DEV)
+    _lib.fourier_embed(t.to(DEV), W.to(DEV), out, 3, 16)
+    proj = t[:, None] * W[None, :] * 2 * np.pi
+    torch.testing.assert_close(out.cpu(), torch.cat([proj.sin(), proj.cos()], -1), rtol=1e-5, atol=2e-6)
+    a = torch.randn(2, 6, 6, 8, generator=g)
+    up, dn = torch.empty(2, 12, 12, 8, device=DEV), torch.empty(2, 3, 3, 8, device=DEV)
+    _lib.resample2x_nhwc(a.to(DEV), up, 2, 6, 6, 8, 1)
+    _lib.resample2x_nhwc(a.to(DEV), dn, 2, 6, 6, 8, 0)
+    torch.testing.assert_close(up.cpu(), a.repeat_interleave(2, 1).repeat_interleave(2, 2))
+    torch.testing.assert_close(dn.cpu(), F.avg_pool2d(a.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1), rtol=1e-6, atol=1e-7)

@@ -1,0 +1,122 @@
+"""GPU parity of the spectrum kernels (centring + fp64 Gram + tridiagonalisation + bisection) and the integer ID.
+
+Tolerance from BASELINE.json north_star: singular values within 1e-4 relative of the reference CPU path, ID exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+import id_diff_amd
+from id_diff_amd import _lib, plot_utils
+from oracle import dim as odim
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SV_RTOL = 1e-4
+
+
+def check(S, ids_exact=True):
+    sv = _lib.spectrum(S.to(DEV)).cpu()
+    ref32 = odim.spectrum(S)
+    ref64 = odim.spectrum_f64(S)
+    n = min(S.shape)
+    # compare where fp32 gesdd itself is meaningful (above its own noise floor ~1e-6 * sigma_max)
+    floor = 2e-5 * float(ref64[0])
+    keep = ref64 > floor
+    np.testing.assert_allclose(sv.numpy()[keep], ref32.numpy()[keep], rtol=SV_RTOL)
+    np.testing.assert_allclose(sv.double().numpy()[keep], ref64.numpy()[keep], rtol=2e-6)
+    assert sv.shape == (n,) and bool((sv[:-1] >= sv[1:]).all())
+    if ids_exact:
+        assert plot_utils.estimate_dim(sv.tolist()) == odim.estimate_dim(ref32.tolist())
+    return sv
+
+
+def test_golden_matrices(golden):
+    z = golden("svd_rule.npz")
+    for i in range(int(z["n_mats"])):
+        S = torch.from_numpy(z[f"m{i}::S"])
+        sv = check(S)
+        np.testing.assert_allclose(sv.numpy(), z[f"m{i}::sv_ref_f32"], rtol=SV_RTOL)
+        assert plot_utils.estimate_dim(sv.tolist()) == int(z[f"m{i}::dim"]) == int(z[f"m{i}::k_true"])
+
+
+@pytest.mark.parametrize("M,D", [(1501, 100), (300, 128), (400, 129), (700, 257), (1100, 1024), (64, 64), (5, 3)])
+def test_gaussian_matrices(M, D):
+    g = torch.Generator().manual_seed(M * 7 + D)
+    S = torch.randn(M, D, generator=g) * 3 + torch.randn(D, generator=g) * 10   # big column means: centring matters
+    check(S, ids_exact=False)
+
+
+@pytest.mark.parametrize("cond", [1e2, 1e3, 1e4])
+def test_geometric_spectra(cond):
+    g = torch.Generator().manual_seed(int(cond))
+    M, D = 900, 200
+    u, _ = torch.linalg.qr(torch.randn(M, D, generator=g, dtype=torch.float64))
+    v, _ = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))
+    s = torch.logspace(0, -np.log10(cond), D, dtype=torch.float64) * 500
+    S = ((u * s) @ v.T).float()
+    check(S, ids_exact=False)
+
+
+def test_batched_ksphere_shape():
+    """BASELINE config 2: P matrices of 1501 x 100 in one call."""
+    g = torch.Generator().manual_seed(2)
+    P = 16
+    S = torch.randn(P, 1501, 100, generator=g)
+    S[:, :, 40:] *= 0.02   # a cliff at index 40
+    sv = _lib.spectrum(S.to(DEV)).cpu()
+    for p in range(P):
+        ref = odim.spectrum(S[p])
+        np.testing.assert_allclose(sv[p].numpy(), ref.numpy(), rtol=SV_RTOL)
+        assert plot_utils.estimate_dim(sv[p].tolist()) == odim.estimate_dim(ref.tolist()) == 60
+
+
+def test_image_sized_matrix():
+    """BASELINE config 3 size (4480 x 3072): large-D path; properties + parity with the CPU SVD."""
+    g = torch.Generator().manual_seed(3)
+    M, D, k = 4480, 3072, 96
+    S = torch.randn(M, D, generator=g)
+    S[:, D - k:] *= 1.0 / 70.0
+    S = S @ torch.linalg.qr(torch.randn(D, D, generator=g))[0]       # hide the cliff in a rotation
+    S = S + 5.0
+    sv, eig = _lib.spectrum(S.to(DEV), return_eig=True)
+    sv, eig = sv.cpu(), eig.cpu()
+    ref = odim.spectrum(S)
+    np.testing.assert_allclose(sv.numpy(), ref.numpy(), rtol=SV_RTOL)
+    assert plot_utils.estimate_dim(sv.tolist()) == odim.estimate_dim(ref.tolist()) == k
+    # trace identity: sum of Gram eigenvalues == squared Frobenius norm of the centred matrix
+    c = S.double() - S.double().mean(0, keepdim=True)
+    assert abs(float(eig.sum()) / float((c * c).sum()) - 1.0) < 1e-10
+
+
+def test_stage_exports():
+    g = torch.Generator().manual_seed(4)
+    M, D = 257, 70
+    S = torch.randn(1, M, D, generator=g)
+    d = S.to(DEV)
+    mean = torch.empty(1, D, device=DEV, dtype=torch.float64)
+    scratch = torch.empty(32 * D, device=DEV, dtype=torch.float64)
+    lib = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.idiff_colmean_f64(d.data_ptr(), 1, M, D, mean.data_ptr(), scratch.data_ptr(), st) == 0
+    np.testing.assert_allclose(mean.cpu().numpy()[0], S[0].double().mean(0).numpy(), rtol=1e-12, atol=1e-14)
+    G = torch.empty(1, D, D, device=DEV, dtype=torch.float64)
+    assert lib.idiff_centered_gram_f64(d.data_ptr(), mean.data_ptr(), 1, M, D, G.data_ptr(), st) == 0
+    c = S[0].double() - S[0].double().mean(0, keepdim=True)
+    np.testing.assert_allclose(G.cpu().numpy()[0], (c.T @ c).numpy(), rtol=1e-11, atol=1e-11)
+    assert torch.equal(G[0], G[0].T)
+    diag, off = torch.empty(1, D, device=DEV, dtype=torch.float64), torch.zeros(1, D, device=DEV, dtype=torch.float64)
+    scr = torch.empty(2 * D + 8, device=DEV, dtype=torch.float64)
+    Gc = G.clone()
+    assert lib.idiff_symtridiag_f64(Gc.data_ptr(), 1, D, diag.data_ptr(), off.data_ptr(), scr.data_ptr(), st) == 0
+    eig = torch.empty(1, D, device=DEV, dtype=torch.float64)
+    assert lib.idiff_tridiag_eigvals_f64(diag.data_ptr(), off.data_ptr(), 1, D, eig.data_ptr(), st) == 0
+    ref = torch.linalg.eigvalsh(c.T @ c)
+    np.testing.assert_allclose(eig.cpu().numpy()[0], ref.numpy(), rtol=1e-9, atol=1e-9 * float(ref[-1]))
+
+
+def test_errors():
+    with pytest.raises(RuntimeError, match="M >= D"):
+        _lib.spectrum(torch.zeros(3, 5, device=DEV))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _lib.spectrum(torch.zeros(5, 3))

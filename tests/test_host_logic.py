@@ -1,0 +1,129 @@
+"""Host-side logic of the product (no GPU): config dict, registries, batching, rule, sharding, drop-in names."""
+import numpy as np
+import pytest
+import torch
+
+import id_diff_amd
+from helpers import fcn_config, ncsnpp_config
+from id_diff_amd import dim_reduction, parallel, plot_utils, sde_lib
+from id_diff_amd.configs.config_dict import ConfigDict
+from id_diff_amd.configs.utils import read_config
+from id_diff_amd.models import utils as mutils
+from oracle import dim as odim, models as omodels
+
+
+def test_config_dict_dotted_access():
+    c = ConfigDict()
+    c.logging = ConfigDict(svd_points=5)
+    c.dim_estimation = ConfigDict()
+    assert hasattr(c, 'logging.svd_points') and not hasattr(c, 'dim_estimation.num_datapoints')
+    assert c.get('dim_estimation.num_datapoints', 26) == 26
+    c.dim_estimation.num_datapoints = 7
+    assert dim_reduction._num_datapoints(c) == 7  # takes precedence, dim_reduction.py:144-147
+    del c.dim_estimation['num_datapoints']
+    assert dim_reduction._num_datapoints(c) == 5
+    with pytest.raises(NameError):
+        dim_reduction._num_datapoints(ConfigDict())
+
+
+def test_batching_matches_oracle():
+    for shape, b in [((100,), 500), ((3, 32, 32), 128), ((3, 64, 64), 128), ((1, 28, 28), 100), ((3, 32, 32), 127)]:
+        assert dim_reduction.batching(shape, b) == odim.batching(shape, b)
+
+
+def test_rule_matches_golden(golden):
+    z = golden("svd_rule.npz")
+    for i in range(int(z["n_rules"])):
+        assert plot_utils.estimate_dim(z[f"r{i}::s"].tolist()) == int(z[f"r{i}::dim"])
+    for i in range(int(z["n_mats"])):
+        assert plot_utils.estimate_dim(z[f"m{i}::sv_ref_f32"].tolist()) == int(z[f"m{i}::dim"])
+    svd = {"singular_values": [z["r0::s"].tolist(), z["agg::s1"].tolist()]}
+    for mode in ("first", "mean", "all"):
+        assert plot_utils.plot_distribution(svd, mode) == [int(v) for v in z[f"agg::{mode}"]]
+    assert plot_utils.plot_dims(svd)[1] == [int(v) for v in z["agg::all"]]
+
+
+def test_sde_matches_golden(golden):
+    z = golden("sde.npz")
+    t, x = torch.from_numpy(z["t"]), torch.from_numpy(z["x"])
+    mean, std = sde_lib.VESDE(1e-2, 4, 1000).marginal_prob(x, t)
+    assert torch.equal(std, torch.from_numpy(z["ve_ksphere::std"])) and torch.equal(mean, x)
+    mean, std = sde_lib.VPSDE(0.1, 20., 1000).marginal_prob(x, t)
+    assert torch.equal(mean, torch.from_numpy(z["vp::mean"])) and torch.equal(std, torch.from_numpy(z["vp::std"]))
+    cfg = fcn_config()
+    sde, eps = sde_lib.configure_sde(cfg)
+    assert isinstance(sde, sde_lib.VESDE) and eps == 1e-5
+
+
+def test_state_dict_keys_match_reference(golden):
+    """Same module list / parameter names / shapes as the reference => its checkpoints load."""
+    from helpers import overrides_from_golden, state_dict_from_golden
+    for variant in ["bench_init0", "ddpm_outskip", "biggan_nofir", "biggan_outskip_sum"]:
+        z = golden(f"ncsnpp_{variant}.npz")
+        model = mutils.create_model(ncsnpp_config(**overrides_from_golden(z)))
+        sd = state_dict_from_golden(z)
+        own = model.state_dict()
+        assert sorted(own) == sorted(sd)
+        assert all(own[k].shape == sd[k].shape for k in sd)
+        model.load_state_dict(sd, strict=True)
+    z = golden("fcn_tiny.npz")
+    model = mutils.create_model(fcn_config(hidden_nodes=64))
+    model.load_state_dict(state_dict_from_golden(z), strict=True)
+
+
+def test_benchmark_model_size():
+    cfg = read_config('configs/dimension_estimation/paper/image_data/cifar_shaped/ncsnpp.py')
+    model = mutils.create_model(cfg)
+    assert len(model.all_modules) == 59
+    assert sum(p.numel() for p in model.parameters()) == 62758915
+    oracle_model = omodels.create_model(cfg)
+    assert sorted(oracle_model.state_dict()) == sorted(model.state_dict())
+
+
+def test_models_fail_loudly_on_cpu():
+    model = mutils.create_model(fcn_config(hidden_nodes=64))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model(torch.zeros(2, 100), torch.zeros(2))
+
+
+def test_round_robin_sharding_is_a_partition():
+    for n in (1, 4, 7, 16):
+        for w in (1, 2, 4, 8):
+            owned = [parallel.my_points(n, r, w) for r in range(w)]
+            assert sorted(sum(owned, [])) == list(range(n))
+            assert max(len(o) for o in owned) == (n + w - 1) // w
+
+
+def test_dropin_names():
+    import sys
+    names = id_diff_amd.install_dropin()
+    from op import upfirdn2d, fused_leaky_relu, FusedLeakyReLU  # noqa: F401  (the reference's import line)
+    import dim_reduction as dr
+    assert dr.get_manifold_dimension is dim_reduction.get_manifold_dimension
+    for n in names:
+        sys.modules.pop(n, None)
+
+
+def test_ksphere_datamodule_matches_golden(golden):
+    from id_diff_amd.lightning_data_modules.KSphereDataset import KSphereDataset
+    z = golden("ksphere.npz")
+    cfg = ConfigDict()
+    cfg.data = ConfigDict(data_samples=32, n_spheres=1, ambient_dim=100, manifold_dim=10, noise_std=0.0,
+                          embedding_type="random_isometry")
+    torch.manual_seed(42)
+    torch.testing.assert_close(KSphereDataset(cfg).data, torch.from_numpy(z["k10::data"]), rtol=0, atol=1e-6)
+
+
+def test_collect_points_stops_one_short():
+    loader = [torch.zeros(3, 4), torch.ones(3, 4), torch.full((3, 4), 2.)]
+    pts = dim_reduction.collect_points(loader, 5)            # idx+1 >= 5 -> 4 points
+    assert len(pts) == 4 and pts[3][0][0].item() == 1.0 and pts[0][1] == 3
+
+
+def test_bessel_ratio_asymptotics():
+    from scipy.special import ive
+    for p in (11, 51, 101):
+        for kappa in (5e3, 1e4, 1e5):
+            approx = 1 - (p - 1) / (2 * kappa) + (p - 1) * (p - 3) / (8 * kappa ** 2) + (p - 1) * (p - 3) / (8 * kappa ** 3)
+            exact = ive(p / 2, kappa) / ive(p / 2 - 1, kappa)
+            assert abs(approx - exact) < 5e-9, (p, kappa, approx, exact)  # O(p^4 / kappa^4)

@@ -1,0 +1,51 @@
+"""world_size-2 test of the sharding + all-gather exchange on CPU (gloo); the GPU path uses the same code on RCCL."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, num_points, n_sv, q):
+    sys.path.insert(0, ROOT)
+    import id_diff_amd  # noqa: F401
+    from id_diff_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    mine = parallel.my_points(num_points, r, w)
+    local = torch.stack([torch.arange(n_sv, dtype=torch.float32) + 100.0 * p for p in mine]) if mine \
+        else torch.empty(0, n_sv)
+    out = parallel.gather_spectra(local, num_points, n_sv, torch.device("cpu"))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, num_points, n_sv=7):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, num_points, n_sv, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = torch.stack([torch.arange(n_sv, dtype=torch.float32) + 100.0 * p for p in range(num_points)])
+    for r in range(world):
+        assert torch.equal(results[r], expect), (r, results[r])
+
+
+def test_gather_two_ranks_even():
+    _run(2, 4)
+
+
+def test_gather_two_ranks_ragged_and_idle_rank():
+    _run(2, 3)   # rank 1 owns one point fewer
+    _run(2, 1)   # rank 1 owns nothing but still joins the collective
