@@ -68,7 +68,9 @@ class ConvProbe:
 def cpu_baseline(cfg, rows_per_point, D):
     """The oracle (CPU restatement of the reference path) on this box's host cores, bounded sample."""
     from oracle import models as omodels, sde as osde
-    cores = os.cpu_count() or 1
+    # the GPU box exposes every host core (os.cpu_count() = 256) but grants a 16-core share per GPU:
+    # oversubscribing the share makes the CPU run arbitrarily slow, so use the share
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = omodels.create_model(cfg)
@@ -76,6 +78,7 @@ def cpu_baseline(cfg, rows_per_point, D):
     n = 32
     x = torch.rand(n, 3, 32, 32)
     t = torch.full((n,), 1e-5)
+    print(f"[bench] cpu_baseline: oracle score_fn on {cores} threads ...", file=sys.stderr, flush=True)
     with torch.no_grad():
         score_fn(x[:4], t[:4])
         t0 = time.perf_counter()
@@ -83,7 +86,9 @@ def cpu_baseline(cfg, rows_per_point, D):
         while time.perf_counter() - t0 < 12.0:
             score_fn(x, t)
             reps += 1
+            print(f"[bench] cpu_baseline: batch {reps} done at {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
     evals_per_s = reps * n / (time.perf_counter() - t0)
+    print("[bench] cpu_baseline: full SVD ...", file=sys.stderr, flush=True)
     S = torch.randn(rows_per_point, D)
     t0 = time.perf_counter()
     c = S - S.mean(0, keepdim=True)

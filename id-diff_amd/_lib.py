@@ -130,6 +130,8 @@ def make_epilogue(bias=None, rowbias=None, rows_per_group=1, act=None, residual=
     ep.ld_residual = (residual.shape[-1] if ld_residual is None else ld_residual) if residual is not None else 0
     ep.out_scale = float(out_scale)
     ep.rowscale = _ptr(rowscale)
+    # the struct only carries raw addresses: keep the tensors alive until the launch that consumes `ep` is enqueued
+    ep._keepalive = (bias, rowbias, residual, rowscale)
     return ep
 
 

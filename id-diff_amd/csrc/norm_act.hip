@@ -326,7 +326,6 @@ IDIFF_API int idiff_groupnorm_stats_f32(const float *x, int C, const float *x2, 
   const int Ctot = C + C2;
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || Ctot % G != 0) return fail("groupnorm_stats: bad shape");
   if (C % 4 || C2 % 4 || C > 1024 || C2 > 1024) return fail("groupnorm_stats: channels must be multiples of 4 and <= 1024");
-  if (C2 && (C % (Ctot / G) != 0)) return fail("groupnorm_stats: a group straddles the two sources");
   if (!al16(x) || (x2 && !al16(x2))) return fail("groupnorm_stats: inputs must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int nsplit = idiff_groupnorm_nsplit(B, HW, Ctot);

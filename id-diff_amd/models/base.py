@@ -50,7 +50,9 @@ class HipScoreModel(nn.Module):
 
     @staticmethod
     def _check_inputs(x, t):
-        _lib._dev(x, "x")
-        _lib._dev(t, "time/labels")
+        """Device / dtype checks; returns contiguous views (the reference's ops call .contiguous() themselves)."""
+        _lib._dev(x, "x", contiguous=False)
+        _lib._dev(t, "time/labels", contiguous=False)
         if t.ndim != 1 or t.shape[0] != x.shape[0]:
             raise RuntimeError(f"time vector must be [batch]; got {tuple(t.shape)} for x {tuple(x.shape)}")
+        return x.contiguous(), t.contiguous()

@@ -38,7 +38,7 @@ class FCN(HipScoreModel):
         return {"w": weights, "b": biases, "kpad": kpad}
 
     def forward(self, x, t, out_rowscale=None):
-        self._check_inputs(x, t)
+        x, t = self._check_inputs(x, t)
         if x.ndim != 2 or x.shape[1] != self.state_size:
             raise NotImplementedError("fcn on the manifold_dimension path takes [batch, state_size] inputs")
         pk = self.packed()

@@ -43,7 +43,7 @@ class KSphereExact(HipScoreModel):
         return {"Q": qpad.contiguous(), "Qt": qpad.t().contiguous(), "kp": kp}
 
     def forward(self, x, labels, out_rowscale=None):
-        self._check_inputs(x, labels)
+        x, labels = self._check_inputs(x, labels)
         pk = self.packed()
         t = labels / (self.N - 1)
         lo = torch.tensor(self.sigma_min).type_as(t)

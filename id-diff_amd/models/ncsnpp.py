@@ -489,7 +489,7 @@ class NCSNpp(HipScoreModel):
 
     # -------------------------------------------------------------------------------------------- forward
     def forward(self, x, time_cond, out_rowscale=None):
-        self._check_inputs(x, time_cond)
+        x, time_cond = self._check_inputs(x, time_cond)
         if x.ndim != 4 or x.shape[1] != self.channels:
             raise RuntimeError(f"ncsnpp: expected [B, {self.channels}, H, W], got {tuple(x.shape)}")
         pk = self.packed()

@@ -101,8 +101,8 @@ int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out, int B, in
 /* GroupNorm statistics over NHWC x [B, HW, C] with G groups: stats[b, g] = {mean, rstd}, biased variance,
  * rstd = 1/sqrt(var + eps) (torch.nn.GroupNorm as used at models/layerspp.py:219,231).  fp64 accumulation.
  * `x2`/`C2` describe an optional second source whose channels are appended to x's (the skip tensor of
- * torch.cat([h, hs.pop()], 1), models/ncsnpp.py:324) so the concatenation is never materialised for the norm;
- * groups must not straddle the two sources.  workspace: >= B * nsplit * (C + C2) * 2 doubles, nsplit as
+ * torch.cat([h, hs.pop()], 1), models/ncsnpp.py:324) so the concatenation is never materialised for the norm
+ * (a group may straddle the two sources: 256 + 128 channels in 32 groups of 12).  workspace: >= B * nsplit * (C + C2) * 2 doubles, nsplit as
  * returned by idiff_groupnorm_nsplit. */
 int idiff_groupnorm_nsplit(int B, int HW, int C);
 int idiff_groupnorm_stats_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G, float eps,

@@ -17,14 +17,17 @@ SV_RTOL = 1e-4
 
 def check(S, ids_exact=True):
     sv = _lib.spectrum(S.to(DEV)).cpu()
-    ref32 = odim.spectrum(S)
-    ref64 = odim.spectrum_f64(S)
+    ref32 = odim.spectrum(S)                       # the reference path: fp32 centring + fp32 gesdd
+    Sd = S.double()
+    exact = torch.linalg.svdvals(Sd - Sd.mean(0, keepdim=True))   # fp64 centring + fp64 SVD of the same input
     n = min(S.shape)
-    # compare where fp32 gesdd itself is meaningful (above its own noise floor ~1e-6 * sigma_max)
-    floor = 2e-5 * float(ref64[0])
-    keep = ref64 > floor
+    # 1e-4 relative against the reference path wherever fp32 gesdd itself is meaningful
+    # (its own absolute noise floor is ~1e-6 * sigma_max)
+    floor = 2e-5 * float(exact[0])
+    keep = exact > floor
     np.testing.assert_allclose(sv.numpy()[keep], ref32.numpy()[keep], rtol=SV_RTOL)
-    np.testing.assert_allclose(sv.double().numpy()[keep], ref64.numpy()[keep], rtol=2e-6)
+    # against the exact answer the HIP path is accurate to its final fp32 rounding
+    np.testing.assert_allclose(sv.double().numpy()[keep], exact.numpy()[keep], rtol=5e-7)
     assert sv.shape == (n,) and bool((sv[:-1] >= sv[1:]).all())
     if ids_exact:
         assert plot_utils.estimate_dim(sv.tolist()) == odim.estimate_dim(ref32.tolist())
