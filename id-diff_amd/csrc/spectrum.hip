@@ -245,6 +245,92 @@ __global__ void tridiag_tail_kernel(const double *__restrict__ A, int D, double 
   diag[D - 1] = A[(int64_t)(D - 1) * D + (D - 1)];
 }
 
+
+// ------------------------------------------------------------------------------------------------ tridiag, fused step
+// One launch per Householder step (D <= FUSED_D_MAX): with (v, p = tau*A22*v, tau) of step k in hand,
+//   1. K = (tau/2) p.v, w = p - K v                                   (every workgroup, redundantly, in LDS)
+//   2. first row of the updated block -> next reflector (v', tau'), diag[k+1], offd[k+1]
+//   3. for its rows: a = A[i][j] - v_i w_j - w_i v_j, store, and accumulate p'_i = tau' * sum_j a * v'_j
+// so the trailing matrix is read and written ONCE per step (16 B/element) instead of read twice and
+// written once by the symv + rank2 pair.  v/p/tau are ping-ponged between steps.
+constexpr int FUSED_D_MAX = 6000;   // 3 vectors of D doubles in LDS
+
+template <int R>
+__global__ void __launch_bounds__(256)
+tridiag_fused_kernel(double *__restrict__ A, int D, int k, const double *__restrict__ v_in,
+                     const double *__restrict__ p_in, const double *__restrict__ tau_in, double *__restrict__ v_out,
+                     double *__restrict__ p_out, double *__restrict__ tau_out, double *__restrict__ diag,
+                     double *__restrict__ offd) {
+  __shared__ double red[4 * 16];
+  extern __shared__ double sm[];
+  const int base = k + 1, n = D - base;
+  double *vs = sm, *ws = sm + n, *vn = sm + 2 * n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double tau = *tau_in;
+  double part = 0.0;
+  for (int j = tid; j < n; j += 256) { const double a = v_in[j], b = p_in[j]; vs[j] = a; ws[j] = b; part += a * b; }
+  const double K = 0.5 * tau * block_sum_d(part, red);
+  for (int j = tid; j < n; j += 256) ws[j] -= K * vs[j];
+  __syncthreads();
+  // updated first row of the block (local row 0); entries 1.. form the next x
+  const double *row0 = A + (int64_t)base * D + base;
+  const double v0 = vs[0], w0 = ws[0];
+  part = 0.0;
+  for (int j = 1 + tid; j < n; j += 256) {
+    const double r = row0[j] - v0 * ws[j] - w0 * vs[j];
+    vn[j] = r;
+    if (j >= 2) part += r * r;
+  }
+  const double tail_sq = block_sum_d(part, red);   // contains a barrier: vn[] is visible afterwards
+  const Reflector h = make_reflector(vn[1], tail_sq);
+  __syncthreads();
+  if (tid == 0) vn[1] = h.v0;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int j = 1 + tid; j < n; j += 256) v_out[j - 1] = vn[j];
+    if (tid == 0) {
+      *tau_out = h.tau;
+      diag[k + 1] = row0[0] - 2.0 * v0 * w0;
+      offd[k + 1] = h.alpha;
+    }
+  }
+  for (int i0 = 1 + blockIdx.x * R; i0 < n; i0 += gridDim.x * R) {
+    double vi[R], wi[R], acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = min(i0 + r, n - 1);
+      vi[r] = vs[i]; wi[r] = ws[i]; acc[r] = 0.0;
+    }
+    for (int j = 1 + tid; j < n; j += 256) {
+      const double vj = vs[j], wj = ws[j], xj = vn[j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (i0 + r < n) {
+          double *ap = A + (int64_t)(base + i0 + r) * D + base + j;
+          const double a = *ap - vi[r] * wj - wi[r] * vj;
+          *ap = a;
+          acc[r] += a * xj;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum_d(acc[r]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) red[wave * 16 + r] = acc[r];
+    }
+    __syncthreads();
+    if (tid < R && i0 + tid < n)
+      p_out[i0 + tid - 1] = h.tau * (red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid]);
+  }
+}
+
+__global__ void tridiag_fused_tail_kernel(const double *__restrict__ A, int D, double *__restrict__ diag,
+                                          double *__restrict__ offd) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { diag[D - 1] = A[(int64_t)(D - 1) * D + (D - 1)]; offd[D - 1] = 0.0; }
+}
+
 // ------------------------------------------------------------------------------------------------ tridiag, D <= 128 in LDS
 // One workgroup per matrix; the whole matrix lives in LDS (pitch D+1 doubles).  Used for the batched
 // k-sphere workload (P matrices of 100 x 100).
@@ -304,22 +390,46 @@ tridiag_small_kernel(const double *__restrict__ G, int D, double *__restrict__ d
 
 // ------------------------------------------------------------------------------------------------ bisection
 // Thread j of matrix p brackets the j-th smallest eigenvalue of the symmetric tridiagonal (d, e) with the
-// Sturm count  #{eigenvalues < x} = #{negative q_i},  q_0 = d_0 - x,  q_i = d_i - x - e_{i-1}^2 / q_{i-1}.
+// Sturm sequence of leading principal minors, division-free:
+//   p_0 = 1, p_1 = d_0 - x, p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1};   #{eigenvalues < x} = #sign changes.
+// (d_i, e_{i-1}^2) pairs sit in LDS as double2 (one broadcast ds_read_b128 per step); the loop is unrolled by 8
+// with the next 8 pairs loaded before the current 8 are consumed, so one dependent FMA paces a step.
+// The matrix is normalised by 1/span first (|d_i - x| <= 2, e^2 <= 1), so p grows by < 3x per step and can only
+// shrink by ~2^-53 per step: renormalising the pair to exponent 0 every 8 steps (v_frexp_exp + v_ldexp) keeps it
+// far from overflow/underflow.  A sign change is the xor of two sign bits (integer ops); an exact zero counts as
+// positive, which yields the same total as the textbook convention because p_{i+1} = -e^2 p_{i-1} after a zero.
+struct SturmState { double pm, pc; int count; };
+
+__device__ __forceinline__ void sturm_step(SturmState &s, double di, double e2, double x) {
+  const double pn = fma(di - x, s.pc, -(e2 * s.pm));
+  s.count += (unsigned)(__double2hiint(pn) ^ __double2hiint(s.pc)) >> 31;
+  s.pm = s.pc; s.pc = pn;
+}
+
+__device__ __forceinline__ void sturm_renorm(SturmState &s) {
+  const double mag = fabs(s.pc);
+  if (mag != 0.0) {
+    const int ex = -ilogb(mag);
+    s.pc = ldexp(s.pc, ex); s.pm = ldexp(s.pm, ex);
+  }
+}
+
+template <bool LDS>
 __global__ void __launch_bounds__(256)
 bisect_kernel(const double *__restrict__ diag, const double *__restrict__ offd, int D, double *__restrict__ eig,
-              float *__restrict__ sv, int use_lds) {
-  extern __shared__ double sh[];  // [2*D] when use_lds: d, e^2
+              float *__restrict__ sv) {
+  extern __shared__ double2 sh2[];  // [D] when LDS: (d_i, e_{i-1}^2) / span, e_{-1} = 0
   __shared__ double red[8];
   const int p = blockIdx.y;
   const double *d = diag + (int64_t)p * D, *e = offd + (int64_t)p * D;
   const int tid = threadIdx.x;
-  // Gershgorin interval and the pivot floor
+  // Gershgorin interval
   double lo = INFINITY, hi = -INFINITY;
   for (int i = tid; i < D; i += 256) {
-    const double r = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < D ? fabs(e[i]) : 0.0);
+    const double el = i > 0 ? e[i - 1] : 0.0, er = i + 1 < D ? e[i] : 0.0;
+    const double r = fabs(el) + fabs(er);
     lo = fmin(lo, d[i] - r);
     hi = fmax(hi, d[i] + r);
-    if (use_lds) { sh[i] = d[i]; sh[D + i] = i + 1 < D ? e[i] * e[i] : 0.0; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
@@ -327,32 +437,57 @@ bisect_kernel(const double *__restrict__ diag, const double *__restrict__ offd, 
   __syncthreads();
   lo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
   hi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-  const double span = fmax(fabs(lo), fabs(hi));
-  const double pivmin = fmax(1.0, span * span) * 1e-292;  // floor for a vanishing pivot q_i
-  lo -= span * 2.3e-16 * (double)D + pivmin;              // Gershgorin bounds are exact up to rounding
-  hi += span * 2.3e-16 * (double)D + pivmin;
+  const double span = fmax(fmax(fabs(lo), fabs(hi)), 1e-300);
+  const double inv = 1.0 / span;
+  if (LDS) {
+    for (int i = tid; i < D; i += 256) {
+      const double el = i > 0 ? e[i - 1] * inv : 0.0;
+      sh2[i] = make_double2(d[i] * inv, el * el);
+    }
+    __syncthreads();
+  }
   const int j = blockIdx.x * 256 + tid;
   if (j >= D) return;
-  const double *dd = use_lds ? sh : d;
-  const double *ee = use_lds ? sh + D : nullptr;
-  double a = lo, b = hi;
-  for (int it = 0; it < 110; ++it) {
+  // normalised bracket, widened by the rounding of the Gershgorin sums
+  double a = lo * inv - 2.3e-16 * (double)D, b = hi * inv + 2.3e-16 * (double)D;
+  for (int it = 0; it < 120; ++it) {
     const double mid = 0.5 * (a + b);
     if (mid <= a || mid >= b) break;
-    int count = 0;
-    double q = dd[0] - mid;
-    if (fabs(q) < pivmin) q = -pivmin;
-    count += q < 0.0;
-    for (int i = 1; i < D; ++i) {
-      const double e2 = use_lds ? ee[i - 1] : e[i - 1] * e[i - 1];
-      q = dd[i] - mid - e2 / q;
-      if (fabs(q) < pivmin) q = -pivmin;
-      count += q < 0.0;
+    SturmState s;
+    s.pm = 1.0; s.pc = (LDS ? sh2[0].x : d[0] * inv) - mid; s.count = (unsigned)__double2hiint(s.pc) >> 31;
+    int i = 1;
+    if (LDS) {
+      double2 cur[8], nxt[8];
+      if (i + 8 <= D) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = sh2[i + u];
+      }
+      for (; i + 8 <= D; i += 8) {
+        const bool more = i + 16 <= D;
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) nxt[u] = sh2[i + 8 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sturm_step(s, cur[u].x, cur[u].y, mid);
+        sturm_renorm(s);
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+        }
+      }
+      for (; i < D; ++i) sturm_step(s, sh2[i].x, sh2[i].y, mid);
+    } else {
+      for (; i < D; ++i) {
+        const double ev = e[i - 1] * inv;
+        sturm_step(s, d[i] * inv, ev * ev, mid);
+        if ((i & 7) == 0) sturm_renorm(s);
+      }
     }
-    if (count > j) b = mid; else a = mid;
-    if (b - a <= 4.4e-16 * fmax(fabs(a), fabs(b))) break;
+    if (s.count > j) b = mid; else a = mid;
+    if (b - a <= 1e-13 * fmax(fabs(a), fabs(b)) + 1e-22) break;
   }
-  const double lam = 0.5 * (a + b);
+  const double lam = 0.5 * (a + b) * span;
   if (eig) eig[(int64_t)p * D + j] = lam;
   if (sv) sv[(int64_t)p * D + (D - 1 - j)] = (float)sqrt(fmax(lam, 0.0));
 }
@@ -362,16 +497,21 @@ constexpr int SMALL_D_MAX = 128;
 size_t small_lds_bytes(int D) { return ((size_t)D * (D + 1) + 2 * D + 8) * sizeof(double); }
 
 int bisect_launch(const double *diag, const double *offd, int P, int D, double *eig, float *sv, hipStream_t st) {
-  const int use_lds = D <= 8192;
-  const size_t lds = use_lds ? (size_t)2 * D * sizeof(double) : 0;
+  const bool use_lds = D <= 8192;
+  const size_t lds = use_lds ? (size_t)D * sizeof(double2) : 0;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(double2));
     if (e != hipSuccess) { idiff::set_error("bisect: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(bisect_kernel, dim3(idiff::ceil_div(D, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv, use_lds);
+  // 64 eigenvalues per workgroup would spread the work over more CUs, but the chain length (D steps per
+  // bisection) is the latency; 256 threads keep the broadcast LDS traffic low.
+  if (use_lds)
+    hipLaunchKernelGGL(bisect_kernel<true>, dim3(idiff::ceil_div(D, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv);
+  else
+    hipLaunchKernelGGL(bisect_kernel<false>, dim3(idiff::ceil_div(D, 256), P), dim3(256), 0, st, diag, offd, D, eig, sv);
   return idiff::launch_status("bisect");
 }
 
@@ -414,7 +554,7 @@ IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double
     hipLaunchKernelGGL(tridiag_small_kernel, dim3(P), dim3(256), lds, st, G, D, diag, offdiag);
     return launch_status("tridiag_small");
   }
-  if (!scratch) return fail("symtridiag: scratch (2*D+8 doubles) required for D > %d", SMALL_D_MAX);
+  if (!scratch) return fail("symtridiag: scratch (4*D+16 doubles) required for D > %d", SMALL_D_MAX);
   if ((size_t)D * sizeof(double) > 60 * 1024) {
     static bool attr_set2 = false;
     if (!attr_set2) {
@@ -426,6 +566,46 @@ IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double
     if ((size_t)D * sizeof(double) > 160 * 1024 - 256) return fail("symtridiag: D=%d exceeds the LDS-resident reflector", D);
   }
   double *v = scratch, *pvec = scratch + D, *tau = scratch + 2 * D;
+  if (D <= FUSED_D_MAX) {
+    static bool attr_fused = false;
+    if (!attr_fused) {
+      const void *fns[3] = {reinterpret_cast<const void *>(tridiag_fused_kernel<16>),
+                            reinterpret_cast<const void *>(tridiag_fused_kernel<8>),
+                            reinterpret_cast<const void *>(tridiag_fused_kernel<4>)};
+      for (const void *fn : fns) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FUSED_D_MAX * 8);
+        if (e != hipSuccess) { set_error("symtridiag: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+      }
+      attr_fused = true;
+    }
+    // ping-pong buffers: [v0 | p0 | v1 | p1 | tau0 tau1]
+    double *vb[2] = {scratch, scratch + 2 * (int64_t)D}, *pb[2] = {scratch + D, scratch + 3 * (int64_t)D};
+    double *tb = scratch + 4 * (int64_t)D;
+    for (int p = 0; p < P; ++p) {
+      double *A = G + (int64_t)p * D * D;
+      double *dg = diag + (int64_t)p * D, *od = offdiag + (int64_t)p * D;
+      const int n0 = D - 1;
+      hipLaunchKernelGGL(tridiag_symv_kernel, dim3(max(1, min(ceil_div(n0, 4), 1024))), dim3(256),
+                         (size_t)n0 * sizeof(double), st, A, D, 0, vb[0], pb[0], dg, od, tb);
+      for (int k = 0; k + 2 < D; ++k) {
+        const int n = D - k - 1, cur = k & 1, nxt = cur ^ 1;
+        const size_t lds = (size_t)3 * n * sizeof(double);
+        const int rows = n - 1;
+        if (rows >= 16 * 100000) {  // measured: 16 rows per workgroup leave CUs idle (n/16 < 256 workgroups)
+          hipLaunchKernelGGL(tridiag_fused_kernel<16>, dim3(max(1, ceil_div(rows, 16))), dim3(256), lds, st, A, D, k, vb[cur],
+                             pb[cur], tb + cur, vb[nxt], pb[nxt], tb + nxt, dg, od);
+        } else if (rows >= 8 * 256) {
+          hipLaunchKernelGGL(tridiag_fused_kernel<8>, dim3(max(1, ceil_div(rows, 8))), dim3(256), lds, st, A, D, k, vb[cur],
+                             pb[cur], tb + cur, vb[nxt], pb[nxt], tb + nxt, dg, od);
+        } else {
+          hipLaunchKernelGGL(tridiag_fused_kernel<4>, dim3(max(1, ceil_div(rows, 4))), dim3(256), lds, st, A, D, k, vb[cur],
+                             pb[cur], tb + cur, vb[nxt], pb[nxt], tb + nxt, dg, od);
+        }
+      }
+      hipLaunchKernelGGL(tridiag_fused_tail_kernel, dim3(1), dim3(64), 0, st, A, D, dg, od);
+    }
+    return launch_status("symtridiag_fused");
+  }
   for (int p = 0; p < P; ++p) {
     double *A = G + (int64_t)p * D * D;
     double *dg = diag + (int64_t)p * D, *od = offdiag + (int64_t)p * D;
@@ -447,11 +627,11 @@ IDIFF_API int idiff_tridiag_eigvals_f64(const double *diag, const double *offdia
   return bisect_launch(diag, offdiag, P, D, eig, nullptr, (hipStream_t)stream);
 }
 
-// workspace layout (doubles): mean[P*D] | colsum partials[P*32*D] | G[P*D*D] | diag[P*D] | offd[P*D] | scratch[2*D+8]
+// workspace layout (doubles): mean[P*D] | colsum partials[P*32*D] | G[P*D*D] | diag[P*D] | offd[P*D] | scratch[4*D+16]
 IDIFF_API int64_t idiff_spectrum_workspace_bytes(int P, int M, int D) {
   (void)M;
   if (P <= 0 || D <= 0) return 0;
-  const int64_t n = (int64_t)P * D * (1 + MEAN_SPLITS) + (int64_t)P * D * D + 2 * (int64_t)P * D + 2 * (int64_t)D + 8;
+  const int64_t n = (int64_t)P * D * (1 + MEAN_SPLITS) + (int64_t)P * D * D + 2 * (int64_t)P * D + 4 * (int64_t)D + 16;
   return n * (int64_t)sizeof(double);
 }
 

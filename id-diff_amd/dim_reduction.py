@@ -85,6 +85,36 @@ class ScoreMatrixBuilder:
         return S
 
 
+class SpectrumPipeline:
+    """Runs the spectrum of point p on a side HIP stream while the score evaluations of point p+1 fill the
+    main stream: the tridiagonalisation is a chain of ~D short bandwidth-bound launches that leaves most CUs
+    idle, the convolutions are MFMA-bound -- the two overlap almost for free."""
+
+    def __init__(self, device, overlap=True):
+        self.device = device
+        self.side = torch.cuda.Stream(device=device) if overlap else None
+        self.pending = []
+
+    def submit(self, S):
+        if self.side is None:
+            self.pending.append(_lib.spectrum(S))
+            return
+        ready = torch.cuda.Event()
+        ready.record()                                   # S is complete on the producing stream
+        self.side.wait_event(ready)
+        with torch.cuda.stream(self.side):
+            sv = _lib.spectrum(S)
+        S.record_stream(self.side)                       # keep S alive until the side stream is done with it
+        self.pending.append(sv)
+
+    def results(self):
+        """All submitted spectra, in order; joins the side stream into the current one."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        out, self.pending = self.pending, []
+        return out
+
+
 def setup_model(config):
     """Steps :123-141 of the reference: data module, module + checkpoint, SDE, device, score_fn."""
     DataModule = create_lightning_datamodule(config)
@@ -135,14 +165,16 @@ def get_manifold_dimension(config, name=None, return_svd=False):
     builder = ScoreMatrixBuilder(score_fn, pl_module.sde, pl_module.sampling_eps, device,
                                  config.get('dim_estimation.inflight_rows', None))
     mine = parallel.my_points(len(points), rank, world)
-    local, n_sv = [], None
+    n_sv = None
+    pipe = SpectrumPipeline(device, overlap=bool(config.get('dim_estimation.overlap_spectrum', True)))
     with torch.no_grad():
         for p in mine:
             x, batchsize = points[p]
             gen = torch.Generator(device=device).manual_seed(seed + 1000003 * (p + 1))
-            S = builder.build(x.to(device), batchsize, generator=gen)
-            local.append(_lib.spectrum(S))
-            n_sv = local[-1].numel()
+            pipe.submit(builder.build(x.to(device), batchsize, generator=gen))
+        local = pipe.results()
+    if local:
+        n_sv = local[-1].numel()
     if n_sv is None:  # a rank without points still takes part in the exchange
         x, batchsize = points[0]
         n_sv = min(batching(tuple(x.shape), batchsize)[2], x.numel())
