@@ -206,7 +206,7 @@ def main():
         conv = probe.summary()
         roofline = None
         if conv:
-            roofline = {"bound": "mfma", "kernel": "igemm_kernel<128,128,2,2,CONV> (3x3 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+            roofline = {"bound": "mfma", "kernel": "igemm_pipe_kernel<128,128,2,2,CONV> (3x3 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                         "achieved": conv["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": conv["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                         "launches_sampled": conv["launches"], "avg_launch_us": conv["avg_us"]}

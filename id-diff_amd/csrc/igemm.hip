@@ -25,6 +25,7 @@
 // Workgroup ids are remapped so that consecutive M-tiles (which share conv halo rows and the weight
 // panel) land on the same XCD's L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -45,6 +46,7 @@ struct IgemmParams {
   int H, W, Cin, OH, OW, KW, stride, pad;
   idiff_epilogue ep;
   int has_ep;
+  uint32_t a_bytes, b_bytes;  // extent of one batch slice of A / Bt for the buffer-addressed kernel
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -259,6 +261,238 @@ int launch_cfg(IgemmParams &p, int batch, hipStream_t st) {
   return idiff::launch_status(CONV ? "igemm_conv" : "igemm_linear");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Pipelined variant (the one the score networks run on): same tiling and MFMA core, but
+//   * operands are addressed through raw buffer descriptors with 32-bit byte offsets; an offset of
+//     0xFFFFFFFF is out of range and returns zeros, so image borders, M/N tails and the K tail need no
+//     branches and no data selects (the compiled loop above spends ~250 VALU + 8 exec-masked branches per
+//     k-tile on that);
+//   * the conv loader keeps (tap, channel) as uniform counters advanced per k-tile (Cin % 32 == 0: a k-tile
+//     never straddles a tap) and a per-row 9-bit tap-validity mask computed once, instead of two integer
+//     divisions per thread per k-tile;
+//   * global loads run TWO k-tiles ahead: in iteration t the registers holding tile t+1 are written to the
+//     other LDS buffer, then reloaded with tile t+2, then the 64 MFMAs of tile t issue.  The non-MFMA part of
+//     an iteration shrinks to ~60 instructions, which matters because the two waves that share a SIMD run the
+//     same program and drift into lockstep (both in their non-MFMA phase at once = idle matrix pipe).
+// Requires 16-byte aligned K-contiguous operands, slices < 4 GiB and (conv) Cin % 32 == 0; everything else
+// takes the general kernel above.
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t OOB = 0xFFFFFFFFu;
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  const uintx4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return __builtin_bit_cast(float4, v);
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV>
+__global__ void __launch_bounds__(WARPS_M *WARPS_N * 64)
+igemm_pipe_kernel(const IgemmParams p) {
+  constexpr int T = WARPS_M * WARPS_N * 64;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_PER_T = BM * (BK / 4) / T;
+  constexpr int B_PER_T = BN * (BK / 4) / T;
+  constexpr int ROW_STEP = T / 8;
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *As = lds;
+  float *Bs = lds + 2 * BM * LDS_PITCH;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  const int batch = blockIdx.y;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WARPS_N) * WTM, wn0 = (wave % WARPS_N) * WTN;
+
+  const __amdgpu_buffer_rsrc_t rA =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + (int64_t)batch * p.strideA), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(p.Bt + (int64_t)batch * p.strideB), 0, (int)p.b_bytes, 0x00020000);
+
+  const int kc = (tid & 7) * 4;
+  const int row_base = tid >> 3;
+
+  uint32_t a_base[A_PER_T], a_mask[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int m = m0 + row_base + i * ROW_STEP;
+    const bool ok = m < p.M;
+    if (CONV) {
+      const int mm = ok ? m : 0;
+      const int ox = mm % p.OW;
+      const int t = mm / p.OW;
+      const int oy = t % p.OH;
+      const int b = t / p.OH;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      // modular 32-bit arithmetic: the pixel offset may be "negative" until the tap offset is added
+      a_base[i] = (uint32_t)(((b * p.H + iy0) * p.W + ix0) * p.Cin + kc) * 4u;
+      uint32_t mask = 0;
+      const int KH = p.K / (p.KW * p.Cin);
+      for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < p.KW; ++kx) {
+          const int iy = iy0 + ky, ix = ix0 + kx;
+          if (ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << (ky * p.KW + kx);
+        }
+      a_mask[i] = mask;
+    } else {
+      a_base[i] = (uint32_t)((int64_t)m * p.lda + kc) * 4u;
+      a_mask[i] = ok ? 1u : 0u;
+    }
+  }
+  uint32_t b_base[B_PER_T];
+  bool b_ok[B_PER_T];
+#pragma unroll
+  for (int i = 0; i < B_PER_T; ++i) {
+    const int n = n0 + row_base + i * ROW_STEP;
+    b_ok[i] = n < p.N;
+    b_base[i] = (uint32_t)((int64_t)n * p.ldb + kc) * 4u;
+  }
+
+  float4 a_reg[A_PER_T], b_reg[B_PER_T];
+  // uniform k-tile state of the NEXT fetch
+  int f_kt = 0, f_c0 = 0, f_tap = 0, f_ky = 0, f_kx = 0;
+
+  auto fetch = [&]() {
+    const int k = f_kt * BK + kc;
+    const bool kok = k < p.K;
+    if (CONV) {
+      const uint32_t tapoff = (uint32_t)((f_ky * p.W + f_kx) * p.Cin + f_c0) * 4u;
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) {
+        const bool ok = (a_mask[i] >> f_tap) & 1u;
+        a_reg[i] = buf_load4(rA, ok ? a_base[i] + tapoff : OOB);
+      }
+      f_c0 += BK;
+      if (f_c0 == p.Cin) { f_c0 = 0; ++f_tap; if (++f_kx == p.KW) { f_kx = 0; ++f_ky; } }
+    } else {
+      const uint32_t koff = (uint32_t)f_kt * (BK * 4u);
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) a_reg[i] = buf_load4(rA, (a_mask[i] && kok) ? a_base[i] + koff : OOB);
+    }
+    const uint32_t koffb = (uint32_t)f_kt * (BK * 4u);
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) b_reg[i] = buf_load4(rB, (b_ok[i] && kok) ? b_base[i] + koffb : OOB);
+    ++f_kt;
+  };
+
+  auto stage = [&](int buf) {
+    float *a_dst = As + buf * BM * LDS_PITCH;
+    float *b_dst = Bs + buf * BN * LDS_PITCH;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i)
+      *reinterpret_cast<float4 *>(a_dst + (row_base + i * ROW_STEP) * LDS_PITCH + kc) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i)
+      *reinterpret_cast<float4 *>(b_dst + (row_base + i * ROW_STEP) * LDS_PITCH + kc) = b_reg[i];
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
+  const int nkt = (p.K + BK - 1) / BK;
+
+  fetch();
+  stage(0);
+  if (nkt > 1) fetch();
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) stage(buf ^ 1);   // tile kt+1: loaded one iteration ago
+    if (kt + 2 < nkt) fetch();          // tile kt+2: lands while this tile's 64 MFMAs run
+    const float *a_src = As + buf * BM * LDS_PITCH + (wm0 + frag_row) * LDS_PITCH + frag_k;
+    const float *b_src = Bs + buf * BN * LDS_PITCH + (wn0 + frag_row) * LDS_PITCH + frag_k;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a_src + i * 32 * LDS_PITCH + g * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(b_src + j * 32 * LDS_PITCH + g * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  float *Cb = p.C + (int64_t)batch * p.strideC;
+  const idiff_epilogue &ep = p.ep;
+  const int col_l = lane & 31, row_l = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn0 + j * 32 + col_l;
+    if (n >= p.N) continue;
+    const float bias = (p.has_ep && ep.bias) ? ep.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bias;
+        if (p.has_ep) {
+          if (ep.rowbias) v += ep.rowbias[(int64_t)(m / ep.rows_per_group) * ep.ld_rowbias + n];
+          v = idiff::act_apply(v, ep.act);
+          if (ep.residual) v += ep.residual[(int64_t)m * ep.ld_residual + n];
+          v *= ep.out_scale;
+          if (ep.rowscale) v *= ep.rowscale[m / ep.rows_per_group];
+        }
+        Cb[(int64_t)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV>
+int launch_pipe(IgemmParams &p, int batch, hipStream_t st) {
+  p.tiles_m = idiff::ceil_div(p.M, BM);
+  p.tiles_n = idiff::ceil_div(p.N, BN);
+  constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(float);
+  auto kern = igemm_pipe_kernel<BM, BN, WARPS_M, WARPS_N, CONV>;
+  static bool attr_set = false;
+  if (lds_bytes > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+      idiff::set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds_bytes, st, p);
+  return idiff::launch_status(CONV ? "igemm_pipe_conv" : "igemm_pipe_linear");
+}
+
+template <bool CONV>
+int dispatch_pipe(IgemmParams &p, int batch, hipStream_t st) {
+  const int64_t wg_big = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 128) * batch;
+  if (p.N > 64 && wg_big >= 256) return launch_pipe<128, 128, 2, 2, CONV>(p, batch, st);
+  const int64_t wg_mid = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 64) * batch;
+  if (wg_mid >= 256 || p.M >= 4096) return launch_pipe<128, 64, 2, 2, CONV>(p, batch, st);
+  return launch_pipe<64, 64, 2, 2, CONV>(p, batch, st);
+}
+
 template <bool CONV, bool VEC>
 int dispatch(IgemmParams &p, int batch, hipStream_t st) {
   // Pick the largest tile that still yields >= ~2 workgroups per CU pair; small problems get small tiles.
@@ -302,6 +536,11 @@ IDIFF_API int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const
   const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) && (strideB % 4 == 0) &&
                    aligned16(A) && aligned16(Bt);
   hipStream_t st = (hipStream_t)stream;
+  const int64_t a_bytes = ((int64_t)(M - 1) * lda + K) * 4, b_bytes = ((int64_t)(N - 1) * ldb + K) * 4;
+  if (vec && a_bytes < 0xFFFFFFF0ll && b_bytes < 0xFFFFFFF0ll && !getenv("IDIFF_NO_PIPE")) {
+    p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
+    return dispatch_pipe<false>(p, batch, st);
+  }
   return vec ? dispatch<false, true>(p, batch, st) : dispatch<false, false>(p, batch, st);
 }
 
@@ -326,5 +565,10 @@ IDIFF_API int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out,
   p.lda = 0; p.ldb = p.K; p.ldc = Cout;
   p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KW = KW; p.stride = stride; p.pad = pad;
   fill_epilogue(p, ep);
+  const int64_t a_bytes = (int64_t)B * H * W * Cin * 4, b_bytes = (int64_t)Cout * p.K * 4;
+  if (Cin % BK == 0 && KH * KW <= 32 && a_bytes < 0xFFFFFFF0ll && b_bytes < 0xFFFFFFF0ll && !getenv("IDIFF_NO_PIPE")) {
+    p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
+    return dispatch_pipe<true>(p, 1, (hipStream_t)stream);
+  }
   return dispatch<true, true>(p, 1, (hipStream_t)stream);
 }
