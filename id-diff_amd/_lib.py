@@ -37,12 +37,12 @@ _SIGNATURES = {
     "idiff_conv2d_nhwc_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [ctypes.POINTER(Epilogue), c_p]),
     "idiff_groupnorm_nsplit": (c_i, [c_i, c_i, c_i]),
     "idiff_groupnorm_stats_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
-    "idiff_groupnorm_apply_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "idiff_groupnorm_apply_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i64, c_i, c_p, c_p]),
     "idiff_softmax_rows_f32": (c_i, [c_p, c_p, c_i64, c_i, c_f, c_p]),
     "idiff_affine_act_f32": (c_i, [c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_i64, c_p]),
     "idiff_add_scale_f32": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_p]),
     "idiff_fourier_embed_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
-    "idiff_positional_embed_f32": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p]),
+    "idiff_positional_embed_f32": (c_i, [c_p, c_p, c_i, c_i, c_f, c_i, c_p]),
     "idiff_concat_cols_f32": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i64, c_p]),
     "idiff_nchw_to_nhwc_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "idiff_nhwc_to_nchw_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
@@ -210,9 +210,10 @@ def groupnorm_stats(x, C, x2, C2, B, HW, G, eps, workspace, stats):
                                            stats.data_ptr(), _stream()), "idiff_groupnorm_stats_f32")
 
 
-def groupnorm_apply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y):
+def groupnorm_apply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None):
     _check(lib().idiff_groupnorm_apply_f32(x.data_ptr(), C, _ptr(x2), C2, B, HW, G, stats.data_ptr(), gamma.data_ptr(),
-                                           beta.data_ptr(), ACT[act], y.data_ptr(), _stream()),
+                                           beta.data_ptr(), _ptr(mod), mod.stride(0) if mod is not None else 0,
+                                           ACT[act], y.data_ptr(), _stream()),
            "idiff_groupnorm_apply_f32")
 
 
@@ -236,8 +237,8 @@ def fourier_embed(t, W, out, B, half):
            "idiff_fourier_embed_f32")
 
 
-def positional_embed(t, out, B, dim, max_positions=10000.0):
-    _check(lib().idiff_positional_embed_f32(t.data_ptr(), out.data_ptr(), B, dim, max_positions, _stream()),
+def positional_embed(t, out, B, dim, max_positions=10000.0, mode=0):
+    _check(lib().idiff_positional_embed_f32(t.data_ptr(), out.data_ptr(), B, dim, max_positions, mode, _stream()),
            "idiff_positional_embed_f32")
 
 

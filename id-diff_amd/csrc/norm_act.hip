@@ -69,7 +69,7 @@ __global__ void gn_finalize_kernel(const double *__restrict__ ws, int B, int nsp
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const float *__restrict__ x, int C, const float *__restrict__ x2, int C2, int HW, int G,
                 const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
-                int act, float *__restrict__ y, int64_t total_vec) {
+                const float *__restrict__ mod, int64_t ld_mod, int act, float *__restrict__ y, int64_t total_vec) {
   const int Ctot = C + C2, CVt = Ctot >> 2, cpg = Ctot / G;
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total_vec; v += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(v % CVt) * 4;
@@ -85,7 +85,10 @@ gn_apply_kernel(const float *__restrict__ x, int C, const float *__restrict__ x2
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float *st = stats + 2 * ((int64_t)b * G + (c + j) / cpg);
-      o[j] = act_apply((o[j] - st[0]) * st[1] * gg[j] + bb[j], act);
+      float v = (o[j] - st[0]) * st[1] * gg[j] + bb[j];
+      // scale-shift conditioning h * (1 + scale) + shift between norm and activation (BeatGANsblocks.py:316-321)
+      if (mod) v = v * (1.0f + mod[(int64_t)b * ld_mod + c + j]) + mod[(int64_t)b * ld_mod + Ctot + c + j];
+      o[j] = act_apply(v, act);
     }
     reinterpret_cast<float4 *>(y)[v] = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -204,15 +207,24 @@ __global__ void fourier_embed_kernel(const float *__restrict__ t, const float *_
 }
 
 __global__ void positional_embed_kernel(const float *__restrict__ t, float *__restrict__ out, int B, int dim,
-                                        float log_max_over) {
+                                        float log_max_over, float neg_log_max, int mode) {
   const int half = dim / 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * half) return;
   const int b = i / half, j = i - b * half;
-  const float freq = expf(__fmul_rn((float)j, -log_max_over));
-  const float arg = __fmul_rn(t[b], freq);
-  out[(int64_t)b * dim + j] = sinf(arg);
-  out[(int64_t)b * dim + half + j] = cosf(arg);
+  if (mode == 0) {
+    // DDPM (models/layers.py:524-538): exp(arange * -(log(max)/(half-1))), [sin, cos]
+    const float freq = expf(__fmul_rn((float)j, -log_max_over));
+    const float arg = __fmul_rn(t[b], freq);
+    out[(int64_t)b * dim + j] = sinf(arg);
+    out[(int64_t)b * dim + half + j] = cosf(arg);
+  } else {
+    // guided-diffusion / BeatGANs (models/BeatGANs_nn.py:107-125): exp(-log(max) * arange / half), [cos, sin]
+    const float freq = expf(__fdiv_rn(__fmul_rn(neg_log_max, (float)j), (float)half));
+    const float arg = __fmul_rn(t[b], freq);
+    out[(int64_t)b * dim + j] = cosf(arg);
+    out[(int64_t)b * dim + half + j] = sinf(arg);
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -337,8 +349,8 @@ IDIFF_API int idiff_groupnorm_stats_f32(const float *x, int C, const float *x2, 
 }
 
 IDIFF_API int idiff_groupnorm_apply_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G,
-                                        const float *stats, const float *gamma, const float *beta, int act, float *y,
-                                        void *stream) {
+                                        const float *stats, const float *gamma, const float *beta, const float *mod,
+                                        int64_t ld_mod, int act, float *y, void *stream) {
   if (!x || !stats || !gamma || !beta || !y) return fail("groupnorm_apply: null pointer");
   if (!x2) C2 = 0;
   const int Ctot = C + C2;
@@ -347,7 +359,7 @@ IDIFF_API int idiff_groupnorm_apply_f32(const float *x, int C, const float *x2, 
     return fail("groupnorm_apply: pointers must be 16-byte aligned");
   const int64_t total_vec = (int64_t)B * HW * (Ctot / 4);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(streaming_grid(total_vec, 256)), dim3(256), 0, (hipStream_t)stream, x, C, x2,
-                     C2, HW, G, stats, gamma, beta, act, y, total_vec);
+                     C2, HW, G, stats, gamma, beta, mod, ld_mod, act, y, total_vec);
   return launch_status("groupnorm_apply");
 }
 
@@ -396,12 +408,15 @@ IDIFF_API int idiff_fourier_embed_f32(const float *t, const float *W, float *out
   return launch_status("fourier_embed");
 }
 
-IDIFF_API int idiff_positional_embed_f32(const float *t, float *out, int B, int dim, float max_positions, void *stream) {
+IDIFF_API int idiff_positional_embed_f32(const float *t, float *out, int B, int dim, float max_positions, int mode,
+                                         void *stream) {
   if (B <= 0 || dim < 4 || dim % 2 || !t || !out) return fail("positional_embed: bad arguments (dim must be even, >= 4)");
+  if (mode != 0 && mode != 1) return fail("positional_embed: mode must be 0 (DDPM) or 1 (guided-diffusion)");
+  const float neg_log_max = (float)(-log((double)max_positions));
   // math.log(max_positions) / (half_dim - 1) is a Python float, rounded to fp32 when it meets the tensor
   const float log_max_over = (float)(log((double)max_positions) / (double)(dim / 2 - 1));
   hipLaunchKernelGGL(positional_embed_kernel, dim3(ceil_div(B * (dim / 2), 256)), dim3(256), 0, (hipStream_t)stream, t, out, B,
-                     dim, log_max_over);
+                     dim, log_max_over, neg_log_max, mode);
   return launch_status("positional_embed");
 }
 

@@ -1,7 +1,7 @@
 """Score networks of the manifold_dimension path, executed with the gfx950 kernels of libidiff_hip.so.
 
-Importing the package registers ``fcn``, ``ncsnpp`` (and ``ksphere_exact``) under the names
+Importing the package registers ``fcn``, ``ncsnpp``, ``BeatGANsUNetModel`` (and ``ksphere_exact``) under the names
 ``config.model.name`` selects (reference: models/utils.py:24-47, models/fcn.py:6, models/ncsnpp.py:39).
 """
 from . import utils  # noqa: F401
-from . import fcn, ncsnpp, ksphere_exact  # noqa: F401
+from . import fcn, ncsnpp, beatgans, ksphere_exact  # noqa: F401

@@ -332,8 +332,8 @@ class NCSNpp(HipScoreModel):
     def _new(self, B, H, W, C, like):
         return _T(torch.empty(B, H * W, C, device=like.device, dtype=torch.float32), H, W, C)
 
-    def _gn_act(self, x, gn, act, x2=None):
-        """GroupNorm (+activation) of x (or of cat[x, x2]) -> new tensor with C + C2 channels."""
+    def _gn_act(self, x, gn, act, x2=None, mod=None):
+        """GroupNorm (+ scale-shift modulation ``mod`` [B, 2*Ctot]) (+activation) of x (or of cat[x, x2])."""
         B = x.buf.shape[0]
         HW = x.H * x.W
         C2 = x2.C if x2 is not None else 0
@@ -344,7 +344,7 @@ class NCSNpp(HipScoreModel):
         _lib.groupnorm_stats(x.buf, x.C, x2.buf if x2 is not None else None, C2, B, HW, G, gn.eps, ws, stats)
         y = self._new(B, x.H, x.W, x.C + C2, x.buf)
         _lib.groupnorm_apply(x.buf, x.C, x2.buf if x2 is not None else None, C2, B, HW, G, stats,
-                             gn.weight.detach(), gn.bias.detach(), act, y.buf)
+                             gn.weight.detach(), gn.bias.detach(), act, y.buf, mod=mod)
         return y
 
     def _conv(self, x, wt, bias, stride=1, pad=1, pad_hi=None, **ep):

@@ -107,10 +107,12 @@ int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out, int B, in
 int idiff_groupnorm_nsplit(int B, int HW, int C);
 int idiff_groupnorm_stats_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G, float eps,
                               double *workspace, float *stats, void *stream);
-/* y[b, p, c] = act((x - mean) * rstd * gamma[c] + beta[c]); writes channel-concatenated output [B, HW, C+C2]. */
+/* y[b, p, c] = act(n * (1 + mod[b, c]) + mod[b, Ctot + c]) with n = (x - mean) * rstd * gamma[c] + beta[c]; writes the
+ * channel-concatenated output [B, HW, Ctot = C+C2].  mod ([B, ld_mod], scale then shift halves) is the scale-shift
+ * conditioning of models/BeatGANsblocks.py:258-332 (`h * (1 + scale) + shift` after the norm); NULL skips it. */
 int idiff_groupnorm_apply_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G,
-                              const float *stats, const float *gamma, const float *beta, int act, float *y,
-                              void *stream);
+                              const float *stats, const float *gamma, const float *beta, const float *mod,
+                              int64_t ld_mod, int act, float *y, void *stream);
 
 /* Row softmax of x [rows, cols] scaled by `scale` before the exponent (layerspp.py:82-84). In place allowed. */
 int idiff_softmax_rows_f32(const float *x, float *y, int64_t rows, int cols, float scale, void *stream);
@@ -123,8 +125,9 @@ int idiff_affine_act_f32(const float *a, float *y, int64_t n, float alpha, float
 int idiff_add_scale_f32(const float *a, const float *b, float *y, int64_t n, float scale, void *stream);
 /* Gaussian Fourier features: out[b] = [sin(2*pi*t[b]*W), cos(2*pi*t[b]*W)] (models/layerspp.py:39-41). */
 int idiff_fourier_embed_f32(const float *t, const float *W, float *out, int B, int half, void *stream);
-/* Sinusoidal positional embedding (models/layers.py:524-538), dim even. */
-int idiff_positional_embed_f32(const float *t, float *out, int B, int dim, float max_positions, void *stream);
+/* Sinusoidal timestep embedding, dim even.  mode 0: DDPM (models/layers.py:524-538, [sin, cos], log(max)/(half-1));
+ * mode 1: guided-diffusion / BeatGANs (models/BeatGANs_nn.py:107-125, [cos, sin], log(max)/half). */
+int idiff_positional_embed_f32(const float *t, float *out, int B, int dim, float max_positions, int mode, void *stream);
 /* out[r, :] = cat(a[r, :Ca], b[r, :Cb]) for r < rows (channel concat of NHWC tensors / fcn's cat([x, t])). */
 int idiff_concat_cols_f32(const float *a, int Ca, const float *b, int Cb, float *out, int64_t rows, void *stream);
 /* Layout changes at the model boundary: NCHW [B, C, HW] <-> NHWC [B, HW, Cpad] (zero-filled pad channels),

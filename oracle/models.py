@@ -482,9 +482,8 @@ class NCSNpp(nn.Module):
         return h
 
 
-MODELS = {"fcn": FCN, "ncsnpp": NCSNpp}
-
-
 def create_model(config):
     """models/utils.py:114-120."""
-    return MODELS[config.model.name](config)
+    from .beatgans import BeatGANsUNetModel
+    models = {"fcn": FCN, "ncsnpp": NCSNpp, "BeatGANsUNetModel": BeatGANsUNetModel}
+    return models[config.model.name](config)

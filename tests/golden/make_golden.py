@@ -41,6 +41,10 @@ def _install_standins():
         def device(self):
             return next(self.parameters()).device
 
+        @property
+        def dtype(self):  # Lightning's DeviceDtypeModuleMixin; BeatGANsUNET.py:257 reads it
+            return next(self.parameters()).dtype
+
     pl.LightningModule = LightningModule
     pl.LightningDataModule = object
     sys.modules["pytorch_lightning"] = pl
@@ -300,6 +304,58 @@ def gen_ncsnpp():
         save(f"ncsnpp_{name}.npz", **out)
 
 
+def beatgans_config(**over):
+    c = ConfigDict()
+    c.data = ConfigDict(image_size=16, effective_image_size=16, num_channels=3, centered=False, shape=[3, 16, 16])
+    c.training = ConfigDict(continuous=True, sde="vesde")
+    c.model = ConfigDict(
+        name="BeatGANsUNetModel", sigma_min=0.01, sigma_max=50, num_scales=1000, image_size=16, in_channels=3,
+        model_channels=32, out_channels=3, num_res_blocks=1, num_input_res_blocks=None, embed_channels=16,
+        attention_resolutions=(8,), time_embed_channels=None, dropout=0.1, channel_mult=(1, 1, 2),
+        input_channel_mult=None, conv_resample=True, dims=2, num_classes=None, use_checkpoint=False, num_heads=1,
+        num_head_channels=-1, num_heads_upsample=-1, resblock_updown=True, use_new_attention_order=False,
+        resnet_two_cond=False, resnet_cond_channels=None, resnet_use_zero_module=True, attn_checkpoint=False)
+    for k, v in over.items():
+        c[k] = v
+    return c
+
+
+BEATGANS_VARIANTS = {
+    "paper_like": {},                                                  # style_gan_BeatGAN.py:29-82 at reduced size
+    "plain_resample": {"model.resblock_updown": False, "model.num_res_blocks": 2,
+                       "model.resnet_use_zero_module": False},          # Downsample/Upsample with 3x3 convs
+}
+
+
+def gen_beatgans():
+    from models import BeatGANsUNET  # noqa: F401  (registers the model)
+    for name, over in BEATGANS_VARIANTS.items():
+        torch.manual_seed(0)
+        cfg = beatgans_config(**over)
+        model = mutils.create_model(cfg)
+        # the reference zero-initialises every block's last conv, the attention projection and the output conv
+        # (BeatGANs_nn.py:73-79); random values there make the fixture exercise every branch
+        g = torch.Generator().manual_seed(3)
+        with torch.no_grad():
+            for prm in model.parameters():
+                if float(prm.abs().sum()) == 0.0:
+                    prm.copy_(torch.randn(prm.shape, generator=g) * 0.05)
+        sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50, N=1000)
+        score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
+        gx = torch.Generator().manual_seed(1)
+        x = torch.rand(2, 3, 16, 16, generator=gx)
+        t = torch.tensor([1e-5, 0.2])
+        with torch.no_grad():
+            y = score_fn(x, t)
+            raw = model.eval()(x, t * 999)
+        out = sd_arrays(model)
+        out["x"] = x.numpy(); out["t"] = t.numpy(); out["score"] = y.numpy(); out["model_out"] = raw.numpy()
+        over_keys = sorted(over)
+        out["override_keys"] = np.array(over_keys, dtype="U64")
+        out["override_vals"] = np.array([repr(over[k]) for k in over_keys], dtype="U64")
+        save(f"beatgans_{name}.npz", **out)
+
+
 def gen_ksphere():
     from lightning_data_modules.KSphereDataset import KSphereDataset
     out = {}
@@ -365,8 +421,8 @@ def gen_svd_and_rule():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "fcn", "ncsnpp", "ksphere", "svd"]
+    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "fcn", "ncsnpp", "ksphere", "svd", "beatgans"]
     table = {"upfirdn2d": gen_upfirdn2d, "fused_act": gen_fused_act, "sde": gen_sde, "fcn": gen_fcn,
-             "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule}
+             "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule, "beatgans": gen_beatgans}
     for w in which:
         table[w]()

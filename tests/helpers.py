@@ -55,3 +55,19 @@ def rel_err(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def beatgans_config(**over):
+    c = ConfigDict()
+    c.data = ConfigDict(image_size=16, effective_image_size=16, num_channels=3, centered=False, shape=[3, 16, 16])
+    c.training = ConfigDict(continuous=True, sde="vesde", batch_size=128)
+    c.model = ConfigDict(
+        name="BeatGANsUNetModel", sigma_min=0.01, sigma_max=50, num_scales=1000, image_size=16, in_channels=3,
+        model_channels=32, out_channels=3, num_res_blocks=1, num_input_res_blocks=None, embed_channels=16,
+        attention_resolutions=(8,), time_embed_channels=None, dropout=0.1, channel_mult=(1, 1, 2),
+        input_channel_mult=None, conv_resample=True, dims=2, num_classes=None, use_checkpoint=False, num_heads=1,
+        num_head_channels=-1, num_heads_upsample=-1, resblock_updown=True, use_new_attention_order=False,
+        resnet_two_cond=False, resnet_cond_channels=None, resnet_use_zero_module=True, attn_checkpoint=False)
+    for k, v in over.items():
+        c[k] = v
+    return c

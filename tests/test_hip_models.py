@@ -4,7 +4,8 @@ import pytest
 import torch
 
 import id_diff_amd
-from helpers import fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden, rel_err
+from helpers import (beatgans_config, fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden,
+                     rel_err)
 from id_diff_amd import _lib, dim_reduction, plot_utils, sde_lib
 from id_diff_amd.configs.utils import read_config
 from id_diff_amd.models import utils as mutils
@@ -49,6 +50,41 @@ def test_ncsnpp_golden(golden, variant):
     assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
     y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x, t)
     assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+
+
+@pytest.mark.parametrize("variant", ["paper_like", "plain_resample"])
+def test_beatgans_golden(golden, variant):
+    z = golden(f"beatgans_{variant}.npz")
+    model = mutils.create_model(beatgans_config(**overrides_from_golden(z)))
+    model.load_state_dict(state_dict_from_golden(z))
+    model.to(DEV)
+    x, t = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV)
+    raw = model(x, t * 999)
+    assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
+    y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x, t)
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+
+
+def test_beatgans_config5_architecture_vs_oracle():
+    """BASELINE config 5 network (64x64x3, model_channels 128, mult (1,1,2,3,4)) at B=2, zero-initialised convs
+    replaced by random values so that every branch contributes."""
+    cfg = read_config('configs/dimension_estimation/extra_experiments/styleGAN/style_gan_64d_BeatGAN.py')
+    torch.manual_seed(0)
+    ref_model = omodels.create_model(cfg)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for prm in ref_model.parameters():
+            if float(prm.abs().sum()) == 0.0:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.02)
+    model = mutils.create_model(cfg)
+    assert sum(p.numel() for p in model.parameters()) == sum(p.numel() for p in ref_model.parameters())
+    model.load_state_dict(ref_model.state_dict())
+    model.to(DEV)
+    x, t = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)), torch.tensor([1e-5, 0.3])
+    with torch.no_grad():
+        ref = osde.get_score_fn(osde.VESDE(0.01, 50, 1000), ref_model)(x, t)
+    y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x.to(DEV), t.to(DEV))
+    assert rel_err(y.cpu(), ref) < NET_RTOL
 
 
 def test_ncsnpp_benchmark_width_vs_oracle():

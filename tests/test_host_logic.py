@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import id_diff_amd
-from helpers import fcn_config, ncsnpp_config
+from helpers import beatgans_config, fcn_config, ncsnpp_config
 from id_diff_amd import dim_reduction, parallel, plot_utils, sde_lib
 from id_diff_amd.configs.config_dict import ConfigDict
 from id_diff_amd.configs.utils import read_config
@@ -69,6 +69,10 @@ def test_state_dict_keys_match_reference(golden):
     z = golden("fcn_tiny.npz")
     model = mutils.create_model(fcn_config(hidden_nodes=64))
     model.load_state_dict(state_dict_from_golden(z), strict=True)
+    for variant in ["paper_like", "plain_resample"]:
+        z = golden(f"beatgans_{variant}.npz")
+        model = mutils.create_model(beatgans_config(**overrides_from_golden(z)))
+        model.load_state_dict(state_dict_from_golden(z), strict=True)
 
 
 def test_benchmark_model_size():
@@ -78,6 +82,14 @@ def test_benchmark_model_size():
     assert sum(p.numel() for p in model.parameters()) == 62758915
     oracle_model = omodels.create_model(cfg)
     assert sorted(oracle_model.state_dict()) == sorted(model.state_dict())
+
+
+def test_config5_model_size():
+    cfg = read_config('configs/dimension_estimation/extra_experiments/styleGAN/style_gan_64d_BeatGAN.py')
+    model = mutils.create_model(cfg)
+    n = sum(p.numel() for p in model.parameters())
+    assert abs(n / 1e6 - 87.5) < 0.5, n     # 87.5 M parameters
+    assert sorted(omodels.create_model(cfg).state_dict()) == sorted(model.state_dict())
 
 
 def test_models_fail_loudly_on_cpu():

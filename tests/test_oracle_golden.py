@@ -3,7 +3,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden, rel_err
+from helpers import (beatgans_config, fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden,
+                     rel_err)
 from oracle import ops as oops, sde as osde, models as omodels, ksphere as oks, dim as odim
 
 
@@ -82,6 +83,19 @@ def test_ncsnpp_score_fn(golden, variant):
         raw = model.eval()(x, t * 999)
         y = osde.get_score_fn(osde.VESDE(0.01, 50, 1000), model)(x, t)
     # same ATen kernels on the same host; the einsum contraction order is the only freedom
+    assert rel_err(raw, z["model_out"]) < 2e-6
+    assert rel_err(y, z["score"]) < 2e-6
+
+
+@pytest.mark.parametrize("variant", ["paper_like", "plain_resample"])
+def test_beatgans_score_fn(golden, variant):
+    z = golden(f"beatgans_{variant}.npz")
+    model = omodels.create_model(beatgans_config(**overrides_from_golden(z)))
+    model.load_state_dict(state_dict_from_golden(z), strict=True)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    with torch.no_grad():
+        raw = model.eval()(x, t * 999)
+        y = osde.get_score_fn(osde.VESDE(0.01, 50, 1000), model)(x, t)
     assert rel_err(raw, z["model_out"]) < 2e-6
     assert rel_err(y, z["score"]) < 2e-6
 
