@@ -11,6 +11,7 @@
 // the exact Gram matrix up to fp64 summation error: squaring the condition number costs ~1e-16 * cond^2
 // relative, far inside the 1e-4 tolerance for the cliffs the ID rule looks for (cond ~ 1e2..1e4).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -331,6 +332,132 @@ __global__ void tridiag_fused_tail_kernel(const double *__restrict__ A, int D, d
   if (threadIdx.x == 0 && blockIdx.x == 0) { diag[D - 1] = A[(int64_t)(D - 1) * D + (D - 1)]; offd[D - 1] = 0.0; }
 }
 
+
+// ------------------------------------------------------------------------------------------------ tridiag, prep + stream
+// Two launches per Householder step, vectors indexed by GLOBAL row/column g (step k works on g >= base = k+1):
+//   prep   (1 workgroup, 1024 threads): p = tau * (sum of the column-segment partials of the previous stream pass),
+//          K = (tau/2) p.v, w = p - K v, then the updated first row of the block -> next reflector v', tau',
+//          diag[k+1], offd[k+1].
+//   stream (grid = row blocks x 512-column segments): a = A[i][j] - v_i w_j - w_i v_j, store, and the partial
+//          dot products part[seg][i] = sum_{j in seg} a * v'_j for the next step.
+// The stream pass touches every element once with 16-byte accesses and needs no LDS for the vectors (a thread
+// keeps the 3 x 2 vector entries of its two columns in registers), so it also serves D = 12288 (config 5), where
+// the Gram matrix (1.2 GB) no longer fits the Infinity Cache and three LDS-resident vectors would not fit a CU.
+constexpr int SEG_COLS = 512;
+constexpr int PREP_THREADS = 1024;
+constexpr int PREP_MAX_PER_THREAD = 12;          // D <= 12288
+constexpr int STREAM_D_MAX = PREP_THREADS * PREP_MAX_PER_THREAD;
+
+__device__ __forceinline__ double block_sum_1024(double v, double *buf /* >= 16 */) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < PREP_THREADS / 64; ++i) s += buf[i];
+  return s;
+}
+
+__global__ void __launch_bounds__(PREP_THREADS)
+tridiag_prep_kernel(const double *__restrict__ A, int D, int k, const double *__restrict__ v, const double *__restrict__ part,
+                    int nseg, int direct_p, const double *__restrict__ tau_in, double *__restrict__ w,
+                    double *__restrict__ v_next, double *__restrict__ tau_next, double *__restrict__ diag,
+                    double *__restrict__ offd) {
+  __shared__ double red[16];
+  __shared__ double bc[2];
+  const int base = k + 1, tid = threadIdx.x;
+  const double tau = *tau_in;
+  double pv[PREP_MAX_PER_THREAD], vv[PREP_MAX_PER_THREAD];
+  double dot = 0.0;
+#pragma unroll
+  for (int u = 0; u < PREP_MAX_PER_THREAD; ++u) {
+    const int g = base + tid + u * PREP_THREADS;
+    pv[u] = 0.0; vv[u] = 0.0;
+    if (g < D) {
+      double s = 0.0;
+      if (direct_p) s = part[g];
+      else { for (int sg = 0; sg < nseg; ++sg) s += part[(int64_t)sg * D + g]; s *= tau; }
+      pv[u] = s; vv[u] = v[g];
+      dot += s * vv[u];
+    }
+  }
+  const double K = 0.5 * tau * block_sum_1024(dot, red);
+  if (tid == 0) { bc[0] = vv[0]; bc[1] = pv[0] - K * vv[0]; }   // v[base], w[base]
+  __syncthreads();
+  const double v0 = bc[0], w0 = bc[1];
+  const double *row0 = A + (int64_t)base * D;
+  double rv[PREP_MAX_PER_THREAD];
+  double tail = 0.0;
+#pragma unroll
+  for (int u = 0; u < PREP_MAX_PER_THREAD; ++u) {
+    const int g = base + tid + u * PREP_THREADS;
+    rv[u] = 0.0;
+    if (g < D) {
+      const double wg = pv[u] - K * vv[u];
+      w[g] = wg;
+      if (g > base) {
+        rv[u] = row0[g] - v0 * wg - w0 * vv[u];
+        if (g > base + 1) tail += rv[u] * rv[u];
+      }
+    }
+  }
+  const double tail_sq = block_sum_1024(tail, red);
+  if (tid == 1) bc[0] = rv[0];                                   // thread 1, u = 0 holds g = base + 1
+  __syncthreads();
+  const Reflector h = make_reflector(bc[0], tail_sq);
+#pragma unroll
+  for (int u = 0; u < PREP_MAX_PER_THREAD; ++u) {
+    const int g = base + tid + u * PREP_THREADS;
+    if (g < D && g > base) v_next[g] = (g == base + 1) ? h.v0 : rv[u];
+  }
+  if (tid == 0) {
+    *tau_next = h.tau;
+    diag[k + 1] = row0[base] - 2.0 * v0 * w0;
+    offd[k + 1] = h.alpha;
+  }
+}
+
+template <int R>
+__global__ void __launch_bounds__(256)
+tridiag_stream_kernel(double *__restrict__ A, int D, int k, const double *__restrict__ v, const double *__restrict__ w,
+                      const double *__restrict__ x, double *__restrict__ part) {
+  __shared__ double red[4 * R];
+  const int lo = k + 2;                       // first live row / column of the shrunken block
+  const int galign = lo & ~1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g0 = galign + blockIdx.y * SEG_COLS + 2 * tid;   // this thread's column pair (g0, g0+1), g0 even
+  const bool in0 = g0 >= lo && g0 < D, in1 = g0 + 1 >= lo && g0 + 1 < D;
+  double vj0 = 0, vj1 = 0, wj0 = 0, wj1 = 0, xj0 = 0, xj1 = 0;
+  if (in0) { vj0 = v[g0]; wj0 = w[g0]; xj0 = x[g0]; }
+  if (in1) { vj1 = v[g0 + 1]; wj1 = w[g0 + 1]; xj1 = x[g0 + 1]; }
+  const int i0 = lo + blockIdx.x * R;
+  double acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    acc[r] = 0.0;
+    const int gi = i0 + r;
+    if (gi < D && (in0 || in1)) {
+      const double vi = v[gi], wi = w[gi];
+      double2 *ap = reinterpret_cast<double2 *>(A + (int64_t)gi * D + g0);
+      double2 a = *ap;
+      a.x -= vi * wj0 + wi * vj0;             // masked columns carry zeros: the element is rewritten unchanged
+      a.y -= vi * wj1 + wi * vj1;
+      *ap = a;
+      acc[r] = a.x * xj0 + a.y * xj1;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = wave_sum_d(acc[r]);
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) red[wave * R + r] = acc[r];
+  }
+  __syncthreads();
+  if (tid < R && i0 + tid < D)
+    part[(int64_t)blockIdx.y * D + i0 + tid] = red[tid] + red[R + tid] + red[2 * R + tid] + red[3 * R + tid];
+}
+
 // ------------------------------------------------------------------------------------------------ tridiag, D <= 128 in LDS
 // One workgroup per matrix; the whole matrix lives in LDS (pitch D+1 doubles).  Used for the batched
 // k-sphere workload (P matrices of 100 x 100).
@@ -554,7 +681,7 @@ IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double
     hipLaunchKernelGGL(tridiag_small_kernel, dim3(P), dim3(256), lds, st, G, D, diag, offdiag);
     return launch_status("tridiag_small");
   }
-  if (!scratch) return fail("symtridiag: scratch (4*D+16 doubles) required for D > %d", SMALL_D_MAX);
+  if (!scratch) return fail("symtridiag: scratch (4*D+16 + (ceil(D/512)+1)*D doubles) required for D > %d", SMALL_D_MAX);
   if ((size_t)D * sizeof(double) > 60 * 1024) {
     static bool attr_set2 = false;
     if (!attr_set2) {
@@ -566,6 +693,37 @@ IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double
     if ((size_t)D * sizeof(double) > 160 * 1024 - 256) return fail("symtridiag: D=%d exceeds the LDS-resident reflector", D);
   }
   double *v = scratch, *pvec = scratch + D, *tau = scratch + 2 * D;
+  if (D % 2 == 0 && D <= STREAM_D_MAX && !getenv("IDIFF_TRIDIAG_FUSED")) {
+    // scratch: v0[D] | v1[D] | w[D] | p0[D] | tau[2] | part[nseg_max][D]
+    const int nseg_max = ceil_div(D, SEG_COLS) + 1;
+    double *vb[2] = {scratch, scratch + (int64_t)D};
+    double *wv = scratch + 2 * (int64_t)D, *p0 = scratch + 3 * (int64_t)D, *tb = scratch + 4 * (int64_t)D;
+    double *part = scratch + 4 * (int64_t)D + 16;
+    (void)nseg_max;
+    for (int p = 0; p < P; ++p) {
+      double *A = G + (int64_t)p * D * D;
+      double *dg = diag + (int64_t)p * D, *od = offdiag + (int64_t)p * D;
+      const int n0 = D - 1;
+      // step 0: reflector + p_0 by the symv kernel (v and p are local-indexed there: shift to global index 1)
+      hipLaunchKernelGGL(tridiag_symv_kernel, dim3(max(1, min(ceil_div(n0, 4), 1024))), dim3(256),
+                         (size_t)n0 * sizeof(double), st, A, D, 0, vb[0] + 1, p0 + 1, dg, od, tb);
+      int nseg_prev = 1;
+      for (int k = 0; k + 2 < D; ++k) {
+        const int cur = k & 1, nxt = cur ^ 1;
+        hipLaunchKernelGGL(tridiag_prep_kernel, dim3(1), dim3(PREP_THREADS), 0, st, A, D, k, vb[cur], k == 0 ? p0 : part,
+                           nseg_prev, k == 0 ? 1 : 0, tb + cur, wv, vb[nxt], tb + nxt, dg, od);
+        const int lo = k + 2, galign = lo & ~1;
+        const int rows = D - lo, nseg = ceil_div(D - galign, SEG_COLS);
+        if (rows >= 8 * 96)
+          hipLaunchKernelGGL(tridiag_stream_kernel<8>, dim3(ceil_div(rows, 8), nseg), dim3(256), 0, st, A, D, k, vb[cur], wv, vb[nxt], part);
+        else
+          hipLaunchKernelGGL(tridiag_stream_kernel<2>, dim3(ceil_div(rows, 2), nseg), dim3(256), 0, st, A, D, k, vb[cur], wv, vb[nxt], part);
+        nseg_prev = nseg;
+      }
+      hipLaunchKernelGGL(tridiag_fused_tail_kernel, dim3(1), dim3(64), 0, st, A, D, dg, od);
+    }
+    return launch_status("symtridiag_stream");
+  }
   if (D <= FUSED_D_MAX) {
     static bool attr_fused = false;
     if (!attr_fused) {
@@ -627,11 +785,13 @@ IDIFF_API int idiff_tridiag_eigvals_f64(const double *diag, const double *offdia
   return bisect_launch(diag, offdiag, P, D, eig, nullptr, (hipStream_t)stream);
 }
 
-// workspace layout (doubles): mean[P*D] | colsum partials[P*32*D] | G[P*D*D] | diag[P*D] | offd[P*D] | scratch[4*D+16]
+// workspace layout (doubles): mean[P*D] | colsum partials[P*32*D] | G[P*D*D] | diag[P*D] | offd[P*D] |
+//                             scratch[4*D+16 + (ceil(D/512)+1)*D]
 IDIFF_API int64_t idiff_spectrum_workspace_bytes(int P, int M, int D) {
   (void)M;
   if (P <= 0 || D <= 0) return 0;
-  const int64_t n = (int64_t)P * D * (1 + MEAN_SPLITS) + (int64_t)P * D * D + 2 * (int64_t)P * D + 4 * (int64_t)D + 16;
+  const int64_t n = (int64_t)P * D * (1 + MEAN_SPLITS) + (int64_t)P * D * D + 2 * (int64_t)P * D + 4 * (int64_t)D + 16 +
+                    (int64_t)((D + 511) / 512 + 1) * D;
   return n * (int64_t)sizeof(double);
 }
 
