@@ -26,12 +26,18 @@ def smooth_decoder_images(n, shape, latent_dim, seed):
 
 
 class SyntheticImageDataset(Dataset):
+    """With ``data.return_labels`` items are (image, label) pairs, label = index % 2, which is what the
+    conditional estimator iterates over (dim_reduction.py:50-57 keeps label == 1)."""
+
     def __init__(self, config):
         d = config.data
         self.data = smooth_decoder_images(d.get('data_samples', 256), list(d.shape), d.get('latent_dim', 64),
                                           d.get('data_seed', 0))
+        self.return_labels = bool(d.get('return_labels', False))
 
     def __getitem__(self, index):
+        if self.return_labels:
+            return self.data[index], index % 2
         return self.data[index]
 
     def __len__(self):

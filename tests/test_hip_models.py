@@ -201,3 +201,41 @@ def test_exact_score_vs_oracle():
     ref = osde.get_score_fn(osde.VESDE(1e-2, 4, 1000), oks.KSphereExact(100, 10, 1e-2, 4))(x, t)
     y = mutils.get_score_fn(sde_lib.VESDE(1e-2, 4, 1000), model)(x.to(DEV), t.to(DEV))
     assert rel_err(y.cpu(), ref) < 1e-4
+
+
+def test_conditional_manifold_dimension_layout(tmp_path):
+    """get_conditional_manifold_dimension (dim_reduction.py:12-114): 12 noise levels, label==1 points only, three
+    pickles per level."""
+    import os, pickle
+    cfg = ncsnpp_config(**{"model.init_scale": 1.0, "model.attn_resolutions": (8,), "data.image_size": 16,
+                           "data.effective_image_size": 16, "data.shape": [3, 16, 16], "model.num_res_blocks": 1})
+    cfg.data.datamodule = 'image_synthetic'
+    cfg.data.data_samples = 200
+    cfg.data.latent_dim = 4
+    cfg.training.batch_size = 100
+    cfg.training.lightning_module = 'base'
+    cfg.validation = type(cfg)(batch_size=100)
+    cfg.model.checkpoint_path = None
+    cfg.logging = type(cfg)(log_path=str(tmp_path), log_name='cond')
+    cfg.dim_estimation = type(cfg)(num_datapoints=3)
+    cfg.device = DEV
+    cfg.seed = 7
+    dim_reduction.get_conditional_manifold_dimension(cfg)
+    root = os.path.join(str(tmp_path), 'cond', 'svd')
+    levels = sorted(os.listdir(root))
+    assert len(levels) == 12 and levels[0] == '0.000' and levels[-1] == '0.300'
+    first = None
+    for lv in levels:
+        with open(os.path.join(root, lv, 'labels_svd.pkl'), 'rb') as f:
+            sv = pickle.load(f)['singular_values']
+        with open(os.path.join(root, lv, 'labels.pkl'), 'rb') as f:
+            labels = pickle.load(f)['labels']
+        with open(os.path.join(root, lv, 'images.pkl'), 'rb') as f:
+            imgs = pickle.load(f)['images']
+        assert labels == [1, 1] and len(sv) == 2 and imgs.shape == (2, 16, 16, 3)   # num_datapoints=3 -> 2 points
+        # the validation split has 20 items, so the loader batch (= rows per score batch) is 20:
+        # ambient 256 -> (256 // 20 + 1) * 4 = 52 batches, 51 * 20 + 16 = 1036 rows >= 768 columns
+        assert all(len(s) == 768 for s in sv)
+        assert all(s[i] >= s[i + 1] for s in sv for i in range(len(s) - 1))
+        first = first or sv
+    assert first != sv     # the spectrum depends on the noise level

@@ -34,6 +34,33 @@ def test_fused_leaky_relu_matches_reference_cpu_branch(golden):
                                    torch.from_numpy(z[f"c{i}::y_slope0.05_scale1.25"]), rtol=1e-6, atol=1e-7)
 
 
+def test_c_restatement_of_native_ops(golden):
+    """oracle/native_ops.c (plain C, the CUDA kernels' index algebra) against the reference's outputs."""
+    from oracle import c_ops
+    z = golden("upfirdn2d.npz")
+    for i in range(int(z["n_cases"])):
+        up, down, p0, p1 = (int(v) for v in z[f"c{i}::params"])
+        x = z[f"c{i}::x"]
+        n, c, h, w = x.shape
+        y = c_ops.upfirdn2d(x.reshape(n * c, h, w, 1), z[f"c{i}::k"], up, up, down, down, p0, p1, p0, p1)
+        np.testing.assert_allclose(y.reshape(z[f"c{i}::y"].shape), z[f"c{i}::y"], rtol=1e-5, atol=1e-6)
+    ux, uy, dx, dy, px0, px1, py0, py1 = (int(v) for v in z["xy::params"])
+    x = z["xy::x"]
+    y = c_ops.upfirdn2d(x.reshape(-1, x.shape[2], x.shape[3], 1), z["xy::k"], ux, uy, dx, dy, px0, px1, py0, py1)
+    np.testing.assert_allclose(y.reshape(z["xy::y"].shape), z["xy::y"], rtol=1e-5, atol=1e-6)
+    z = golden("fused_act.npz")
+    for i in range(int(z["n_cases"])):
+        y = c_ops.fused_bias_act(z[f"c{i}::x"], z[f"c{i}::b"], None, 3, 0, 0.2, 2 ** 0.5)
+        np.testing.assert_allclose(y, z[f"c{i}::y_default"], rtol=1e-6, atol=1e-7)
+    # NHWC (minor = C) agrees with the NCHW view
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 6, 9, 7, generator=g)
+    k = torch.randn(4, 4, generator=g)
+    ref = oops.upfirdn2d(x, k, up=2, down=1, pad=(2, 1)).permute(0, 2, 3, 1).numpy()
+    y = c_ops.upfirdn2d(x.permute(0, 2, 3, 1).numpy(), k.numpy(), 2, 2, 1, 1, 2, 1, 2, 1)
+    np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6)
+
+
 def test_sde_marginals(golden):
     z = golden("sde.npz")
     t, x = torch.from_numpy(z["t"]), torch.from_numpy(z["x"])
