@@ -47,7 +47,7 @@ class ConvProbe:
         def timed(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue=None, pad_hi=None):
             # only launches that dispatch to the dominant 128x128 template (csrc/igemm.hip: dispatch())
             rows_out = out.numel() // Cout
-            big = Cout > 64 and ((rows_out + 127) // 128) * ((Cout + 127) // 128) >= 256
+            big = Cout > 64 and ((rows_out + 127) // 128) * ((Cout + 127) // 128) >= 1024 and Cin % 32 == 0
             if not (probe.active and KH == 3 and big):
                 return probe._orig(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue, pad_hi)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -206,7 +206,7 @@ def main():
         conv = probe.summary()
         roofline = None
         if conv:
-            roofline = {"bound": "mfma", "kernel": "igemm_pipe_kernel<128,128,2,2,CONV> (3x3 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+            roofline = {"bound": "mfma", "kernel": "igemm_pipe_kernel<128,128,2,2,CONV,single-buffer> (3x3 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                         "achieved": conv["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": conv["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                         "launches_sampled": conv["launches"], "avg_launch_us": conv["avg_us"]}

@@ -271,10 +271,14 @@ int launch_cfg(IgemmParams &p, int batch, hipStream_t st) {
 //   * the conv loader keeps (tap, channel) as uniform counters advanced per k-tile (Cin % 32 == 0: a k-tile
 //     never straddles a tap) and a per-row 9-bit tap-validity mask computed once, instead of two integer
 //     divisions per thread per k-tile;
-//   * global loads run TWO k-tiles ahead: in iteration t the registers holding tile t+1 are written to the
-//     other LDS buffer, then reloaded with tile t+2, then the 64 MFMAs of tile t issue.  The non-MFMA part of
-//     an iteration shrinks to ~60 instructions, which matters because the two waves that share a SIMD run the
-//     same program and drift into lockstep (both in their non-MFMA phase at once = idle matrix pipe).
+//   * global loads run TWO k-tiles ahead: in iteration t the registers holding tile t+1 are written to
+//     LDS, then reloaded with tile t+2, while the 64 MFMAs of tile t issue.  The non-MFMA part of an iteration
+//     shrinks to ~60 instructions, which matters because the waves that share a SIMD run the same program and
+//     drift into lockstep (all in their non-MFMA phase at once = idle matrix pipe);
+//   * two residency forms: DBUF (two LDS buffers, one barrier per k-tile, 2 workgroups per CU) for grids that
+//     cannot fill the chip four times over, and the single-buffer form (two barriers per k-tile, 36.9 KB LDS,
+//     128 registers -> FOUR workgroups per CU) whose extra resident waves cover each other's barrier and
+//     staging phases: 135-139 TFLOP/s on the conv shapes of NCSN++ (0.86-0.88 of the fp32 MFMA peak).
 // Requires 16-byte aligned K-contiguous operands, slices < 4 GiB and (conv) Cin % 32 == 0; everything else
 // takes the general kernel above.
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
@@ -285,8 +289,8 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t b
   return __builtin_bit_cast(float4, v);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV>
-__global__ void __launch_bounds__(WARPS_M *WARPS_N * 64)
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF>
+__global__ void __launch_bounds__(WARPS_M *WARPS_N * 64, DBUF ? 2 : 4)
 igemm_pipe_kernel(const IgemmParams p) {
   constexpr int T = WARPS_M * WARPS_N * 64;
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
@@ -297,7 +301,7 @@ igemm_pipe_kernel(const IgemmParams p) {
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *As = lds;
-  float *Bs = lds + 2 * BM * LDS_PITCH;
+  float *Bs = lds + (DBUF ? 2 : 1) * BM * LDS_PITCH;
 
   const int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
@@ -410,9 +414,11 @@ igemm_pipe_kernel(const IgemmParams p) {
   __syncthreads();
 
   for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) stage(buf ^ 1);   // tile kt+1: loaded one iteration ago
-    if (kt + 2 < nkt) fetch();          // tile kt+2: lands while this tile's 64 MFMAs run
+    const int buf = DBUF ? (kt & 1) : 0;
+    if (DBUF) {
+      if (kt + 1 < nkt) stage(buf ^ 1);   // tile kt+1: loaded one iteration ago
+      if (kt + 2 < nkt) fetch();          // tile kt+2: lands while this tile's 64 MFMAs run
+    }
     const float *a_src = As + buf * BM * LDS_PITCH + (wm0 + frag_row) * LDS_PITCH + frag_k;
     const float *b_src = Bs + buf * BN * LDS_PITCH + (wn0 + frag_row) * LDS_PITCH + frag_k;
 #pragma unroll
@@ -433,6 +439,13 @@ igemm_pipe_kernel(const IgemmParams p) {
         }
     }
     __syncthreads();
+    if (!DBUF) {
+      // single LDS buffer (half the LDS -> three workgroups per CU): restage between two barriers; the other
+      // resident workgroups keep the matrix pipe busy meanwhile
+      if (kt + 1 < nkt) stage(0);
+      if (kt + 2 < nkt) fetch();
+      __syncthreads();
+    }
   }
 
   float *Cb = p.C + (int64_t)batch * p.strideC;
@@ -463,12 +476,12 @@ igemm_pipe_kernel(const IgemmParams p) {
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF = true>
 int launch_pipe(IgemmParams &p, int batch, hipStream_t st) {
   p.tiles_m = idiff::ceil_div(p.M, BM);
   p.tiles_n = idiff::ceil_div(p.N, BN);
-  constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(float);
-  auto kern = igemm_pipe_kernel<BM, BN, WARPS_M, WARPS_N, CONV>;
+  constexpr size_t lds_bytes = (size_t)(DBUF ? 2 : 1) * (BM + BN) * LDS_PITCH * sizeof(float);
+  auto kern = igemm_pipe_kernel<BM, BN, WARPS_M, WARPS_N, CONV, DBUF>;
   static bool attr_set = false;
   if (lds_bytes > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -487,6 +500,9 @@ int launch_pipe(IgemmParams &p, int batch, hipStream_t st) {
 template <bool CONV>
 int dispatch_pipe(IgemmParams &p, int batch, hipStream_t st) {
   const int64_t wg_big = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 128) * batch;
+  // >= 4 workgroups per CU available: single LDS buffer, 128 registers, four resident workgroups per CU
+  // (measured 135-142 TFLOP/s vs 124-135 for the double-buffered two-workgroup form)
+  if (p.N > 64 && wg_big >= 1024 && !getenv("IDIFF_DBUF_ONLY")) return launch_pipe<128, 128, 2, 2, CONV, false>(p, batch, st);
   if (p.N > 64 && wg_big >= 256) return launch_pipe<128, 128, 2, 2, CONV>(p, batch, st);
   const int64_t wg_mid = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 64) * batch;
   if (wg_mid >= 256 || p.M >= 4096) return launch_pipe<128, 64, 2, 2, CONV>(p, batch, st);
