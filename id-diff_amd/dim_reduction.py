@@ -115,6 +115,25 @@ class SpectrumPipeline:
         return out
 
 
+def build_many(builder, xs, batchsize, generators):
+    """S [P, M, D] for P small (vector) points with ONE score_fn call over all P*M rows: the k-sphere workload is
+    launch-bound one point at a time (M = 1501 rows of a 7-layer MLP), so points are batched (BASELINE config 2)."""
+    x0 = xs[0]
+    _, _, rows = batching(tuple(x0.shape), batchsize)
+    D, P, dev = x0.numel(), len(xs), builder.device
+    vec_t = torch.full((rows,), float(builder.eps), device=dev, dtype=torch.float32)
+    mean_unit, std = builder.sde.marginal_prob(torch.ones((), device=dev), vec_t)
+    coeff = None if mean_unit.ndim == 0 else mean_unit.reshape(-1).contiguous()
+    std = std.contiguous()
+    batch = torch.empty(P, rows, D, device=dev, dtype=torch.float32)
+    for i, (x, gen) in enumerate(zip(xs, generators)):
+        z = torch.randn(rows, D, device=dev, dtype=torch.float32, generator=gen)
+        _lib.perturb(x.reshape(-1).contiguous(), z, std, coeff, batch[i], rows, D)
+    t_all = torch.full((P * rows,), float(builder.eps), device=dev, dtype=torch.float32)
+    score = builder.score_fn(batch.view(P * rows, *x0.shape), t_all)
+    return score.reshape(P, rows, D)
+
+
 def setup_model(config):
     """Steps :123-141 of the reference: data module, module + checkpoint, SDE, device, score_fn."""
     DataModule = create_lightning_datamodule(config)
@@ -167,12 +186,26 @@ def get_manifold_dimension(config, name=None, return_svd=False):
     mine = parallel.my_points(len(points), rank, world)
     n_sv = None
     pipe = SpectrumPipeline(device, overlap=bool(config.get('dim_estimation.overlap_spectrum', True)))
+    def point_generator(p):
+        return torch.Generator(device=device).manual_seed(seed + 1000003 * (p + 1))
+
     with torch.no_grad():
-        for p in mine:
-            x, batchsize = points[p]
-            gen = torch.Generator(device=device).manual_seed(seed + 1000003 * (p + 1))
-            pipe.submit(builder.build(x.to(device), batchsize, generator=gen))
-        local = pipe.results()
+        small = bool(mine) and points[mine[0]][0].numel() <= 4096 and len({points[p][1] for p in mine}) == 1
+        if small:
+            # vector data: many points per launch set, batched spectrum kernel (one workgroup per matrix for D <= 128)
+            rows = batching(tuple(points[mine[0]][0].shape), points[mine[0]][1])[2]
+            group = max(1, min(len(mine), int(config.get('dim_estimation.points_per_launch', max(1, 131072 // rows)))))
+            for lo in range(0, len(mine), group):
+                ids = mine[lo:lo + group]
+                S = build_many(builder, [points[p][0].to(device) for p in ids], points[ids[0]][1],
+                               [point_generator(p) for p in ids])
+                pipe.submit(S)
+            local = [sv for block in pipe.results() for sv in block]
+        else:
+            for p in mine:
+                x, batchsize = points[p]
+                pipe.submit(builder.build(x.to(device), batchsize, generator=point_generator(p)))
+            local = pipe.results()
     if local:
         n_sv = local[-1].numel()
     if n_sv is None:  # a rank without points still takes part in the exchange
