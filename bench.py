@@ -55,7 +55,7 @@ class ConvProbe:
             r = probe._orig(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue, pad_hi)
             b.record()
             flops = 2.0 * out.numel() * KH * KW * Cin
-            probe.records.append((a, b, flops))
+            probe.records.append((a, b, flops, f"{B}x{H}x{W}x{Cin}->{Cout}"))
             return r
 
         _lib.conv2d_nhwc = timed
@@ -63,9 +63,24 @@ class ConvProbe:
     def summary(self):
         if not self.records:
             return None
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
-        return {"launches": len(self.records), "avg_us": ms * 1e3 / len(self.records), "tflops": fl / (ms * 1e-3) / 1e12}
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        fl = sum(r[2] for r in self.records)
+        return {"launches": len(self.records), "avg_us": ms * 1e3 / len(self.records), "tflops": fl / (ms * 1e-3) / 1e12,
+                "traffic": self.traffic()}
+
+    def traffic(self):
+        """HBM bytes per launch of the sampled shapes, from the committed PMC table (FETCH_SIZE / WRITE_SIZE passes,
+        gfx950 corrections applied; profiles/r01_conv_traffic.json); None if a sampled shape is not in the table."""
+        path = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+        if not os.path.exists(path):
+            return None
+        table = json.load(open(path))["shapes"]
+        keys = [r[3] for r in self.records]
+        if any(k not in table for k in keys):
+            return None
+        return {"bytes_per_launch": sum(table[k]["total_bytes"] for k in keys) / len(keys),
+                "algorithmic_bytes_per_launch": sum(table[k]["algorithmic_bytes"] for k in keys) / len(keys),
+                "source": "profiles/r01_conv_traffic.json"}
 
 
 def cpu_baseline(cfg, rows_per_point, D):
@@ -145,12 +160,13 @@ def main():
         probe.active = False
         pipe.submit(S)   # spectrum of this point overlaps the score evaluations of the next one
 
-    # probe only the first inflight chunk per step: wrap builder.score_fn
+    # probe only one inflight chunk per step: wrap builder.score_fn
     orig_score_fn = builder.score_fn
     state = {"calls": 0}
 
     def sampled_score_fn(x, t):
-        first = state["calls"] == 0
+        # sample one launch set per step: a middle one (the first overlaps the previous point's spectrum)
+        first = state["calls"] == 4
         state["calls"] += 1
         was = probe.active
         probe.active = was and first
@@ -208,7 +224,9 @@ def main():
         if conv:
             roofline = {"bound": "mfma", "kernel": "igemm_pipe_kernel<128,128,2,2,CONV,single-buffer> (3x3 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                         "achieved": conv["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": conv["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "frac": conv["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                        "traffic": conv["traffic"]["bytes_per_launch"] if conv["traffic"] else None,
+                        "traffic_detail": conv["traffic"],
                         "launches_sampled": conv["launches"], "avg_launch_us": conv["avg_us"]}
         line = {
             "metric": "score-vector evals/sec (rows of S per second incl. the per-point spectrum), 32x32 ncsnpp",

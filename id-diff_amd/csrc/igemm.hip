@@ -363,24 +363,30 @@ igemm_pipe_kernel(const IgemmParams p) {
   // uniform k-tile state of the NEXT fetch
   int f_kt = 0, f_c0 = 0, f_tap = 0, f_ky = 0, f_kx = 0;
 
+  const int ntaps = CONV ? p.K / p.Cin : 1;
   auto fetch = [&]() {
     const int k = f_kt * BK + kc;
     const bool kok = k < p.K;
+    uint32_t koffb = (uint32_t)f_kt * (BK * 4u);
     if (CONV) {
+      // k-tiles walk the taps of one 32-channel slice before moving to the next slice (the reduction order is
+      // free): the same input lines are then re-read one (kx) or KW (ky) k-tiles later instead of Cin/32 and
+      // KW*Cin/32 tiles later, i.e. while they are still in the XCD's L2
       const uint32_t tapoff = (uint32_t)((f_ky * p.W + f_kx) * p.Cin + f_c0) * 4u;
+      koffb = (uint32_t)(f_tap * p.Cin + f_c0) * 4u;
 #pragma unroll
       for (int i = 0; i < A_PER_T; ++i) {
         const bool ok = (a_mask[i] >> f_tap) & 1u;
         a_reg[i] = buf_load4(rA, ok ? a_base[i] + tapoff : OOB);
       }
-      f_c0 += BK;
-      if (f_c0 == p.Cin) { f_c0 = 0; ++f_tap; if (++f_kx == p.KW) { f_kx = 0; ++f_ky; } }
+      ++f_tap;
+      if (++f_kx == p.KW) { f_kx = 0; ++f_ky; }
+      if (f_tap == ntaps) { f_tap = 0; f_kx = 0; f_ky = 0; f_c0 += BK; }
     } else {
       const uint32_t koff = (uint32_t)f_kt * (BK * 4u);
 #pragma unroll
       for (int i = 0; i < A_PER_T; ++i) a_reg[i] = buf_load4(rA, (a_mask[i] && kok) ? a_base[i] + koff : OOB);
     }
-    const uint32_t koffb = (uint32_t)f_kt * (BK * 4u);
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) b_reg[i] = buf_load4(rB, (b_ok[i] && kok) ? b_base[i] + koffb : OOB);
     ++f_kt;
