@@ -94,6 +94,49 @@ gn_apply_kernel(const float *__restrict__ x, int C, const float *__restrict__ x2
   }
 }
 
+// Row-structured apply: grid.y = sample, a thread owns one float4 channel column, so mean/rstd/gamma/beta (and
+// the optional scale-shift modulation) collapse into per-thread constants y = act(x * s + t) and the pixel loop
+// is a pure 16-byte stream.  (The flat form above spends ~8 integer divisions per element on index
+// decomposition and ran at 39-44 % of HBM peak.)
+__global__ void __launch_bounds__(256)
+gn_apply_rows_kernel(const float *__restrict__ x, int C, const float *__restrict__ x2, int C2, int HW, int G,
+                     const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
+                     const float *__restrict__ mod, int64_t ld_mod, int act, float *__restrict__ y, int rows_per_block) {
+  const int Ctot = C + C2, CVt = Ctot >> 2, cpg = Ctot / G;
+  const int RP = 256 / CVt;
+  const int tid = threadIdx.x;
+  const int r0 = tid / CVt, c4 = tid - r0 * CVt;
+  if (r0 >= RP) return;
+  const int b = blockIdx.y, c = c4 * 4;
+  float mu[4], s[4], t[4];   // y = act((x - mu) * s + t): the mean is subtracted first, as torch does
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float *st = stats + 2 * ((int64_t)b * G + (c + j) / cpg);
+    float sc = st[1] * gamma[c + j], sh = beta[c + j];
+    if (mod) {
+      const float m1 = 1.0f + mod[(int64_t)b * ld_mod + c + j];
+      sc *= m1;
+      sh = sh * m1 + mod[(int64_t)b * ld_mod + Ctot + c + j];
+    }
+    mu[j] = st[0]; s[j] = sc; t[j] = sh;
+  }
+  const bool first = c < C;
+  const float4 *src = first ? reinterpret_cast<const float4 *>(x + (int64_t)b * HW * C + c)
+                            : reinterpret_cast<const float4 *>(x2 + (int64_t)b * HW * C2 + (c - C));
+  const int src_stride = (first ? C : C2) >> 2;
+  float4 *dst = reinterpret_cast<float4 *>(y + (int64_t)b * HW * Ctot + c);
+  const int p_lo = blockIdx.x * rows_per_block, p_hi = min(HW, p_lo + rows_per_block);
+  for (int p = p_lo + r0; p < p_hi; p += RP) {
+    const float4 v = src[(int64_t)p * src_stride];
+    float4 o;
+    o.x = act_apply((v.x - mu[0]) * s[0] + t[0], act);
+    o.y = act_apply((v.y - mu[1]) * s[1] + t[1], act);
+    o.z = act_apply((v.z - mu[2]) * s[2] + t[2], act);
+    o.w = act_apply((v.w - mu[3]) * s[3] + t[3], act);
+    dst[(int64_t)p * CVt] = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row softmax: one wave per row, values kept in registers for cols <= 1024.
 // ------------------------------------------------------------------------------------------------
@@ -358,6 +401,17 @@ IDIFF_API int idiff_groupnorm_apply_f32(const float *x, int C, const float *x2, 
   if (!al16(x) || (x2 && !al16(x2)) || !al16(y) || !al16(gamma) || !al16(beta))
     return fail("groupnorm_apply: pointers must be 16-byte aligned");
   const int64_t total_vec = (int64_t)B * HW * (Ctot / 4);
+  const int CVt = Ctot / 4;
+  if (CVt <= 256 && B <= 65535) {
+    // ~2048 workgroups in total, each a contiguous range of pixels of one sample
+    const int RP = 256 / CVt;
+    int xblocks = max(1, min(ceil_div(HW, RP), ceil_div(2048, B)));
+    const int rows_per_block = ceil_div(ceil_div(HW, xblocks), RP) * RP;
+    xblocks = ceil_div(HW, rows_per_block);
+    hipLaunchKernelGGL(gn_apply_rows_kernel, dim3(xblocks, B), dim3(256), 0, (hipStream_t)stream, x, C, x2, C2, HW, G, stats,
+                       gamma, beta, mod, ld_mod, act, y, rows_per_block);
+    return launch_status("groupnorm_apply_rows");
+  }
   hipLaunchKernelGGL(gn_apply_kernel, dim3(streaming_grid(total_vec, 256)), dim3(256), 0, (hipStream_t)stream, x, C, x2,
                      C2, HW, G, stats, gamma, beta, mod, ld_mod, act, y, total_vec);
   return launch_status("groupnorm_apply");

@@ -7,12 +7,13 @@
 //   iy in [ceil((oy*down_y - pad_y0)/up_y), floor((oy*down_y + kh-1 - pad_y0)/up_y)] clipped to [0, in_h),
 //   ky = iy*up_y + pad_y0 - oy*down_y.
 //
-// Three kernels, chosen by layout:
-//   planes_lds   minor == 1 (the reference's NCHW view): W is the contiguous axis; a workgroup stages the
-//                input window of a [planes x TOH x TOW] output tile in LDS with coalesced row loads, then
-//                every output pixel reads its taps from LDS.  HBM traffic = algorithmic bytes.
-//   nhwc_vec4    minor % 4 == 0 (NHWC activations of the score networks): a thread owns 4 channels of one
-//                output pixel; every tap is one coalesced float4; neighbours re-read through L1/L2.
+// Kernels, chosen by layout and size:
+//   planes_whole minor == 1 (the reference's NCHW view), planes <= 32 KB: `ppb` consecutive planes are copied to
+//                LDS as one contiguous 16-byte-per-lane stream, every output pixel reads its taps from LDS.
+//   planes_lds   minor == 1, large planes: a workgroup stages the input window of a [TOH x TOW] output tile.
+//   nhwc_rows    minor % 4 == 0 (NHWC activations of the score networks): grid.y = (plane, output row), a thread
+//                owns 4 channels; every tap is one coalesced float4; neighbours re-read through L1/L2.
+//   nhwc_vec4    same layout, flat grid-stride form for shapes the row form cannot index.
 //   generic      anything else, scalar.
 #include "common.h"
 
@@ -121,6 +122,152 @@ upfirdn2d_nhwc_vec4(const float *__restrict__ x, const float *__restrict__ k, fl
   }
 }
 
+
+// ---------------------------------------------------------------- minor == 1, whole planes in LDS
+// The score networks' planes are small (4 KB at 32x32): a workgroup copies `ppb` consecutive planes -- one
+// contiguous chunk of HBM -- into LDS with 16-byte loads, then thread (ty, tx) produces output pixel (oy, ox) of
+// every plane.  No index arithmetic beyond adds in the loops (the tap ranges are clipped once per pixel), the
+// input is read exactly once and the output written exactly once.
+// UPLOG >= 0: up_x == up_y == 1 << UPLOG and kh, kw <= 4 (every FIR the score networks use): the 4x4 tap loop is
+// fully unrolled with the taps in registers, and a tap is "on" when its stuffed coordinate is a multiple of up
+// and inside the image -- per-pixel validity bits and LDS offsets are computed once and reused for all planes.
+template <int UPLOG>
+__global__ void __launch_bounds__(256)
+upfirdn2d_planes_whole(const float *__restrict__ x, const float *__restrict__ k, float *__restrict__ out, UfdParams p,
+                       int ppb, int tx_log2) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *taps = lds;            // [kMaxTaps] flipped
+  float *pl = lds + kMaxTaps;   // [ppb][in_h * in_w]
+  const int tid = threadIdx.x;
+  const int ntap = p.kh * p.kw;
+  for (int i = tid; i < ntap; i += 256) {
+    int ky = i / p.kw, kx = i - ky * p.kw;
+    taps[i] = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+  }
+  const int plane0 = blockIdx.x * ppb;
+  const int nplanes = min(ppb, p.major - plane0);
+  const int psz = p.in_h * p.in_w;
+  const int total = nplanes * psz;
+  const float *src = x + (int64_t)plane0 * psz;
+  if (((psz & 3) == 0) && ((((uintptr_t)src) & 15) == 0)) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(pl);
+    for (int i = tid; i < (total >> 2); i += 256) d4[i] = s4[i];
+  } else {
+    for (int i = tid; i < total; i += 256) pl[i] = src[i];
+  }
+  __syncthreads();
+  // thread -> (tq, ty, tx): TX x TY covers the output tile (powers of two); when the whole plane has fewer than
+  // 256 pixels the remaining thread bits index planes (TQ planes in flight), so no lane idles on 8x8 outputs
+  const int TX = 1 << tx_log2;
+  int ty_log2 = 0;
+  while ((1 << ty_log2) < p.out_h && (TX << ty_log2) < 256) ++ty_log2;
+  const int TY = 1 << ty_log2, TQ = 256 >> (tx_log2 + ty_log2);
+  const int tx = tid & (TX - 1), ty = (tid >> tx_log2) & (TY - 1), tq = tid >> (tx_log2 + ty_log2);
+  const int osz = p.out_h * p.out_w;
+  float *dst = out + (int64_t)plane0 * osz;
+  for (int oy = ty; oy < p.out_h; oy += TY) {
+    const int by = oy * p.down_y - p.pad_y0;
+    const int iy_lo = max(ceil_div_s(by, p.up_y), 0), iy_hi = min(floor_div(by + p.kh - 1, p.up_y), p.in_h - 1);
+    for (int ox = tx; ox < p.out_w; ox += TX) {
+      const int bx = ox * p.down_x - p.pad_x0;
+      const int ix_lo = max(ceil_div_s(bx, p.up_x), 0), ix_hi = min(floor_div(bx + p.kw - 1, p.up_x), p.in_w - 1);
+      if (UPLOG >= 0) {
+        // only the taps whose stuffed coordinate is a multiple of up can be on: ky = ky0 + up*a, ky0 = (-by) mod up
+        constexpr int UL = UPLOG >= 0 ? UPLOG : 0, UP = 1 << UL, UM = UP - 1, NI = 4 >> UL;
+        const int ky0 = (UP - (by & UM)) & UM, kx0 = (UP - (bx & UM)) & UM;
+        float T[NI * NI];
+        int off[NI * NI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+          for (int b = 0; b < NI; ++b) {
+            const int ky = ky0 + UP * a, kx = kx0 + UP * b, iy = (by + ky) >> UL, ix = (bx + kx) >> UL;
+            const bool ok = ky < p.kh && kx < p.kw && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+            T[a * NI + b] = ok ? taps[ky * p.kw + kx] : 0.f;    // an "off" tap reads pixel 0 with weight 0
+            off[a * NI + b] = ok ? iy * p.in_w + ix : 0;
+          }
+        for (int q = tq; q < nplanes; q += TQ) {
+          const float *plane = pl + q * psz;
+          float acc = 0.f;
+#pragma unroll
+          for (int i = 0; i < NI * NI; ++i) acc += plane[off[i]] * T[i];
+          dst[(int64_t)q * osz + oy * p.out_w + ox] = acc;
+        }
+      } else {
+        for (int q = tq; q < nplanes; q += TQ) {
+          const float *plane = pl + q * psz;
+          float acc = 0.f;
+          for (int iy = iy_lo; iy <= iy_hi; ++iy) {
+            const float *trow = taps + (iy * p.up_y - by) * p.kw - bx;
+            const float *prow = plane + iy * p.in_w;
+            for (int ix = ix_lo; ix <= ix_hi; ++ix) acc += prow[ix] * trow[ix * p.up_x];
+          }
+          dst[(int64_t)q * osz + oy * p.out_w + ox] = acc;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- minor % 4 == 0, row-structured
+// grid.y = (plane, oy); a thread keeps its channel vector c4 and walks output columns, so the only integer
+// divisions are the two that split blockIdx.y (uniform) -- the per-element 64-bit div/mod of a flat grid-stride
+// loop made this kernel VALU-bound.
+template <int UPLOG>
+__global__ void __launch_bounds__(256)
+upfirdn2d_nhwc_rows(const float *__restrict__ x, const float *__restrict__ k, float *__restrict__ out, UfdParams p,
+                    int cv, int col_step) {
+  __shared__ float taps[kMaxTaps];
+  const int ntap = p.kh * p.kw;
+  for (int i = threadIdx.x; i < ntap; i += 256) {
+    int ky = i / p.kw, kx = i - ky * p.kw;
+    taps[i] = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+  }
+  __syncthreads();
+  const int plane = blockIdx.y / p.out_h, oy = blockIdx.y - plane * p.out_h;
+  const int c4 = threadIdx.x % cv, col0 = threadIdx.x / cv;
+  if (col0 >= col_step) return;
+  const int by = oy * p.down_y - p.pad_y0;
+  const int iy_lo = max(ceil_div_s(by, p.up_y), 0), iy_hi = min(floor_div(by + p.kh - 1, p.up_y), p.in_h - 1);
+  const float4 *xp = reinterpret_cast<const float4 *>(x) + (int64_t)plane * p.in_h * p.in_w * cv + c4;
+  float4 *op = reinterpret_cast<float4 *>(out) + ((int64_t)plane * p.out_h + oy) * p.out_w * cv + c4;
+  for (int ox = blockIdx.x * col_step + col0; ox < p.out_w; ox += gridDim.x * col_step) {
+    const int bx = ox * p.down_x - p.pad_x0;
+    const int ix_lo = max(ceil_div_s(bx, p.up_x), 0), ix_hi = min(floor_div(bx + p.kw - 1, p.up_x), p.in_w - 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (UPLOG >= 0) {
+      constexpr int UL = UPLOG >= 0 ? UPLOG : 0, UP = 1 << UL, UM = UP - 1, NI = 4 >> UL;
+      const int ky0 = (UP - (by & UM)) & UM, kx0 = (UP - (bx & UM)) & UM;
+#pragma unroll
+      for (int a = 0; a < NI; ++a) {
+        const int ky = ky0 + UP * a, iy = (by + ky) >> UL;
+        const bool vy = ky < p.kh && (unsigned)iy < (unsigned)p.in_h;
+        const float4 *row = xp + (int64_t)(vy ? iy : 0) * p.in_w * cv;
+#pragma unroll
+        for (int b = 0; b < NI; ++b) {
+          const int kx = kx0 + UP * b, ix = (bx + kx) >> UL;
+          const bool ok = vy && kx < p.kw && (unsigned)ix < (unsigned)p.in_w;
+          const float w = ok ? taps[ky * p.kw + kx] : 0.f;       // an "off" tap reads pixel 0 with weight 0
+          const float4 s = row[(int64_t)(ok ? ix : 0) * cv];
+          acc.x += s.x * w; acc.y += s.y * w; acc.z += s.z * w; acc.w += s.w * w;
+        }
+      }
+    } else {
+      for (int iy = iy_lo; iy <= iy_hi; ++iy) {
+        const float *trow = taps + (iy * p.up_y - by) * p.kw - bx;
+        const float4 *row = xp + (int64_t)iy * p.in_w * cv;
+        for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+          const float w = trow[ix * p.up_x];
+          const float4 s = row[(int64_t)ix * cv];
+          acc.x += s.x * w; acc.y += s.y * w; acc.z += s.z * w; acc.w += s.w * w;
+        }
+      }
+    }
+    op[(int64_t)ox * cv] = acc;
+  }
+}
+
 // ---------------------------------------------------------------- anything else
 __global__ void __launch_bounds__(256)
 upfirdn2d_generic(const float *__restrict__ x, const float *__restrict__ k, float *__restrict__ out, UfdParams p,
@@ -168,6 +315,24 @@ IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, in
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)major * p.out_h * p.out_w * minor;
 
+  if (minor == 1 && kh * kw <= kMaxTaps && (int64_t)in_h * in_w <= 8192 && (int64_t)p.out_h * p.out_w <= 16384) {
+    // whole planes in LDS: <= 32 KB per plane; as many planes per workgroup as fit 32 KB / ~16 outputs per thread
+    const int psz = in_h * in_w, osz = p.out_h * p.out_w;
+    int ppb = max(1, min((32 * 1024 / 4) / psz, 4096 / max(osz, 1)));
+    ppb = max(1, min(ppb, max(1, major / 1024)));  // keep >= ~4 workgroups per CU when there are few planes
+    int tx_log2 = 0;
+    while ((1 << tx_log2) < min(p.out_w, 64)) ++tx_log2;
+    const size_t lds_bytes = (kMaxTaps + (size_t)ppb * psz) * sizeof(float);
+    const int uplog = (up_x == up_y && kh <= 4 && kw <= 4) ? (up_x == 1 ? 0 : up_x == 2 ? 1 : -1) : -1;
+    const dim3 grid(ceil_div(major, ppb));
+    if (uplog == 0)
+      hipLaunchKernelGGL(upfirdn2d_planes_whole<0>, grid, dim3(256), lds_bytes, st, x, k, out, p, ppb, tx_log2);
+    else if (uplog == 1)
+      hipLaunchKernelGGL(upfirdn2d_planes_whole<1>, grid, dim3(256), lds_bytes, st, x, k, out, p, ppb, tx_log2);
+    else
+      hipLaunchKernelGGL(upfirdn2d_planes_whole<-1>, grid, dim3(256), lds_bytes, st, x, k, out, p, ppb, tx_log2);
+    return launch_status("upfirdn2d_planes_whole");
+  }
   if (minor == 1 && kh * kw <= kMaxTaps) {
     // output tile: up to 32 x 64 pixels, several planes per workgroup when planes are small
     const int tow = min(p.out_w, 64), toh = min(p.out_h, 32);
@@ -187,6 +352,22 @@ IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, in
         return launch_status("upfirdn2d_planes_lds");
       }
     }
+  }
+  if (minor % 4 == 0 && minor <= 1024 && kh * kw <= kMaxTaps && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+      (int64_t)major * p.out_h <= 65535) {
+    const int cv = minor / 4, col_step = 256 / cv;
+    // enough rows to fill the chip: one workgroup per output row (each thread walks out_w / col_step pixels);
+    // otherwise split rows over up to 8 workgroups
+    const int gx = (int64_t)major * p.out_h >= 2048 ? 1 : max(1, min(ceil_div(p.out_w, col_step), 8));
+    const int uplog = (up_x == up_y && kh <= 4 && kw <= 4) ? (up_x == 1 ? 0 : up_x == 2 ? 1 : -1) : -1;
+    const dim3 grid(gx, major * p.out_h);
+    if (uplog == 0)
+      hipLaunchKernelGGL(upfirdn2d_nhwc_rows<0>, grid, dim3(256), 0, st, x, k, out, p, cv, col_step);
+    else if (uplog == 1)
+      hipLaunchKernelGGL(upfirdn2d_nhwc_rows<1>, grid, dim3(256), 0, st, x, k, out, p, cv, col_step);
+    else
+      hipLaunchKernelGGL(upfirdn2d_nhwc_rows<-1>, grid, dim3(256), 0, st, x, k, out, p, cv, col_step);
+    return launch_status("upfirdn2d_nhwc_rows");
   }
   if (minor % 4 == 0 && kh * kw <= kMaxTaps && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
     const int64_t total_vec = total / 4;

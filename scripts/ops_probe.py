@@ -1,0 +1,55 @@
+"""Achieved HBM GB/s of the memory-bound kernels at BASELINE sizes (algorithmic bytes / time)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import id_diff_amd
+from id_diff_amd import _lib, op
+
+dev = "cuda"
+def timeit(fn, reps=20):
+    fn(); fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+def say(name, nbytes, dt):
+    print(f"{name:58s} {dt*1e6:8.1f} us  {nbytes/dt/1e9:7.0f} GB/s  ({nbytes/dt/8e12*100:4.1f}% of 8 TB/s)", flush=True)
+
+k = torch.tensor(np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0, dtype=torch.float32, device=dev)
+# op.upfirdn2d (NCHW, minor = 1) at the three ncsnpp families, B = 128
+for shape, up, down, pad in [((128, 128, 32, 32), 1, 2, (1, 1)), ((128, 256, 16, 16), 1, 2, (1, 1)), ((128, 256, 16, 16), 2, 1, (2, 1)),
+                             ((128, 256, 8, 8), 2, 1, (2, 1)), ((128, 3, 32, 32), 1, 1, (2, 2)), ((128, 128, 16, 16), 1, 1, (2, 2))]:
+    x = torch.randn(*shape, device=dev)
+    kk = k * (4 if up == 2 else 1)
+    y = op.upfirdn2d(x, kk, up=up, down=down, pad=pad)
+    out = torch.empty_like(y)
+    n, c, h, w = shape
+    def f(): _lib.upfirdn2d_raw(x, kk, out, n * c, h, w, 1, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
+    say(f"upfirdn2d NCHW {shape} up{up} down{down}", 4 * (x.numel() + y.numel()) + 64, timeit(f))
+# NHWC (minor = C) as the networks call it, 512 rows
+for (B, H, C, up, down, pad) in [(512, 32, 128, 1, 2, (1, 1)), (512, 16, 256, 2, 1, (2, 1)), (512, 16, 256, 1, 2, (1, 1))]:
+    x = torch.randn(B, H * H, C, device=dev)
+    OH = _lib.upfirdn2d_out_size(H, up, down, pad[0], pad[1], 4)
+    out = torch.empty(B, OH * OH, C, device=dev)
+    kk = k * (4 if up == 2 else 1)
+    def f(): _lib.upfirdn2d_raw(x, kk, out, B, H, H, C, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
+    say(f"upfirdn2d NHWC B={B} {H}x{H}x{C} up{up} down{down}", 4 * (x.numel() + out.numel()) + 64, timeit(f))
+for shape in [(128, 128, 32, 32), (128, 256, 16, 16), (128, 256, 8, 8), (128, 256, 4, 4)]:
+    x = torch.randn(*shape, device=dev); b = torch.randn(shape[1], device=dev)
+    say(f"fused_leaky_relu {shape}", 4 * (2 * x.numel() + shape[1]), timeit(lambda: op.fused_leaky_relu(x, b)))
+for (B, HW, C, G) in [(512, 1024, 128, 32), (512, 256, 256, 32), (512, 1024, 256, 32)]:
+    x = torch.randn(B, HW, C, device=dev)
+    ns = _lib.groupnorm_nsplit(B, HW, C)
+    ws = torch.empty(B * ns * C * 2, device=dev, dtype=torch.float64); st = torch.empty(B * G * 2, device=dev)
+    ga = torch.ones(C, device=dev); be = torch.zeros(C, device=dev); y = torch.empty_like(x)
+    say(f"groupnorm_stats B={B} HW={HW} C={C}", 4 * x.numel(), timeit(lambda: _lib.groupnorm_stats(x, C, None, 0, B, HW, G, 1e-6, ws, st)))
+    say(f"groupnorm_apply+silu B={B} HW={HW} C={C}", 8 * x.numel(), timeit(lambda: _lib.groupnorm_apply(x, C, None, 0, B, HW, G, st, ga, be, "silu", y)))
+x = torch.randn(512 * 256, 256, device=dev)
+say("softmax_rows 131072 x 256", 8 * x.numel(), timeit(lambda: _lib.softmax_rows(x, x, x.shape[0], 256, 0.0625)))
+S = torch.randn(4480, 3072, device=dev)
+mean = torch.empty(3072, device=dev, dtype=torch.float64); scr = torch.empty(32 * 3072, device=dev, dtype=torch.float64)
+G = torch.empty(3072, 3072, device=dev, dtype=torch.float64)
+lib = _lib.lib(); stq = torch.cuda.current_stream().cuda_stream
+dt = timeit(lambda: lib.idiff_centered_gram_f64(S.data_ptr(), mean.data_ptr(), 1, 4480, 3072, G.data_ptr(), stq), reps=5)
+print(f"centered_gram_f64 4480x3072: {dt*1e3:.2f} ms  {2*4480*3072*3072/2/dt/1e12:.1f} TFLOP/s fp64 (upper-triangular tiles)", flush=True)
