@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--inflight", type=int, default=512, help="score rows per launch set")
+    ap.add_argument("--inflight", type=int, default=2240, help="score rows per launch set (measured best of 512..4480)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run each point's spectrum on the main stream")
     args = ap.parse_args()
@@ -165,8 +165,8 @@ def main():
     state = {"calls": 0}
 
     def sampled_score_fn(x, t):
-        # sample one launch set per step: a middle one (the first overlaps the previous point's spectrum)
-        first = state["calls"] == 4
+        # sample one launch set per step: the last one (the first overlaps the previous point's spectrum)
+        first = state["calls"] == n_chunks - 1
         state["calls"] += 1
         was = probe.active
         probe.active = was and first
@@ -175,6 +175,7 @@ def main():
         return out
 
     builder.score_fn = sampled_score_fn
+    n_chunks = (rows + builder.rows_per_launch(rows, D) - 1) // builder.rows_per_launch(rows, D)
 
     with torch.no_grad():
         for i in range(args.warmup):
