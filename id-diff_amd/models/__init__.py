@@ -4,4 +4,4 @@ Importing the package registers ``fcn``, ``ncsnpp``, ``BeatGANsUNetModel`` (and 
 ``config.model.name`` selects (reference: models/utils.py:24-47, models/fcn.py:6, models/ncsnpp.py:39).
 """
 from . import utils  # noqa: F401
-from . import fcn, ncsnpp, beatgans, ksphere_exact  # noqa: F401
+from . import fcn, ncsnpp, ddpm, beatgans, ksphere_exact  # noqa: F401

@@ -573,6 +573,11 @@ class NCSNpp(HipScoreModel):
                     pyr = self._conv(n, w, b, residual=self._fir(pyr, pk, "up").buf)
             elif op == "up":
                 h = self._resblock(step[1], h, temb_all, pk) if step[2] else self._fir(h, pk, "up")
+            elif op == "up_plain":   # layers.Upsample (models/layers.py:593-604): nearest x2 (+ 3x3 conv)
+                h = self._box(h, True)
+                if M[step[1]].with_conv:
+                    w, b = self._conv_w(pk, (step[1], "upconv"), M[step[1]].Conv_0)
+                    h = self._conv(h, w, b)
             elif op == "head":
                 n = self._gn_act(h, M[step[1]], self.act_name)
                 w, b = self._conv_w(pk, (step[2], "head"), M[step[2]])
@@ -580,6 +585,7 @@ class NCSNpp(HipScoreModel):
             elif op == "head_pyramid":
                 h = pyr
         assert not hs
-        out = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
-        _lib.nhwc_to_nchw(h.buf, out, B, C, H * W, h.C, out_rowscale)
+        c_out = getattr(self, "out_channels", C)
+        out = torch.empty(B, c_out, H, W, device=dev, dtype=torch.float32)
+        _lib.nhwc_to_nchw(h.buf, out, B, c_out, H * W, h.C, out_rowscale)
         return out

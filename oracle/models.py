@@ -482,8 +482,120 @@ class NCSNpp(nn.Module):
         return h
 
 
+# ----------------------------------------------------------------------------
+# ddpm (the model every shipped image config selects)
+# ----------------------------------------------------------------------------
+class _DDPMRes(nn.Module):
+    """layers.ResnetBlockDDPM :632-680: GroupNorm(32) blocks, NIN shortcut, plain residual sum."""
+
+    def __init__(self, act, in_ch, out_ch, temb_dim, dropout):
+        super().__init__()
+        self.GroupNorm_0 = nn.GroupNorm(num_groups=32, num_channels=in_ch, eps=1e-6)
+        self.Conv_0 = _conv(in_ch, out_ch, 3)
+        self.Dense_0 = _dense(temb_dim, out_ch)
+        self.GroupNorm_1 = nn.GroupNorm(num_groups=32, num_channels=out_ch, eps=1e-6)
+        self.Dropout_0 = nn.Dropout(dropout)
+        self.Conv_1 = _conv(out_ch, out_ch, 3, init_scale=0.)
+        if in_ch != out_ch:
+            self.NIN_0 = NIN(in_ch, out_ch)
+        self.act, self.in_ch, self.out_ch = act, in_ch, out_ch
+
+    def forward(self, x, temb):
+        h = self.Conv_0(self.act(self.GroupNorm_0(x)))
+        h = h + self.Dense_0(self.act(temb))[:, :, None, None]
+        h = self.Conv_1(self.Dropout_0(self.act(self.GroupNorm_1(h))))
+        return (self.NIN_0(x) if self.in_ch != self.out_ch else x) + h
+
+
+class _DDPMAttn(AttnBlockpp):
+    """layers.AttnBlock :567-590 = AttnBlockpp without rescale, 32 groups."""
+
+    def __init__(self, channels):
+        super().__init__(channels, skip_rescale=False, init_scale=0.)
+        self.GroupNorm_0 = nn.GroupNorm(num_groups=32, num_channels=channels, eps=1e-6)
+
+
+class _DDPMResample(nn.Module):
+    """layers.Upsample :593-604 / layers.Downsample :607-629."""
+
+    def __init__(self, channels, with_conv, up):
+        super().__init__()
+        self.up, self.with_conv = up, with_conv
+        if with_conv:
+            self.Conv_0 = _conv(channels, channels, 3) if up else _conv(channels, channels, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        if self.up:
+            h = F.interpolate(x, scale_factor=2, mode="nearest")
+            return self.Conv_0(h) if self.with_conv else h
+        return self.Conv_0(F.pad(x, (0, 1, 0, 1))) if self.with_conv else F.avg_pool2d(x, 2, 2)
+
+
+class DDPM(nn.Module):
+    """models/ddpm.py:80-213."""
+
+    def __init__(self, config):
+        super().__init__()
+        m = config.model
+        self.act = act = get_act(config)
+        self.nf = nf = m.nf
+        self.nrb, self.attn_res = m.num_res_blocks, m.attn_resolutions
+        self.levels = levels = len(m.ch_mult)
+        res = [config.data.effective_image_size // (2 ** i) for i in range(levels)]
+        self.centered = config.data.centered
+        assert m.conditional
+        mods = [_dense(nf, nf * 4), _dense(nf * 4, nf * 4), _conv(m.input_channels, nf, 3)]
+        skips, ch = [nf], nf
+        for lvl in range(levels):
+            for _ in range(m.num_res_blocks):
+                mods.append(_DDPMRes(act, ch, nf * m.ch_mult[lvl], 4 * nf, m.dropout))
+                ch = nf * m.ch_mult[lvl]
+                if res[lvl] in m.attn_resolutions:
+                    mods.append(_DDPMAttn(ch))
+                skips.append(ch)
+            if lvl != levels - 1:
+                mods.append(_DDPMResample(ch, m.resamp_with_conv, up=False))
+                skips.append(ch)
+        mods += [_DDPMRes(act, ch, ch, 4 * nf, m.dropout), _DDPMAttn(ch), _DDPMRes(act, ch, ch, 4 * nf, m.dropout)]
+        for lvl in reversed(range(levels)):
+            for _ in range(m.num_res_blocks + 1):
+                mods.append(_DDPMRes(act, ch + skips.pop(), nf * m.ch_mult[lvl], 4 * nf, m.dropout))
+                ch = nf * m.ch_mult[lvl]
+            if res[lvl] in m.attn_resolutions:
+                mods.append(_DDPMAttn(ch))
+            if lvl != 0:
+                mods.append(_DDPMResample(ch, m.resamp_with_conv, up=True))
+        mods += [nn.GroupNorm(num_channels=ch, num_groups=32, eps=1e-6), _conv(ch, m.output_channels, 3, init_scale=0.)]
+        self.all_modules = nn.ModuleList(mods)
+
+    def forward(self, x, labels):
+        M, i = self.all_modules, 0
+        temb = M[1](self.act(M[0](positional_embedding(labels, self.nf))))
+        h = x if self.centered else 2 * x - 1.
+        hs = [M[2](h)]
+        i = 3
+        for lvl in range(self.levels):
+            for _ in range(self.nrb):
+                h = M[i](hs[-1], temb); i += 1
+                if h.shape[-1] in self.attn_res:
+                    h = M[i](h); i += 1
+                hs.append(h)
+            if lvl != self.levels - 1:
+                hs.append(M[i](hs[-1])); i += 1
+        h = M[i](hs[-1], temb); h = M[i + 1](h); h = M[i + 2](h, temb); i += 3
+        for lvl in reversed(range(self.levels)):
+            for _ in range(self.nrb + 1):
+                h = M[i](torch.cat([h, hs.pop()], dim=1), temb); i += 1
+            if h.shape[-1] in self.attn_res:
+                h = M[i](h); i += 1
+            if lvl != 0:
+                h = M[i](h); i += 1
+        assert not hs and i + 2 == len(M)
+        return M[i + 1](self.act(M[i](h)))
+
+
 def create_model(config):
     """models/utils.py:114-120."""
     from .beatgans import BeatGANsUNetModel
-    models = {"fcn": FCN, "ncsnpp": NCSNpp, "BeatGANsUNetModel": BeatGANsUNetModel}
+    models = {"fcn": FCN, "ncsnpp": NCSNpp, "BeatGANsUNetModel": BeatGANsUNetModel, "ddpm": DDPM}
     return models[config.model.name](config)

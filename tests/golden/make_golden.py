@@ -356,6 +356,51 @@ def gen_beatgans():
         save(f"beatgans_{name}.npz", **out)
 
 
+def ddpm_config(**over):
+    c = ConfigDict()
+    c.data = ConfigDict(image_size=16, effective_image_size=16, num_channels=1, centered=False, shape=[1, 16, 16])
+    c.training = ConfigDict(continuous=True, sde="vesde")
+    c.model = ConfigDict(name="ddpm", nf=32, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), dropout=0.1,
+                         resamp_with_conv=True, conditional=True, nonlinearity="swish", normalization="GroupNorm",
+                         input_channels=1, output_channels=1, sigma_min=0.009, sigma_max=50, num_scales=1000,
+                         scale_by_sigma=True, ema_rate=0.999)
+    for k, v in over.items():
+        c[k] = v
+    return c
+
+
+DDPM_VARIANTS = {"mnist_like": {}, "pool_resample": {"model.resamp_with_conv": False, "model.nonlinearity": "elu",
+                                                     "data.centered": True}}
+
+
+def gen_ddpm():
+    """`ddpm` is the model every shipped image config selects (e.g. .../image_data/MNIST/config.py:121)."""
+    from models import ddpm  # noqa: F401  (registers the model)
+    for name, over in DDPM_VARIANTS.items():
+        torch.manual_seed(0)
+        cfg = ddpm_config(**over)
+        model = mutils.create_model(cfg)
+        g = torch.Generator().manual_seed(3)
+        with torch.no_grad():   # zero-/1e-10-initialised tensors (init_scale=0.) get real values so every branch counts
+            for prm in model.parameters():
+                if float(prm.abs().max()) < 1e-6 and prm.ndim > 1:
+                    prm.copy_(torch.randn(prm.shape, generator=g) * 0.05)
+        sde = sde_lib.VESDE(sigma_min=0.009, sigma_max=50, N=1000)
+        score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
+        x = torch.rand(2, 1, 16, 16, generator=torch.Generator().manual_seed(1))
+        t = torch.tensor([1e-5, 0.2])
+        with torch.no_grad():
+            y = score_fn(x, t)
+            raw = model.eval()(x, t * 999)
+        out = sd_arrays(model)
+        out["x"] = x.numpy(); out["t"] = t.numpy(); out["score"] = y.numpy(); out["model_out"] = raw.numpy()
+        over_keys = sorted(over)
+        out["override_keys"] = np.array(over_keys, dtype="U64")
+        out["override_vals"] = np.array([repr(over[k]) for k in over_keys], dtype="U64")
+        out["n_modules"] = np.array(len(model.all_modules))
+        save(f"ddpm_{name}.npz", **out)
+
+
 def gen_ksphere():
     from lightning_data_modules.KSphereDataset import KSphereDataset
     out = {}
@@ -421,8 +466,8 @@ def gen_svd_and_rule():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "fcn", "ncsnpp", "ksphere", "svd", "beatgans"]
+    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "fcn", "ncsnpp", "ksphere", "svd", "beatgans", "ddpm"]
     table = {"upfirdn2d": gen_upfirdn2d, "fused_act": gen_fused_act, "sde": gen_sde, "fcn": gen_fcn,
-             "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule, "beatgans": gen_beatgans}
+             "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule, "beatgans": gen_beatgans, "ddpm": gen_ddpm}
     for w in which:
         table[w]()

@@ -71,3 +71,16 @@ def beatgans_config(**over):
     for k, v in over.items():
         c[k] = v
     return c
+
+
+def ddpm_config(**over):
+    c = ConfigDict()
+    c.data = ConfigDict(image_size=16, effective_image_size=16, num_channels=1, centered=False, shape=[1, 16, 16])
+    c.training = ConfigDict(continuous=True, sde="vesde", batch_size=128)
+    c.model = ConfigDict(name="ddpm", nf=32, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), dropout=0.1,
+                         resamp_with_conv=True, conditional=True, nonlinearity="swish", normalization="GroupNorm",
+                         input_channels=1, output_channels=1, sigma_min=0.009, sigma_max=50, num_scales=1000,
+                         scale_by_sigma=True, ema_rate=0.999)
+    for k, v in over.items():
+        c[k] = v
+    return c

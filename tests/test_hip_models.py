@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import id_diff_amd
-from helpers import (beatgans_config, fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden,
+from helpers import (beatgans_config, ddpm_config, fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden,
                      rel_err)
 from id_diff_amd import _lib, dim_reduction, plot_utils, sde_lib
 from id_diff_amd.configs.utils import read_config
@@ -62,6 +62,20 @@ def test_beatgans_golden(golden, variant):
     raw = model(x, t * 999)
     assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
     y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x, t)
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+
+
+@pytest.mark.parametrize("variant", ["mnist_like", "pool_resample"])
+def test_ddpm_golden(golden, variant):
+    z = golden(f"ddpm_{variant}.npz")
+    model = mutils.create_model(ddpm_config(**overrides_from_golden(z)))
+    assert len(model.all_modules) == int(z["n_modules"])
+    model.load_state_dict(state_dict_from_golden(z))
+    model.to(DEV)
+    x, t = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV)
+    raw = model(x, t * 999)
+    assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
+    y = mutils.get_score_fn(sde_lib.VESDE(0.009, 50, 1000), model)(x, t)
     assert rel_err(y.cpu(), z["score"]) < NET_RTOL
 
 

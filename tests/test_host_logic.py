@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import id_diff_amd
-from helpers import beatgans_config, fcn_config, ncsnpp_config
+from helpers import beatgans_config, ddpm_config, fcn_config, ncsnpp_config
 from id_diff_amd import dim_reduction, parallel, plot_utils, sde_lib
 from id_diff_amd.configs.config_dict import ConfigDict
 from id_diff_amd.configs.utils import read_config
@@ -69,6 +69,10 @@ def test_state_dict_keys_match_reference(golden):
     z = golden("fcn_tiny.npz")
     model = mutils.create_model(fcn_config(hidden_nodes=64))
     model.load_state_dict(state_dict_from_golden(z), strict=True)
+    for variant in ["mnist_like", "pool_resample"]:
+        z = golden(f"ddpm_{variant}.npz")
+        model = mutils.create_model(ddpm_config(**overrides_from_golden(z)))
+        model.load_state_dict(state_dict_from_golden(z), strict=True)
     for variant in ["paper_like", "plain_resample"]:
         z = golden(f"beatgans_{variant}.npz")
         model = mutils.create_model(beatgans_config(**overrides_from_golden(z)))

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (beatgans_config, fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden,
+from helpers import (beatgans_config, ddpm_config, fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden,
                      rel_err)
 from oracle import ops as oops, sde as osde, models as omodels, ksphere as oks, dim as odim
 
@@ -123,6 +123,20 @@ def test_beatgans_score_fn(golden, variant):
     with torch.no_grad():
         raw = model.eval()(x, t * 999)
         y = osde.get_score_fn(osde.VESDE(0.01, 50, 1000), model)(x, t)
+    assert rel_err(raw, z["model_out"]) < 2e-6
+    assert rel_err(y, z["score"]) < 2e-6
+
+
+@pytest.mark.parametrize("variant", ["mnist_like", "pool_resample"])
+def test_ddpm_score_fn(golden, variant):
+    z = golden(f"ddpm_{variant}.npz")
+    model = omodels.create_model(ddpm_config(**overrides_from_golden(z)))
+    assert len(model.all_modules) == int(z["n_modules"])
+    model.load_state_dict(state_dict_from_golden(z), strict=True)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    with torch.no_grad():
+        raw = model.eval()(x, t * 999)
+        y = osde.get_score_fn(osde.VESDE(0.009, 50, 1000), model)(x, t)
     assert rel_err(raw, z["model_out"]) < 2e-6
     assert rel_err(y, z["score"]) < 2e-6
 
