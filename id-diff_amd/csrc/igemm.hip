@@ -540,6 +540,19 @@ void fill_epilogue(IgemmParams &p, const idiff_epilogue *ep) {
 
 bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
+// The fast kernel addresses an operand through one 32-bit-offset buffer descriptor (< 4 GiB).  Larger problems
+// are cut into row ranges on the host (rows are independent): this returns the epilogue of the range that
+// starts at row m0, which must be a multiple of rows_per_group.
+idiff_epilogue shift_epilogue(const idiff_epilogue &ep, int64_t m0) {
+  idiff_epilogue e = ep;
+  const int64_t g0 = m0 / (ep.rows_per_group > 0 ? ep.rows_per_group : 1);
+  if (e.rowbias) e.rowbias += g0 * ep.ld_rowbias;
+  if (e.residual) e.residual += m0 * ep.ld_residual;
+  if (e.rowscale) e.rowscale += g0;
+  return e;
+}
+constexpr int64_t BUF_LIMIT = 0xFFFFFFF0ll;
+
 }  // namespace
 
 IDIFF_API int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt, int64_t ldb,
@@ -559,7 +572,19 @@ IDIFF_API int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const
                    aligned16(A) && aligned16(Bt);
   hipStream_t st = (hipStream_t)stream;
   const int64_t a_bytes = ((int64_t)(M - 1) * lda + K) * 4, b_bytes = ((int64_t)(N - 1) * ldb + K) * 4;
-  if (vec && a_bytes < 0xFFFFFFF0ll && b_bytes < 0xFFFFFFF0ll && !getenv("IDIFF_NO_PIPE")) {
+  if (vec && batch == 1 && a_bytes >= BUF_LIMIT && b_bytes < BUF_LIMIT && !getenv("IDIFF_NO_PIPE")) {
+    const int rpg = (ep && ep->rows_per_group > 0) ? ep->rows_per_group : 1;
+    const int mid = (M / 2 / rpg) * rpg;
+    if (mid > 0) {
+      idiff_epilogue lo, hi;
+      if (ep) { lo = *ep; hi = shift_epilogue(*ep, mid); }
+      int rc = idiff_gemm_f32(A, lda, 0, Bt, ldb, 0, C, ldc, 0, mid, N, K, 1, ep ? &lo : nullptr, stream);
+      if (rc) return rc;
+      return idiff_gemm_f32(A + (int64_t)mid * lda, lda, 0, Bt, ldb, 0, C + (int64_t)mid * ldc, ldc, 0, M - mid, N, K, 1,
+                            ep ? &hi : nullptr, stream);
+    }
+  }
+  if (vec && a_bytes < BUF_LIMIT && b_bytes < BUF_LIMIT && !getenv("IDIFF_NO_PIPE")) {
     p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
     return dispatch_pipe<false>(p, batch, st);
   }
@@ -588,7 +613,22 @@ IDIFF_API int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out,
   p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KW = KW; p.stride = stride; p.pad = pad;
   fill_epilogue(p, ep);
   const int64_t a_bytes = (int64_t)B * H * W * Cin * 4, b_bytes = (int64_t)Cout * p.K * 4;
-  if (Cin % BK == 0 && KH * KW <= 32 && a_bytes < 0xFFFFFFF0ll && b_bytes < 0xFFFFFFF0ll && !getenv("IDIFF_NO_PIPE")) {
+  const bool fast_ok = Cin % BK == 0 && KH * KW <= 32 && b_bytes < BUF_LIMIT && !getenv("IDIFF_NO_PIPE");
+  if (fast_ok && a_bytes >= BUF_LIMIT && B > 1) {
+    // split the batch (images are independent) so that each half fits one buffer descriptor
+    const int rpg = (ep && ep->rows_per_group > 0) ? ep->rows_per_group : 1;
+    const int b_lo = B / 2;
+    const int64_t m_lo = (int64_t)b_lo * OH * OW;
+    if (m_lo % rpg == 0) {
+      idiff_epilogue lo, hi;
+      if (ep) { lo = *ep; hi = shift_epilogue(*ep, m_lo); }
+      int rc = idiff_conv2d_nhwc_f32(x, wt, out, b_lo, H, W, Cin, Cout, KH, KW, stride, pad_lo, pad_hi, ep ? &lo : nullptr, stream);
+      if (rc) return rc;
+      return idiff_conv2d_nhwc_f32(x + (int64_t)b_lo * H * W * Cin, wt, out + m_lo * Cout, B - b_lo, H, W, Cin, Cout, KH, KW,
+                                   stride, pad_lo, pad_hi, ep ? &hi : nullptr, stream);
+    }
+  }
+  if (fast_ok && a_bytes < BUF_LIMIT) {
     p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
     return dispatch_pipe<true>(p, 1, (hipStream_t)stream);
   }

@@ -179,6 +179,34 @@ def test_conv2d_nhwc_vs_cpu(B, H, W, Cin, Cout, k, stride, pad, pad_hi):
     assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 2e-6
 
 
+def test_operands_beyond_4gib_are_split_on_the_host():
+    """The fast kernel addresses operands through 32-bit-offset buffer descriptors; larger problems are cut into
+    row / image ranges (igemm.hip: shift_epilogue).  Checked on the rows / images around the cut."""
+    g = torch.Generator(device=DEV).manual_seed(0)
+    M, K, N, grp = 1_200_000, 1024, 64, 1000           # A = 4.9 GB
+    a = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / 32
+    rb = torch.randn(M // grp, N, device=DEV, generator=g)
+    rsc = torch.rand(M // grp, device=DEV, generator=g) + 0.5
+    y = _lib.gemm(a, w, epilogue=_lib.make_epilogue(rowbias=rb, rows_per_group=grp, rowscale=rsc))
+    rows = torch.tensor([0, 1, 599_999, 600_000, 600_001, 999_999, M - 1], device=DEV)
+    ref = (a[rows].double().cpu() @ w.double().cpu().T + rb[rows // grp].double().cpu()) * rsc[rows // grp].double().cpu()[:, None]
+    assert rel_err(y[rows].cpu(), ref) < 2e-6
+    del a, y
+    B, H, Cin, Cout = 2100, 32, 512, 32                # x = 4.4 GB
+    x = torch.randn(B, H * H, Cin, device=DEV, generator=g)
+    wt = torch.randn(Cout, 3, 3, Cin, device=DEV, generator=g) / 68
+    res = torch.randn(B, H * H, Cout, device=DEV, generator=g)
+    out = torch.empty(B, H * H, Cout, device=DEV)
+    _lib.conv2d_nhwc(x, wt, out, B, H, H, Cin, Cout, 3, 3, 1, 1, epilogue=_lib.make_epilogue(residual=res, out_scale=0.5,
+                                                                                             rows_per_group=H * H))
+    for b in (0, 1049, 1050, B - 1):
+        xi = x[b].reshape(H, H, Cin).permute(2, 0, 1)[None].double().cpu()
+        ref = F.conv2d(xi, wt.permute(0, 3, 1, 2).double().cpu(), padding=1)[0].permute(1, 2, 0).reshape(H * H, Cout)
+        ref = (ref + res[b].double().cpu()) * 0.5
+        assert rel_err(out[b].cpu(), ref) < 2e-6, b
+
+
 # ------------------------------------------------------------------ norm / pointwise
 @pytest.mark.parametrize("B,HW,C,C2,G", [(4, 1024, 128, 0, 32), (3, 256, 256, 128, 32), (2, 64, 8, 0, 2), (2, 16, 24, 0, 6),
                                          (5, 1024, 16, 8, 6)])
