@@ -152,11 +152,10 @@ def main():
     pipe = dim_reduction.SpectrumPipeline(dev, overlap=not args.no_overlap)
 
     def one_point(i, timed):
-        gen = torch.Generator(device=dev).manual_seed(1234 + 1000003 * (i + 1) + rank)
         # sample the dominant kernel on the first launch set of every timed step
         if timed:
             probe.active = True
-        S = builder.build(images[i], B, generator=gen)
+        S = builder.build(images[i], B, seed=1234 + 1000003 * (i + 1) + rank)
         probe.active = False
         pipe.submit(S)   # spectrum of this point overlaps the score evaluations of the next one
 

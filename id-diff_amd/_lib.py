@@ -48,6 +48,7 @@ _SIGNATURES = {
     "idiff_nhwc_to_nchw_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "idiff_resample2x_nhwc_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "idiff_perturb_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p]),
+    "idiff_perturb_randn_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, ctypes.c_uint64, c_p, c_p]),
     "idiff_spectrum_workspace_bytes": (c_i64, [c_i, c_i, c_i]),
     "idiff_spectrum_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p]),
     "idiff_colmean_f64": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
@@ -260,6 +261,11 @@ def nhwc_to_nchw(x, y, B, C, HW, Cpad, rowscale=None):
 def perturb(x, z, std, mean_coeff, out, rows, D):
     _check(lib().idiff_perturb_f32(x.data_ptr(), z.data_ptr(), std.data_ptr(), _ptr(mean_coeff), out.data_ptr(), rows, D,
                                    _stream()), "idiff_perturb_f32")
+
+
+def perturb_randn(x, std, mean_coeff, out, rows, D, row0, seed, z_out=None):
+    _check(lib().idiff_perturb_randn_f32(x.data_ptr(), std.data_ptr(), _ptr(mean_coeff), out.data_ptr(), rows, D, row0,
+                                         int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(z_out), _stream()), "idiff_perturb_randn_f32")
 
 
 def resample2x_nhwc(x, y, B, H, W, C, up):

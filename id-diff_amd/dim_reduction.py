@@ -14,8 +14,9 @@ What is different, by design for MI355X:
 * score evaluations run ``inflight`` rows at a time (default: as many of the point's rows as fit the
   ``dim_estimation.inflight_rows`` budget) instead of B -- every row is an independent sample, GroupNorm is
   per-sample and the model is in eval mode, so the batch boundary is not observable;
-* noise comes from a per-point ``torch.Generator`` seeded ``seed + point_index`` so results do not depend on
-  how points are distributed over GPUs; points are sharded round-robin over the ranks of the process group and
+* noise comes from an in-kernel Philox stream keyed by ``seed + 1000003 * (point_index + 1)`` and indexed by the
+  element's position in the point's noise matrix (csrc/rng.hip), fused with the perturbation, so results depend
+  neither on how points are distributed over GPUs nor on the launch-set size; points are sharded round-robin over the ranks of the process group and
   the spectra are combined by one all-gather (parallel.py).
 """
 import math
@@ -64,8 +65,11 @@ class ScoreMatrixBuilder:
             return rows
         return min(rows, max(128, (2240 * 3072) // sample_numel))
 
-    def build(self, x, batchsize, t=None, noise=None, generator=None):
-        """x: one sample on the device; returns S [M, D] fp32 (rows in the reference's order)."""
+    def build(self, x, batchsize, t=None, noise=None, generator=None, seed=None):
+        """x: one sample on the device; returns S [M, D] fp32 (rows in the reference's order).
+
+        Noise: ``noise`` (explicit draws, for parity tests) > ``seed`` (in-kernel Philox stream, the default of the
+        drivers: independent of the launch-set size) > ``generator`` (torch.randn)."""
         _, _, rows = batching(tuple(x.shape), batchsize)
         D = x.numel()
         t = self.eps if t is None else t
@@ -77,12 +81,15 @@ class ScoreMatrixBuilder:
             vec_t = torch.full((n,), float(t), device=self.device, dtype=torch.float32)
             mean_unit, std = self.sde.marginal_prob(torch.ones((), device=self.device), vec_t)
             coeff = None if mean_unit.ndim == 0 else mean_unit.reshape(-1).contiguous()
-            if noise is not None:
-                z = noise[lo:lo + n].reshape(n, D).contiguous()
-            else:
-                z = torch.randn(n, D, device=self.device, dtype=torch.float32, generator=generator)
             batch = torch.empty(n, D, device=self.device, dtype=torch.float32)
-            _lib.perturb(xf, z, std.contiguous(), coeff, batch, n, D)
+            if noise is None and seed is not None and D % 4 == 0:
+                _lib.perturb_randn(xf, std.contiguous(), coeff, batch, n, D, lo, seed)
+            else:
+                if noise is not None:
+                    z = noise[lo:lo + n].reshape(n, D).contiguous()
+                else:
+                    z = torch.randn(n, D, device=self.device, dtype=torch.float32, generator=generator)
+                _lib.perturb(xf, z, std.contiguous(), coeff, batch, n, D)
             score = self.score_fn(batch.view(n, *x.shape), vec_t)
             S[lo:lo + n].copy_(score.reshape(n, D))
         return S
@@ -118,7 +125,7 @@ class SpectrumPipeline:
         return out
 
 
-def build_many(builder, xs, batchsize, generators):
+def build_many(builder, xs, batchsize, seeds):
     """S [P, M, D] for P small (vector) points with ONE score_fn call over all P*M rows: the k-sphere workload is
     launch-bound one point at a time (M = 1501 rows of a 7-layer MLP), so points are batched (BASELINE config 2)."""
     x0 = xs[0]
@@ -129,9 +136,12 @@ def build_many(builder, xs, batchsize, generators):
     coeff = None if mean_unit.ndim == 0 else mean_unit.reshape(-1).contiguous()
     std = std.contiguous()
     batch = torch.empty(P, rows, D, device=dev, dtype=torch.float32)
-    for i, (x, gen) in enumerate(zip(xs, generators)):
-        z = torch.randn(rows, D, device=dev, dtype=torch.float32, generator=gen)
-        _lib.perturb(x.reshape(-1).contiguous(), z, std, coeff, batch[i], rows, D)
+    for i, (x, seed) in enumerate(zip(xs, seeds)):
+        if D % 4 == 0:
+            _lib.perturb_randn(x.reshape(-1).contiguous(), std, coeff, batch[i], rows, D, 0, seed)
+        else:
+            z = torch.randn(rows, D, device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(seed))
+            _lib.perturb(x.reshape(-1).contiguous(), z, std, coeff, batch[i], rows, D)
     t_all = torch.full((P * rows,), float(builder.eps), device=dev, dtype=torch.float32)
     score = builder.score_fn(batch.view(P * rows, *x0.shape), t_all)
     return score.reshape(P, rows, D)
@@ -189,8 +199,8 @@ def get_manifold_dimension(config, name=None, return_svd=False):
     mine = parallel.my_points(len(points), rank, world)
     n_sv = None
     pipe = SpectrumPipeline(device, overlap=bool(config.get('dim_estimation.overlap_spectrum', True)))
-    def point_generator(p):
-        return torch.Generator(device=device).manual_seed(seed + 1000003 * (p + 1))
+    def point_seed(p):
+        return seed + 1000003 * (p + 1)
 
     with torch.no_grad():
         small = bool(mine) and points[mine[0]][0].numel() <= 4096 and len({points[p][1] for p in mine}) == 1
@@ -201,13 +211,13 @@ def get_manifold_dimension(config, name=None, return_svd=False):
             for lo in range(0, len(mine), group):
                 ids = mine[lo:lo + group]
                 S = build_many(builder, [points[p][0].to(device) for p in ids], points[ids[0]][1],
-                               [point_generator(p) for p in ids])
+                               [point_seed(p) for p in ids])
                 pipe.submit(S)
             local = [sv for block in pipe.results() for sv in block]
         else:
             for p in mine:
                 x, batchsize = points[p]
-                pipe.submit(builder.build(x.to(device), batchsize, generator=point_generator(p)))
+                pipe.submit(builder.build(x.to(device), batchsize, seed=point_seed(p)))
             local = pipe.results()
     if local:
         n_sv = local[-1].numel()
@@ -251,8 +261,7 @@ def get_conditional_manifold_dimension(config, name=None):
                     if idx + 1 >= num_datapoints:
                         break
                     imgs.append(x.permute(1, 2, 0))
-                    gen = torch.Generator(device=device).manual_seed(seed + 1000003 * (idx + 1))
-                    S = builder.build(x.to(device), batchsize, t=float(t_slice), generator=gen)
+                    S = builder.build(x.to(device), batchsize, t=float(t_slice), seed=seed + 1000003 * (idx + 1))
                     singular_values.append(_lib.spectrum(S).tolist())
                     labels.append(y.item())
                     idx += 1

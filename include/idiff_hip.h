@@ -140,6 +140,12 @@ int idiff_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int HW, int C
  * out[r, :] = mean_coeff[r] * x[:] + std[r] * z[r, :]; mean_coeff NULL means 1 (VE SDE, sde_lib.py:346). */
 int idiff_perturb_f32(const float *x, const float *z, const float *std_, const float *mean_coeff, float *out,
                       int64_t rows, int64_t D, void *stream);
+/* Same perturbation with the Gaussian draw generated in the kernel (replaces `z = torch.randn_like(batch)` of
+ * dim_reduction.py:181): Philox4x32-10 keyed by `seed`, counter = position of the element in the point's logical
+ * [total_rows, D] noise matrix (row0 = first row of this launch), Box-Muller.  The draw for an element does not depend on
+ * how rows are cut into launches.  D % 4 == 0.  z_out (optional, [rows, D]) receives the N(0,1) values for tests. */
+int idiff_perturb_randn_f32(const float *x, const float *std_, const float *mean_coeff, float *out, int64_t rows,
+                            int64_t D, int64_t row0, uint64_t seed, float *z_out, void *stream);
 /* Nearest x2 upsample / 2x2 mean downsample of NHWC tensors (naive_upsample_2d / naive_downsample_2d,
  * models/up_or_down_sampling.py:59-69; BeatGANs Upsample/Downsample, models/BeatGANsblocks.py:335-396). */
 int idiff_resample2x_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, int up, void *stream);

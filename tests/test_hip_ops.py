@@ -261,3 +261,31 @@ def test_pointwise_and_layout():
     _lib.resample2x_nhwc(a.to(DEV), dn, 2, 6, 6, 8, 0)
     torch.testing.assert_close(up.cpu(), a.repeat_interleave(2, 1).repeat_interleave(2, 2))
     torch.testing.assert_close(dn.cpu(), F.avg_pool2d(a.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1), rtol=1e-6, atol=1e-7)
+
+
+def test_perturb_randn_stream():
+    """In-kernel Philox noise: N(0, 1) moments, reproducible, independent of how rows are cut into launches."""
+    D, rows = 3072, 1024
+    x = torch.rand(D, device=DEV)
+    std = torch.full((rows,), 0.01, device=DEV)
+    out, z = torch.empty(rows, D, device=DEV), torch.empty(rows, D, device=DEV)
+    _lib.perturb_randn(x, std, None, out, rows, D, 0, 12345, z)
+    zc = z.double().cpu()
+    assert abs(float(zc.mean())) < 3e-3 and abs(float(zc.var()) - 1.0) < 5e-3
+    assert abs(float((zc ** 4).mean()) - 3.0) < 0.05                      # Gaussian kurtosis
+    assert abs(float((zc[:, :-1] * zc[:, 1:]).mean())) < 3e-3            # neighbours uncorrelated
+    assert abs(float((zc[:-1] * zc[1:]).mean())) < 3e-3
+    torch.testing.assert_close(out.cpu(), (x[None] + 0.01 * z).cpu(), rtol=1e-6, atol=1e-7)
+    again = torch.empty_like(out)
+    _lib.perturb_randn(x, std, None, again, rows, D, 0, 12345)
+    assert torch.equal(out, again)
+    # second half generated as its own launch with row0 = 512 equals rows 512.. of the full launch
+    half = torch.empty(512, D, device=DEV)
+    _lib.perturb_randn(x, std[:512].contiguous(), None, half, 512, D, 512, 12345)
+    assert torch.equal(half, out[512:])
+    other = torch.empty_like(out)
+    _lib.perturb_randn(x, std, None, other, rows, D, 0, 12346)
+    assert not torch.equal(other, out)
+    coeff = torch.full((rows,), 0.5, device=DEV)
+    _lib.perturb_randn(x, std, coeff, other, rows, D, 0, 12345)
+    torch.testing.assert_close(other.cpu(), (0.5 * x[None] + 0.01 * z).cpu(), rtol=1e-6, atol=1e-7)
