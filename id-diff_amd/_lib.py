@@ -24,7 +24,7 @@ c_i, c_i64, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_vo
 class Epilogue(ctypes.Structure):
     """Mirror of ``idiff_epilogue`` (include/idiff_hip.h)."""
     _fields_ = [("bias", c_p), ("rowbias", c_p), ("ld_rowbias", c_i64), ("rows_per_group", c_i), ("act", c_i),
-                ("residual", c_p), ("ld_residual", c_i64), ("out_scale", c_f), ("rowscale", c_p)]
+                ("residual", c_p), ("ld_residual", c_i64), ("out_scale", c_f), ("rowscale", c_p), ("colstats", c_p)]
 
 
 _SIGNATURES = {
@@ -35,6 +35,9 @@ _SIGNATURES = {
     "idiff_gemm_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i,
                              ctypes.POINTER(Epilogue), c_p]),
     "idiff_conv2d_nhwc_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [ctypes.POINTER(Epilogue), c_p]),
+    "idiff_gemm_colstats_split": (c_i, [c_i, c_i, c_i, c_i64, c_i64, c_i]),
+    "idiff_conv2d_colstats_split": (c_i, [c_i] * 10),
+    "idiff_groupnorm_finalize_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "idiff_groupnorm_nsplit": (c_i, [c_i, c_i, c_i]),
     "idiff_groupnorm_stats_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
     "idiff_groupnorm_apply_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i64, c_i, c_p, c_p]),
@@ -120,7 +123,7 @@ def _ptr(t):
 
 
 def make_epilogue(bias=None, rowbias=None, rows_per_group=1, act=None, residual=None, out_scale=1.0,
-                  ld_rowbias=None, ld_residual=None, rowscale=None):
+                  ld_rowbias=None, ld_residual=None, rowscale=None, colstats=None):
     ep = Epilogue()
     ep.bias = _ptr(bias)
     ep.rowbias = _ptr(rowbias)
@@ -131,8 +134,9 @@ def make_epilogue(bias=None, rowbias=None, rows_per_group=1, act=None, residual=
     ep.ld_residual = (residual.shape[-1] if ld_residual is None else ld_residual) if residual is not None else 0
     ep.out_scale = float(out_scale)
     ep.rowscale = _ptr(rowscale)
+    ep.colstats = _ptr(colstats)
     # the struct only carries raw addresses: keep the tensors alive until the launch that consumes `ep` is enqueued
-    ep._keepalive = (bias, rowbias, residual, rowscale)
+    ep._keepalive = (bias, rowbias, residual, rowscale, colstats)
     return ep
 
 
@@ -202,6 +206,19 @@ def conv2d_nhwc(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue=No
 
 
 # ------------------------------------------------------------------------------------------- norm / pointwise
+def gemm_colstats_split(M, N, K, lda, ldb, rows_per_sample):
+    return lib().idiff_gemm_colstats_split(M, N, K, lda, ldb, rows_per_sample)
+
+
+def conv2d_colstats_split(B, H, W, Cin, Cout, KH, KW, stride, pad, pad_hi=None):
+    return lib().idiff_conv2d_colstats_split(B, H, W, Cin, Cout, KH, KW, stride, pad, pad if pad_hi is None else pad_hi)
+
+
+def groupnorm_finalize(ws1, nsplit1, C1, ws2, nsplit2, C2, B, HW, G, eps, stats):
+    _check(lib().idiff_groupnorm_finalize_f32(ws1.data_ptr(), nsplit1, C1, _ptr(ws2), nsplit2, C2, B, HW, G, eps,
+                                              stats.data_ptr(), _stream()), "idiff_groupnorm_finalize_f32")
+
+
 def groupnorm_nsplit(B, HW, C):
     return lib().idiff_groupnorm_nsplit(B, HW, C)
 

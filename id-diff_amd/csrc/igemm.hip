@@ -457,17 +457,22 @@ igemm_pipe_kernel(const IgemmParams p) {
   float *Cb = p.C + (int64_t)batch * p.strideC;
   const idiff_epilogue &ep = p.ep;
   const int col_l = lane & 31, row_l = (lane >> 5) * 4;
+  // optional per-tile column statistics (sum, sum of squares in fp64) of the values being stored: the GroupNorm that
+  // consumes this tensor then needs no pass of its own over HBM (idiff_epilogue.colstats)
+  const bool want_stats = p.has_ep && ep.colstats != nullptr;
+  double *red = reinterpret_cast<double *>(lds);   // [WARPS_M][BN][2]; operand staging is finished
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + j * 32 + col_l;
-    if (n >= p.N) continue;
-    const float bias = (p.has_ep && ep.bias) ? ep.bias[n] : 0.f;
+    const bool n_ok = n < p.N;
+    const float bias = (n_ok && p.has_ep && ep.bias) ? ep.bias[n] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-        if (m >= p.M) continue;
+        if (m >= p.M || !n_ok) continue;
         float v = acc[i][j][r] + bias;
         if (p.has_ep) {
           if (ep.rowbias) v += ep.rowbias[(int64_t)(m / ep.rows_per_group) * ep.ld_rowbias + n];
@@ -477,7 +482,29 @@ igemm_pipe_kernel(const IgemmParams p) {
           if (ep.rowscale) v *= ep.rowscale[m / ep.rows_per_group];
         }
         Cb[(int64_t)m * p.ldc + n] = v;
+        if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
       }
+    }
+    if (want_stats) {
+      // lanes l and l+32 hold the same column: fold, then one slot per (wave row, column)
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 32) {
+        const int slot = ((wave / WARPS_N) * BN + wn0 + j * 32 + col_l) * 2;
+        red[slot] = s1; red[slot + 1] = s2;
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    for (int c = tid; c < BN; c += T) {
+      const int n = n0 + c;
+      if (n >= p.N) continue;
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < WARPS_M; ++w) { a += red[(w * BN + c) * 2]; b += red[(w * BN + c) * 2 + 1]; }
+      double *dst = ep.colstats + ((int64_t)tile_m * p.N + n) * 2;
+      dst[0] = a; dst[1] = b;
     }
   }
 }
@@ -501,6 +528,15 @@ int launch_pipe(IgemmParams &p, int batch, hipStream_t st) {
   dim3 grid(p.tiles_m * p.tiles_n, batch);
   hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds_bytes, st, p);
   return idiff::launch_status(CONV ? "igemm_pipe_conv" : "igemm_pipe_linear");
+}
+
+// Rows per workgroup tile the pipelined dispatcher picks for (M, N, batch); keep in step with dispatch_pipe.
+int pipe_tile_rows(int M, int N, int batch) {
+  const int64_t wg_big = (int64_t)idiff::ceil_div(M, 128) * idiff::ceil_div(N, 128) * batch;
+  if (N > 64 && wg_big >= 256) return 128;
+  const int64_t wg_mid = (int64_t)idiff::ceil_div(M, 128) * idiff::ceil_div(N, 64) * batch;
+  if (wg_mid >= 256 || M >= 4096) return 128;
+  return 64;
 }
 
 template <bool CONV>
@@ -573,6 +609,7 @@ IDIFF_API int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const
   hipStream_t st = (hipStream_t)stream;
   const int64_t a_bytes = ((int64_t)(M - 1) * lda + K) * 4, b_bytes = ((int64_t)(N - 1) * ldb + K) * 4;
   if (vec && batch == 1 && a_bytes >= BUF_LIMIT && b_bytes < BUF_LIMIT && !getenv("IDIFF_NO_PIPE")) {
+    if (ep && ep->colstats) return fail("gemm: colstats is not available for operands beyond 4 GiB");
     const int rpg = (ep && ep->rows_per_group > 0) ? ep->rows_per_group : 1;
     const int mid = (M / 2 / rpg) * rpg;
     if (mid > 0) {
@@ -588,6 +625,8 @@ IDIFF_API int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const
     p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
     return dispatch_pipe<false>(p, batch, st);
   }
+  if (ep && ep->colstats) return fail("gemm: colstats requested for a problem the pipelined kernel does not take "
+                                      "(ask idiff_gemm_colstats_split first)");
   return vec ? dispatch<false, true>(p, batch, st) : dispatch<false, false>(p, batch, st);
 }
 
@@ -614,6 +653,9 @@ IDIFF_API int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out,
   fill_epilogue(p, ep);
   const int64_t a_bytes = (int64_t)B * H * W * Cin * 4, b_bytes = (int64_t)Cout * p.K * 4;
   const bool fast_ok = Cin % BK == 0 && KH * KW <= 32 && b_bytes < BUF_LIMIT && !getenv("IDIFF_NO_PIPE");
+  if (ep && ep->colstats && !(fast_ok && a_bytes < BUF_LIMIT))
+    return fail("conv2d: colstats requested for a problem the pipelined kernel does not take "
+                "(ask idiff_conv2d_colstats_split first)");
   if (fast_ok && a_bytes >= BUF_LIMIT && B > 1) {
     // split the batch (images are independent) so that each half fits one buffer descriptor
     const int rpg = (ep && ep->rows_per_group > 0) ? ep->rows_per_group : 1;
@@ -633,4 +675,29 @@ IDIFF_API int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out,
     return dispatch_pipe<true>(p, 1, (hipStream_t)stream);
   }
   return dispatch<true, true>(p, 1, (hipStream_t)stream);
+}
+
+
+// Number of workgroup row-tiles per sample when `rows_per_sample` consecutive output rows form one sample, i.e. the
+// `nsplit` of the [samples, nsplit, N, 2] fp64 layout idiff_epilogue.colstats is written in -- or 0 when the fused
+// statistics are not available for this problem (then the consumer runs idiff_groupnorm_stats_f32 as usual).
+IDIFF_API int idiff_gemm_colstats_split(int M, int N, int K, int64_t lda, int64_t ldb, int rows_per_sample) {
+  if (M <= 0 || N <= 0 || K <= 0 || rows_per_sample <= 0 || M % rows_per_sample) return 0;
+  if (getenv("IDIFF_NO_PIPE") || getenv("IDIFF_NO_COLSTATS")) return 0;
+  if (K % 4 || lda % 4 || ldb % 4) return 0;
+  if (((int64_t)(M - 1) * lda + K) * 4 >= BUF_LIMIT || ((int64_t)(N - 1) * ldb + K) * 4 >= BUF_LIMIT) return 0;
+  const int bm = pipe_tile_rows(M, N, 1);
+  return rows_per_sample % bm == 0 ? rows_per_sample / bm : 0;
+}
+
+IDIFF_API int idiff_conv2d_colstats_split(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_lo,
+                                          int pad_hi) {
+  if (B <= 0 || Cin % BK || KH * KW > 32 || getenv("IDIFF_NO_PIPE") || getenv("IDIFF_NO_COLSTATS")) return 0;
+  const int OH = (H + pad_lo + pad_hi - KH) / stride + 1, OW = (W + pad_lo + pad_hi - KW) / stride + 1;
+  if (OH <= 0 || OW <= 0) return 0;
+  if ((int64_t)B * H * W * Cin * 4 >= BUF_LIMIT || (int64_t)Cout * KH * KW * Cin * 4 >= BUF_LIMIT) return 0;
+  const int64_t M = (int64_t)B * OH * OW;
+  if (M > 0x7fffffff) return 0;
+  const int bm = pipe_tile_rows((int)M, Cout, 1), rps = OH * OW;
+  return rps % bm == 0 ? rps / bm : 0;
 }

@@ -66,6 +66,28 @@ __global__ void gn_finalize_kernel(const double *__restrict__ ws, int B, int nsp
   stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// Statistics from per-tile column sums written by the producing contraction's epilogue (idiff_epilogue.colstats,
+// layout [B][nsplit][C][2] per source): no pass over the activations at all.
+__global__ void gn_finalize2_kernel(const double *__restrict__ ws1, int ns1, int C1, const double *__restrict__ ws2,
+                                    int ns2, int C2, int B, int G, int HW, float eps, float *__restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * G) return;
+  const int b = i / G, g = i - b * G, Ctot = C1 + C2, cpg = Ctot / G;
+  double s = 0, q = 0;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    const bool first = c < C1;
+    const double *w = first ? ws1 + ((int64_t)b * ns1 * C1 + c) * 2 : ws2 + ((int64_t)b * ns2 * C2 + (c - C1)) * 2;
+    const int ns = first ? ns1 : ns2, Cs = first ? C1 : C2;
+    for (int sp = 0; sp < ns; ++sp) { s += w[(int64_t)sp * Cs * 2]; q += w[(int64_t)sp * Cs * 2 + 1]; }
+  }
+  const double n = (double)cpg * HW;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  stats[2 * i] = (float)mean;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const float *__restrict__ x, int C, const float *__restrict__ x2, int C2, int HW, int G,
                 const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -389,6 +411,17 @@ IDIFF_API int idiff_groupnorm_stats_f32(const float *x, int C, const float *x2, 
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(B * G, 256)), dim3(256), 0, st, workspace, B, nsplit, Ctot, G,
                      HW, eps, stats);
   return launch_status("groupnorm_stats");
+}
+
+IDIFF_API int idiff_groupnorm_finalize_f32(const double *ws1, int nsplit1, int C1, const double *ws2, int nsplit2, int C2,
+                                           int B, int HW, int G, float eps, float *stats, void *stream) {
+  if (!ws1 || !stats || B <= 0 || HW <= 0 || C1 <= 0 || nsplit1 <= 0 || G <= 0) return fail("groupnorm_finalize: bad arguments");
+  if (!ws2) { C2 = 0; nsplit2 = 0; }
+  if (ws2 && (C2 <= 0 || nsplit2 <= 0)) return fail("groupnorm_finalize: second source needs C2, nsplit2 > 0");
+  if ((C1 + C2) % G) return fail("groupnorm_finalize: channels not divisible by groups");
+  hipLaunchKernelGGL(gn_finalize2_kernel, dim3(ceil_div(B * G, 256)), dim3(256), 0, (hipStream_t)stream, ws1, nsplit1, C1, ws2,
+                     nsplit2, C2, B, G, HW, eps, stats);
+  return launch_status("groupnorm_finalize");
 }
 
 IDIFF_API int idiff_groupnorm_apply_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G,

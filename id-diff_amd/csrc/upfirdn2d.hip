@@ -211,8 +211,8 @@ upfirdn2d_planes_whole(const float *__restrict__ x, const float *__restrict__ k,
 }
 
 // ---------------------------------------------------------------- minor % 4 == 0, row-structured
-// grid.y = (plane, oy); a thread keeps its channel vector c4 and walks output columns, so the only integer
-// divisions are the two that split blockIdx.y (uniform) -- the per-element 64-bit div/mod of a flat grid-stride
+// grid.x = (plane, oy); a thread keeps its channel vector c4 and walks output columns, so the only integer
+// divisions are the two that split blockIdx.x (uniform) -- the per-element 64-bit div/mod of a flat grid-stride
 // loop made this kernel VALU-bound.
 template <int UPLOG>
 __global__ void __launch_bounds__(256)
@@ -225,14 +225,14 @@ upfirdn2d_nhwc_rows(const float *__restrict__ x, const float *__restrict__ k, fl
     taps[i] = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
   }
   __syncthreads();
-  const int plane = blockIdx.y / p.out_h, oy = blockIdx.y - plane * p.out_h;
+  const int plane = blockIdx.x / p.out_h, oy = blockIdx.x - plane * p.out_h;   // rows on grid.x (no 65535 limit)
   const int c4 = threadIdx.x % cv, col0 = threadIdx.x / cv;
   if (col0 >= col_step) return;
   const int by = oy * p.down_y - p.pad_y0;
   const int iy_lo = max(ceil_div_s(by, p.up_y), 0), iy_hi = min(floor_div(by + p.kh - 1, p.up_y), p.in_h - 1);
   const float4 *xp = reinterpret_cast<const float4 *>(x) + (int64_t)plane * p.in_h * p.in_w * cv + c4;
   float4 *op = reinterpret_cast<float4 *>(out) + ((int64_t)plane * p.out_h + oy) * p.out_w * cv + c4;
-  for (int ox = blockIdx.x * col_step + col0; ox < p.out_w; ox += gridDim.x * col_step) {
+  for (int ox = blockIdx.y * col_step + col0; ox < p.out_w; ox += gridDim.y * col_step) {
     const int bx = ox * p.down_x - p.pad_x0;
     const int ix_lo = max(ceil_div_s(bx, p.up_x), 0), ix_hi = min(floor_div(bx + p.kw - 1, p.up_x), p.in_w - 1);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -354,13 +354,13 @@ IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, in
     }
   }
   if (minor % 4 == 0 && minor <= 1024 && kh * kw <= kMaxTaps && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
-      (int64_t)major * p.out_h <= 65535) {
+      (int64_t)major * p.out_h <= 0x7fffffff) {
     const int cv = minor / 4, col_step = 256 / cv;
     // enough rows to fill the chip: one workgroup per output row (each thread walks out_w / col_step pixels);
     // otherwise split rows over up to 8 workgroups
     const int gx = (int64_t)major * p.out_h >= 2048 ? 1 : max(1, min(ceil_div(p.out_w, col_step), 8));
     const int uplog = (up_x == up_y && kh <= 4 && kw <= 4) ? (up_x == 1 ? 0 : up_x == 2 ? 1 : -1) : -1;
-    const dim3 grid(gx, major * p.out_h);
+    const dim3 grid(major * p.out_h, gx);
     if (uplog == 0)
       hipLaunchKernelGGL(upfirdn2d_nhwc_rows<0>, grid, dim3(256), 0, st, x, k, out, p, cv, col_step);
     else if (uplog == 1)

@@ -188,7 +188,7 @@ class BeatGANsUNetModel(HipScoreModel):
             assert x2 is None
             h, x = self._box(h, mod.up), self._box(x, mod.up)
         w0, b0 = self._cw(pk, mod.in_layers[2])
-        h = self._conv(h, w0, b0)
+        h = self._conv(h, w0, b0, stats=True)
         off = pk["emb_off"][id(mod)]
         h = self._gn_act(h, mod.out_layers[0], "silu", mod=emb_all[:, off:off + 2 * mod.out_channels])
         if isinstance(mod.skip_connection, nn.Identity):
@@ -202,7 +202,7 @@ class BeatGANsUNetModel(HipScoreModel):
                 part = self._pointwise(x, ws[0].view(ws[0].shape[0], -1), bsk)
                 sc = self._pointwise(x2, ws[1].view(ws[1].shape[0], -1), None, residual=part.buf)
         w1, b1 = self._cw(pk, mod.out_layers[3])
-        return self._conv(h, w1, b1, residual=sc.buf)
+        return self._conv(h, w1, b1, residual=sc.buf, stats=True)
 
     def _attn(self, mod, x, pk):
         """AttentionBlock._forward (BeatGANsblocks.py:433-443) with QKVAttentionLegacy (:466-491), one head."""
@@ -230,7 +230,7 @@ class BeatGANsUNetModel(HipScoreModel):
         mixed = torch.empty(B, HW, C, device=dev, dtype=torch.float32)
         _lib.gemm(logits, vt, out=mixed, M=HW, N=C, K=HW, lda=HW, ldb=HW, ldc=C, batch=B, stride_a=HW * HW,
                   stride_b=C * HW, stride_c=HW * C, epilogue=_lib.make_epilogue(bias=bv))  # V bias after P.V: rows of P sum to 1
-        return self._pointwise(_T(mixed, x.H, x.W, C), wo, bo, residual=x.buf)
+        return self._pointwise(_T(mixed, x.H, x.W, C), wo, bo, residual=x.buf, stats=True)
 
     def _resample(self, mod, x, pk):
         if mod.up:

@@ -157,11 +157,12 @@ def _pad4(c):
 
 
 class _T:
-    """An NHWC activation: buffer [B, H*W, C] + geometry."""
-    __slots__ = ("buf", "H", "W", "C")
+    """An NHWC activation: buffer [B, H*W, C] + geometry (+ the per-tile column sums [B, nsplit, C, 2] its producing
+    contraction wrote through epilogue.colstats, which let the consuming GroupNorm skip its statistics pass)."""
+    __slots__ = ("buf", "H", "W", "C", "stats")
 
-    def __init__(self, buf, H, W, C):
-        self.buf, self.H, self.W, self.C = buf, H, W, C
+    def __init__(self, buf, H, W, C, stats=None):
+        self.buf, self.H, self.W, self.C, self.stats = buf, H, W, C, stats
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -338,16 +339,22 @@ class NCSNpp(HipScoreModel):
         HW = x.H * x.W
         C2 = x2.C if x2 is not None else 0
         G = gn.num_groups
-        nsplit = _lib.groupnorm_nsplit(B, HW, x.C + C2)
-        ws = torch.empty(B * nsplit * (x.C + C2) * 2, device=x.buf.device, dtype=torch.float64)
         stats = torch.empty(B * G * 2, device=x.buf.device, dtype=torch.float32)
-        _lib.groupnorm_stats(x.buf, x.C, x2.buf if x2 is not None else None, C2, B, HW, G, gn.eps, ws, stats)
+        if x.stats is not None and (x2 is None or x2.stats is not None):
+            # both sources carry the column sums their producing contraction wrote: no pass over the activations
+            ws2, ns2 = x2.stats if x2 is not None else (None, 0)
+            _lib.groupnorm_finalize(x.stats[0], x.stats[1], x.C, ws2, ns2, C2, B, HW, G, gn.eps, stats)
+        else:
+            nsplit = _lib.groupnorm_nsplit(B, HW, x.C + C2)
+            ws = torch.empty(B * nsplit * (x.C + C2) * 2, device=x.buf.device, dtype=torch.float64)
+            _lib.groupnorm_stats(x.buf, x.C, x2.buf if x2 is not None else None, C2, B, HW, G, gn.eps, ws, stats)
         y = self._new(B, x.H, x.W, x.C + C2, x.buf)
         _lib.groupnorm_apply(x.buf, x.C, x2.buf if x2 is not None else None, C2, B, HW, G, stats,
                              gn.weight.detach(), gn.bias.detach(), act, y.buf, mod=mod)
         return y
 
-    def _conv(self, x, wt, bias, stride=1, pad=1, pad_hi=None, **ep):
+    def _conv(self, x, wt, bias, stride=1, pad=1, pad_hi=None, stats=False, **ep):
+        """``stats=True``: the output feeds a GroupNorm -> ask the epilogue for its per-tile column sums."""
         B = x.buf.shape[0]
         cout, kh, kw, cin = wt.shape
         assert cin == x.C, (cin, x.C)
@@ -357,16 +364,26 @@ class NCSNpp(HipScoreModel):
         y = self._new(B, OH, OW, cout, x.buf)
         if "rows_per_group" not in ep:
             ep["rows_per_group"] = OH * OW
+        if stats:
+            ns = _lib.conv2d_colstats_split(B, x.H, x.W, cin, cout, kh, kw, stride, pad, pad_hi)
+            if ns > 0:
+                y.stats = (torch.empty(B * ns * cout * 2, device=x.buf.device, dtype=torch.float64), ns)
+                ep["colstats"] = y.stats[0]
         _lib.conv2d_nhwc(x.buf, wt, y.buf, B, x.H, x.W, cin, cout, kh, kw, stride, pad,
                          epilogue=_lib.make_epilogue(bias=bias, **ep), pad_hi=pad_hi)
         return y
 
-    def _pointwise(self, x, w, bias, **ep):
+    def _pointwise(self, x, w, bias, stats=False, **ep):
         """1x1 conv / NIN on NHWC = plain GEMM over [B*HW, Cin]; w is [Cout, Cin]."""
         B = x.buf.shape[0]
         cout, cin = w.shape
         assert cin == x.C, (cin, x.C)
         y = self._new(B, x.H, x.W, cout, x.buf)
+        if stats:
+            ns = _lib.gemm_colstats_split(B * x.H * x.W, cout, cin, cin, w.stride(0), x.H * x.W)
+            if ns > 0:
+                y.stats = (torch.empty(B * ns * cout * 2, device=x.buf.device, dtype=torch.float64), ns)
+                ep["colstats"] = y.stats[0]
         _lib.gemm(x.buf.view(-1, cin), w, out=y.buf.view(-1, cout), epilogue=_lib.make_epilogue(bias=bias, **ep))
         return y
 
@@ -421,7 +438,7 @@ class NCSNpp(HipScoreModel):
                 h, x = self._box(h, mod.up), self._box(x, mod.up)
         w0, b0 = self._conv_w(pk, (idx, 0), mod.Conv_0)
         off = pk["dense_off"][idx]
-        h = self._conv(h, w0, b0, rowbias=temb_all[:, off:off + mod.out_ch])
+        h = self._conv(h, w0, b0, rowbias=temb_all[:, off:off + mod.out_ch], stats=True)
         h = self._gn_act(h, mod.GroupNorm_1, self.act_name)
         # shortcut
         if hasattr(mod, "Conv_2") or hasattr(mod, "NIN_0"):
@@ -440,7 +457,7 @@ class NCSNpp(HipScoreModel):
             assert x2 is None
             sc = x
         w1, b1 = self._conv_w(pk, (idx, 1), mod.Conv_1)
-        return self._conv(h, w1, b1, residual=sc.buf, out_scale=rs)
+        return self._conv(h, w1, b1, residual=sc.buf, out_scale=rs, stats=True)   # next: a GroupNorm_0 / skip
 
     def _attn(self, idx, x, pk):
         """AttnBlockpp (layerspp.py:62-91)."""
@@ -469,7 +486,7 @@ class NCSNpp(HipScoreModel):
         _lib.gemm(logits, vt, out=mixed, M=HW, N=C, K=HW, lda=HW, ldb=HW, ldc=C, batch=B,
                   stride_a=HW * HW, stride_b=C * HW, stride_c=HW * C, epilogue=_lib.make_epilogue(bias=bv))
         rs = _INV_SQRT2 if self.skip_rescale else 1.0
-        return self._pointwise(_T(mixed, x.H, x.W, C), w3, b3, residual=x.buf, out_scale=rs)
+        return self._pointwise(_T(mixed, x.H, x.W, C), w3, b3, residual=x.buf, out_scale=rs, stats=True)
 
     def _downsample(self, idx, x, pk, **ep):
         """layerspp.Downsample (:129-163) for every (fir, with_conv) pair."""
@@ -523,7 +540,7 @@ class NCSNpp(HipScoreModel):
                     _lib.nchw_to_nhwc(x, xin.buf, B, C, H * W, cp, 2.0, -1.0)  # 2x - 1, ncsnpp.py:264-266
                 pyr_in = xin
                 w, b = self._conv_w(pk, (step[1], "stem"), M[step[1]])
-                hs = [self._conv(xin, w, b)]
+                hs = [self._conv(xin, w, b, stats=True)]
             elif op == "res_push":
                 h = self._resblock(step[1], hs[-1], temb_all, pk)
                 if step[2] is not None:

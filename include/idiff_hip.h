@@ -74,6 +74,9 @@ typedef struct idiff_epilogue {
   int64_t ld_residual;
   float out_scale;        /* 1.0f for none */
   const float *rowscale;  /* [M / rows_per_group] or NULL */
+  double *colstats;       /* NULL, or [tiles_m, N, 2] fp64: per row-tile column sums (sum, sum of squares) of the stored
+                             values, so that the GroupNorm consuming the output needs no statistics pass of its own; only
+                             valid when idiff_gemm_colstats_split / idiff_conv2d_colstats_split returns > 0 */
 } idiff_epilogue;
 
 /* Batched C[b] = epilogue(A[b] (M x K, row-major, lda) * Bt[b]^T (Bt is N x K, row-major, ldb)).
@@ -96,6 +99,13 @@ int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt
 int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out, int B, int H, int W, int Cin, int Cout,
                           int KH, int KW, int stride, int pad_lo, int pad_hi, const idiff_epilogue *ep, void *stream);
 
+/* Fused GroupNorm statistics: when `rows_per_sample` consecutive output rows form one sample, these return the number of
+ * workgroup row-tiles per sample (`nsplit`: epilogue.colstats is then laid out [samples, nsplit, N, 2]) or 0 when the
+ * fused statistics are unavailable for the problem (general kernel, operands beyond 4 GiB, tiles straddling samples). */
+int idiff_gemm_colstats_split(int M, int N, int K, int64_t lda, int64_t ldb, int rows_per_sample);
+int idiff_conv2d_colstats_split(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_lo,
+                                int pad_hi);
+
 /* ------------------------------------------------------------------ normalisation / pointwise (HBM-bound) */
 
 /* GroupNorm statistics over NHWC x [B, HW, C] with G groups: stats[b, g] = {mean, rstd}, biased variance,
@@ -107,6 +117,10 @@ int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out, int B, in
 int idiff_groupnorm_nsplit(int B, int HW, int C);
 int idiff_groupnorm_stats_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G, float eps,
                               double *workspace, float *stats, void *stream);
+/* Same statistics from the per-tile column sums a producing contraction wrote through epilogue.colstats (one workspace
+ * per source tensor, [B, nsplit_i, C_i, 2] fp64); ws2 may be NULL.  No pass over the activations. */
+int idiff_groupnorm_finalize_f32(const double *ws1, int nsplit1, int C1, const double *ws2, int nsplit2, int C2, int B,
+                                 int HW, int G, float eps, float *stats, void *stream);
 /* y[b, p, c] = act(n * (1 + mod[b, c]) + mod[b, Ctot + c]) with n = (x - mean) * rstd * gamma[c] + beta[c]; writes the
  * channel-concatenated output [B, HW, Ctot = C+C2].  mod ([B, ld_mod], scale then shift halves) is the scale-shift
  * conditioning of models/BeatGANsblocks.py:258-332 (`h * (1 + scale) + shift` after the norm); NULL skips it. */

@@ -42,8 +42,8 @@ def test_abi_version_and_loader(library):
 
 
 def test_epilogue_struct_layout_matches_header():
-    # 8 + 8 + 8 + 4 + 4 + 8 + 8 + 4 (+4 pad) + 8
-    assert ctypes.sizeof(_lib.Epilogue) == 64
+    # 8 + 8 + 8 + 4 + 4 + 8 + 8 + 4 (+4 pad) + 8 + 8
+    assert ctypes.sizeof(_lib.Epilogue) == 72
     assert _lib.Epilogue.rowscale.offset == 56 and _lib.Epilogue.residual.offset == 32
 
 

@@ -289,3 +289,32 @@ def test_perturb_randn_stream():
     coeff = torch.full((rows,), 0.5, device=DEV)
     _lib.perturb_randn(x, std, coeff, other, rows, D, 0, 12345)
     torch.testing.assert_close(other.cpu(), (0.5 * x[None] + 0.01 * z).cpu(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(8, 32, 128, 128), (16, 16, 256, 256), (40, 16, 64, 96)])
+def test_fused_colstats_feed_groupnorm(B, H, Cin, Cout):
+    """epilogue.colstats: per-tile column sums written by the conv + idiff_groupnorm_finalize_f32 give the same
+    GroupNorm statistics as the stand-alone statistics pass over the stored tensor."""
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, H * H, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    ns = _lib.conv2d_colstats_split(B, H, H, Cin, Cout, 3, 3, 1, 1)
+    assert ns == H * H // 128
+    cs = torch.empty(B * ns * Cout * 2, device=DEV, dtype=torch.float64)
+    out = torch.empty(B, H * H, Cout, device=DEV)
+    _lib.conv2d_nhwc(x, w, out, B, H, H, Cin, Cout, 3, 3, 1, 1,
+                     epilogue=_lib.make_epilogue(bias=bias, act="silu", rows_per_group=H * H, colstats=cs))
+    ref = out.double().reshape(B, ns, 128, Cout)
+    np.testing.assert_allclose(cs.view(B, ns, Cout, 2)[..., 0].cpu().numpy(), ref.sum(2).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(cs.view(B, ns, Cout, 2)[..., 1].cpu().numpy(), (ref * ref).sum(2).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    G = 32
+    st_a, st_b = torch.empty(B * G * 2, device=DEV), torch.empty(B * G * 2, device=DEV)
+    _lib.groupnorm_finalize(cs, ns, Cout, None, 0, 0, B, H * H, G, 1e-6, st_a)
+    nsp = _lib.groupnorm_nsplit(B, H * H, Cout)
+    ws = torch.empty(B * nsp * Cout * 2, device=DEV, dtype=torch.float64)
+    _lib.groupnorm_stats(out, Cout, None, 0, B, H * H, G, 1e-6, ws, st_b)
+    torch.testing.assert_close(st_a, st_b, rtol=1e-6, atol=1e-7)
+    # samples smaller than a row tile: not available, the caller keeps the stand-alone pass
+    assert _lib.conv2d_colstats_split(4096, 8, 8, Cin, Cout, 3, 3, 1, 1) == 0   # 64-row samples inside 128-row tiles
+    assert _lib.conv2d_colstats_split(B, H, H, 4, Cout, 3, 3, 1, 1) == 0     # general kernel (Cin % 32 != 0)
