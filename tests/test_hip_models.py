@@ -253,3 +253,21 @@ def test_conditional_manifold_dimension_layout(tmp_path):
         assert all(s[i] >= s[i + 1] for s in sv for i in range(len(s) - 1))
         first = first or sv
     assert first != sv     # the spectrum depends on the noise level
+
+
+def test_score_matrix_does_not_depend_on_launch_set_size():
+    """In-kernel Philox noise is indexed by the element's position in the point's noise matrix and every kernel is
+    free of atomics, so cutting the rows of a point into different launch sets changes nothing observable."""
+    cfg = ncsnpp_config(**{"model.init_scale": 1.0})
+    torch.manual_seed(5)
+    model = mutils.create_model(cfg).to(DEV)
+    sde = sde_lib.VESDE(0.01, 50, 1000)
+    score_fn = mutils.get_score_fn(sde, model)
+    x = torch.rand(3, 32, 32, device=DEV)
+    mats = []
+    for inflight in (None, 96, 1000):
+        b = dim_reduction.ScoreMatrixBuilder(score_fn, sde, 1e-5, torch.device(DEV), inflight_rows=inflight)
+        mats.append(b.build(x, 700, seed=99))                    # (1024 // 700 + 1) * 4 = 8 batches, extra 324 -> 5224 rows
+    assert mats[0].shape == (5224, 3072)
+    for other in mats[1:]:
+        assert rel_err(other.cpu(), mats[0].cpu()) < 2e-6
