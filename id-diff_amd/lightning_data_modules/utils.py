@@ -1,20 +1,9 @@
 """Data-module registry (drop-in for /root/reference/lightning_data_modules/utils.py:4-30), without Lightning."""
-_LIGHTNING_DATA_MODULES = {}
+from ..registry import Registry
 
-
-def register_lightning_datamodule(cls=None, *, name=None):
-    def _register(cls):
-        local_name = cls.__name__ if name is None else name
-        if local_name in _LIGHTNING_DATA_MODULES:
-            raise ValueError(f'Already registered model with name: {local_name}')
-        _LIGHTNING_DATA_MODULES[local_name] = cls
-        return cls
-
-    return _register if cls is None else _register(cls)
-
-
-def get_lightning_datamodule_by_name(name):
-    return _LIGHTNING_DATA_MODULES[name]
+_DATA_MODULES = Registry("data module")
+register_lightning_datamodule = _DATA_MODULES.register
+get_lightning_datamodule_by_name = _DATA_MODULES.get
 
 
 def create_lightning_datamodule(config):

@@ -11,24 +11,11 @@ so the division never costs a separate pass over HBM.
 """
 import torch
 
-_MODELS = {}
+from ..registry import Registry
 
-
-def register_model(cls=None, *, name=None):
-    """Decorator registering a model class under ``name`` (models/utils.py:27-43)."""
-
-    def _register(cls):
-        local_name = cls.__name__ if name is None else name
-        if local_name in _MODELS:
-            raise ValueError(f'Already registered model with name: {local_name}')
-        _MODELS[local_name] = cls
-        return cls
-
-    return _register if cls is None else _register(cls)
-
-
-def get_model(name):
-    return _MODELS[name]
+_MODELS = Registry("score model")
+register_model = _MODELS.register     # @register_model / @register_model(name='fcn'), as models/utils.py:27-43
+get_model = _MODELS.get
 
 
 def create_model(config):
