@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 import id_diff_amd
-from id_diff_amd import _lib, dim_reduction, parallel, plot_utils
+from id_diff_amd import _lib, dim_reduction, parallel, plot_utils, sde_lib
 from id_diff_amd.configs.utils import read_config
 from id_diff_amd.models import utils as mutils
 from id_diff_amd.lightning_data_modules.SyntheticImages import smooth_decoder_images
@@ -139,7 +139,7 @@ def main():
     cfg.model.init_scale = 1.0      # random weights with every branch numerically active (SURVEY 8-d cfg 3)
     torch.manual_seed(0)
     model = mutils.create_model(cfg).to(dev).eval()
-    sde, eps = id_diff_amd.sde_lib.configure_sde(cfg)
+    sde, eps = sde_lib.configure_sde(cfg)
     score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
     B = cfg.training.batch_size
     images = smooth_decoder_images(args.steps + args.warmup, [3, 32, 32], 64, seed=100 + rank).to(dev)

@@ -35,3 +35,18 @@ if len(sys.argv) > 2 and sys.argv[2] == "svd":
     torch.cuda.synchronize(); t0 = time.perf_counter()
     sv = _lib.spectrum(S); torch.cuda.synchronize()
     say(f"spectrum {M}x{D}: {(time.perf_counter()-t0):.2f} s; ID rule -> {plot_utils.estimate_dim(sv.tolist())} (expect 64)")
+if len(sys.argv) > 2 and sys.argv[2] == "pipeline":
+    from id_diff_amd.lightning_data_modules.SyntheticImages import smooth_decoder_images
+    imgs = smooth_decoder_images(3, [3, 64, 64], 64, seed=0).to(dev)
+    builder = dim_reduction.ScoreMatrixBuilder(score_fn, sde, eps, dev)
+    pipe = dim_reduction.SpectrumPipeline(dev)
+    with torch.no_grad():
+        pipe.submit(builder.build(imgs[0], 128, seed=1)); pipe.results(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in (1, 2):
+            pipe.submit(builder.build(imgs[i], 128, seed=2 + i))
+        svs = pipe.results(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    rows = dim_reduction.batching((3, 64, 64), 128)[2]
+    say(f"config 5 pipeline: 2 points x {rows} rows in {dt:.2f} s -> {2*rows/dt:.0f} evals/s incl. spectra of {rows}x12288; "
+        f"IDs {[plot_utils.estimate_dim(s.tolist()) for s in svs]}")

@@ -4,7 +4,8 @@ import torch
 import id_diff_amd
 from id_diff_amd import _lib
 dev = "cuda"
-shapes = [(512, 32, 128, 128), (512, 16, 256, 256), (512, 32, 256, 128)]
+BB = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+shapes = [(BB, 32, 128, 128), (BB, 16, 256, 256), (BB, 32, 256, 128), (BB, 32, 384, 128), (BB, 8, 256, 256)]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 for (B, H, Cin, Cout) in shapes + shapes:
     xx = torch.randn(B, H * H, Cin, device=dev)
