@@ -37,6 +37,11 @@ _SIGNATURES = {
     "idiff_conv2d_nhwc_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [ctypes.POINTER(Epilogue), c_p]),
     "idiff_gemm_colstats_split": (c_i, [c_i, c_i, c_i, c_i64, c_i64, c_i]),
     "idiff_conv2d_colstats_split": (c_i, [c_i] * 10),
+    "idiff_conv2d_winograd_ok": (c_i, [c_i] * 5),
+    "idiff_winograd_weight_floats": (c_i64, [c_i, c_i]),
+    "idiff_winograd_pack_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    "idiff_conv2d_winograd_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 5 + [ctypes.POINTER(Epilogue), c_p]),
+    "idiff_conv2d_winograd_colstats_split": (c_i, [c_i] * 5),
     "idiff_groupnorm_finalize_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "idiff_groupnorm_nsplit": (c_i, [c_i, c_i, c_i]),
     "idiff_groupnorm_stats_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
@@ -203,6 +208,31 @@ def conv2d_nhwc(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue=No
     _check(lib().idiff_conv2d_nhwc_f32(x.data_ptr(), wt.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, KH, KW, stride,
                                        pad, pad if pad_hi is None else pad_hi, ep, _stream()), "idiff_conv2d_nhwc_f32")
     return out
+
+
+def conv2d_winograd_ok(B, H, W, Cin, Cout):
+    return bool(lib().idiff_conv2d_winograd_ok(B, H, W, Cin, Cout))
+
+
+def winograd_pack(wt, Cin, Cout):
+    """wt [Cout, 3, 3, Cin] (the direct kernel's panel) -> the transformed filter bank of idiff_conv2d_winograd_f32."""
+    _dev(wt, "wt")
+    if wt.numel() != Cout * 9 * Cin:
+        raise RuntimeError(f"winograd_pack: expected {Cout}x3x3x{Cin} weights, got {tuple(wt.shape)}")
+    u = torch.empty(lib().idiff_winograd_weight_floats(Cin, Cout), device=wt.device, dtype=torch.float32)
+    _check(lib().idiff_winograd_pack_f32(wt.data_ptr(), u.data_ptr(), Cin, Cout, _stream()), "idiff_winograd_pack_f32")
+    return u
+
+
+def conv2d_winograd(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+    ep = ctypes.byref(epilogue) if epilogue is not None else None
+    _check(lib().idiff_conv2d_winograd_f32(x.data_ptr(), u.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, ep, _stream()),
+           "idiff_conv2d_winograd_f32")
+    return out
+
+
+def conv2d_winograd_colstats_split(B, H, W, Cin, Cout):
+    return lib().idiff_conv2d_winograd_colstats_split(B, H, W, Cin, Cout)
 
 
 # ------------------------------------------------------------------------------------------- norm / pointwise

@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRC="runtime.hip upfirdn2d.hip fused_bias_act.hip igemm.hip norm_act.hip rng.hip spectrum.hip"
+SRC="runtime.hip upfirdn2d.hip fused_bias_act.hip igemm.hip norm_act.hip rng.hip spectrum.hip winograd.hip"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
   -Wall -Wno-unused-function -o libidiff_hip.so.tmp $SRC
 mv -f libidiff_hip.so.tmp libidiff_hip.so

@@ -106,6 +106,23 @@ int idiff_gemm_colstats_split(int M, int N, int K, int64_t lda, int64_t ldb, int
 int idiff_conv2d_colstats_split(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_lo,
                                 int pad_hi);
 
+/* The same 3x3 / stride 1 / pad 1 convolution (ddpm_conv3x3, models/layers.py:100-116; conv3x3 of
+ * models/layerspp.py) by Winograd F(2x2, 3x3): 2.25x fewer multiplications than the implicit GEMM, still fp32
+ * throughout (results agree with idiff_conv2d_nhwc_f32 to fp32 rounding, not bit for bit).
+ *   idiff_conv2d_winograd_ok       1 when the geometry is served (H, W even, Cin % 8 == 0, Cout % 64 == 0), else 0.
+ *   idiff_winograd_weight_floats   size of the transformed filter bank u (16 * Cin * Cout floats).
+ *   idiff_winograd_pack_f32        wt [Cout, 3, 3, Cin] (the panel idiff_conv2d_nhwc_f32 takes) -> u, once per layer.
+ *   idiff_conv2d_winograd_f32      x [B, H, W, Cin] -> out [B, H, W, Cout], epilogue as above (rows_per_group counts
+ *                                  output pixels).
+ *   idiff_conv2d_winograd_colstats_split   nsplit of epilogue.colstats ([samples, nsplit, Cout, 2]) or 0 when the
+ *                                  fused statistics are unavailable (fewer than 64 output tiles per sample). */
+int idiff_conv2d_winograd_ok(int B, int H, int W, int Cin, int Cout);
+int64_t idiff_winograd_weight_floats(int Cin, int Cout);
+int idiff_winograd_pack_f32(const float *wt, float *u, int Cin, int Cout, void *stream);
+int idiff_conv2d_winograd_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
+                              const idiff_epilogue *ep, void *stream);
+int idiff_conv2d_winograd_colstats_split(int B, int H, int W, int Cin, int Cout);
+
 /* ------------------------------------------------------------------ normalisation / pointwise (HBM-bound) */
 
 /* GroupNorm statistics over NHWC x [B, HW, C] with G groups: stats[b, g] = {mean, rstd}, biased variance,

@@ -179,6 +179,71 @@ def test_conv2d_nhwc_vs_cpu(B, H, W, Cin, Cout, k, stride, pad, pad_hi):
     assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 32, 32, 128, 128), (5, 16, 16, 256, 64), (7, 8, 8, 64, 128),
+                                              (9, 4, 4, 32, 64), (2, 6, 10, 8, 64), (1, 2, 2, 16, 64), (33, 4, 4, 8, 64)])
+def test_conv2d_winograd_vs_cpu(B, H, W, Cin, Cout):
+    """F(2x2, 3x3) conv against the fp64 CPU convolution, with every epilogue term (per-sample bias, activation,
+    residual, scales); tile counts that do not fill a workgroup, maps smaller than a workgroup's 64 tiles."""
+    g = torch.Generator().manual_seed(B * H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    temb = torch.randn(B, Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    rsc = torch.rand(B, generator=g) + 0.5
+    assert _lib.conv2d_winograd_ok(B, H, W, Cin, Cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wt = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    u = _lib.winograd_pack(wt, Cin, Cout)
+    out = torch.empty(B, H, W, Cout, device=DEV)
+    _lib.conv2d_winograd(xd, u, out, B, H, W, Cin, Cout, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 3e-6
+    direct = torch.empty_like(out)
+    _lib.conv2d_nhwc(xd, wt, direct, B, H, W, Cin, Cout, 3, 3, 1, 1, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
+    assert rel_err(out.cpu(), direct.double().cpu()) < 3e-6
+    resd = res.permute(0, 2, 3, 1).contiguous().to(DEV)
+    _lib.conv2d_winograd(xd, u, out, B, H, W, Cin, Cout,
+                         epilogue=_lib.make_epilogue(bias=b.to(DEV), rowbias=temb.to(DEV), rows_per_group=H * W, act="silu",
+                                                     residual=resd, out_scale=0.7071, rowscale=rsc.to(DEV)))
+    ref2 = (F.silu(ref + temb.double()[:, :, None, None]) + res.double()) * 0.7071 * rsc.double()[:, None, None, None]
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref2) < 3e-6
+
+
+def test_conv2d_winograd_rejects_what_it_cannot_take():
+    assert not _lib.conv2d_winograd_ok(2, 7, 8, 32, 64)      # odd height
+    assert not _lib.conv2d_winograd_ok(2, 8, 8, 4, 64)       # Cin % 8
+    assert not _lib.conv2d_winograd_ok(2, 8, 8, 32, 3)       # Cout % 64
+    x = torch.zeros(2, 7, 8, 32, device=DEV)
+    with pytest.raises(RuntimeError, match="not supported"):
+        _lib.conv2d_winograd(x, torch.zeros(16 * 32 * 64, device=DEV), torch.zeros(2, 7, 8, 64, device=DEV), 2, 7, 8, 32, 64)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(3, 32, 64, 128), (6, 16, 128, 64)])
+def test_winograd_colstats_feed_groupnorm(B, H, Cin, Cout):
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, H * H, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    ns = _lib.conv2d_winograd_colstats_split(B, H, H, Cin, Cout)
+    assert ns == H * H // 256
+    cs = torch.empty(B * ns * Cout * 2, device=DEV, dtype=torch.float64)
+    out = torch.empty(B, H * H, Cout, device=DEV)
+    _lib.conv2d_winograd(x, _lib.winograd_pack(w, Cin, Cout), out, B, H, H, Cin, Cout,
+                         epilogue=_lib.make_epilogue(bias=bias, act="silu", rows_per_group=H * H, colstats=cs))
+    G = 32
+    st_a, st_b = torch.empty(B * G * 2, device=DEV), torch.empty(B * G * 2, device=DEV)
+    _lib.groupnorm_finalize(cs, ns, Cout, None, 0, 0, B, H * H, G, 1e-6, st_a)
+    nsp = _lib.groupnorm_nsplit(B, H * H, Cout)
+    ws = torch.empty(B * nsp * Cout * 2, device=DEV, dtype=torch.float64)
+    _lib.groupnorm_stats(out, Cout, None, 0, B, H * H, G, 1e-6, ws, st_b)
+    torch.testing.assert_close(st_a, st_b, rtol=1e-6, atol=1e-7)
+    tot = cs.view(B, ns, Cout, 2).sum(1)
+    np.testing.assert_allclose(tot[..., 0].cpu().numpy(), out.double().sum(1).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(tot[..., 1].cpu().numpy(), (out.double() ** 2).sum(1).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    assert _lib.conv2d_winograd_colstats_split(64, 8, 8, Cin, Cout) == 0     # 16 tiles per sample < one workgroup
+
+
 def test_operands_beyond_4gib_are_split_on_the_host():
     """The fast kernel addresses operands through 32-bit-offset buffer descriptors; larger problems are cut into
     row / image ranges (igemm.hip: shift_epilogue).  Checked on the rows / images around the cut."""
