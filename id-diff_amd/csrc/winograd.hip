@@ -77,7 +77,10 @@ winograd_kernel(const WinoParams p) {
   }
   const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
   const int tile0 = tile_m * WG_TILES, n0 = tile_n * WG_COUT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index in an SGPR: roles, operand halves and buffer descriptors stay provably wave-uniform (no waterfall
+  // loops around the buffer loads, scalar branches for the role split)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ph = wave & 1, tb = (wave >> 1) & 1, cb = wave >> 2;
 
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);

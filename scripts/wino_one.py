@@ -1,0 +1,18 @@
+"""One Winograd conv shape, a few launches (for rocprofv3 --pmc runs): wino_one.py H Cin Cout [B]."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import id_diff_amd
+from id_diff_amd import _lib
+H, Cin, Cout = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 2240
+dev = torch.device("cuda:0")
+x = torch.randn(B, H * H, Cin, device=dev)
+w = torch.randn(Cout, 3, 3, Cin, device=dev) / (9 * Cin) ** 0.5
+u = _lib.winograd_pack(w, Cin, Cout)
+o = torch.empty(B, H * H, Cout, device=dev)
+ep = _lib.make_epilogue(bias=torch.randn(Cout, device=dev))
+for _ in range(4):
+    _lib.conv2d_winograd(x, u, o, B, H, H, Cin, Cout, epilogue=ep)
+torch.cuda.synchronize()
+print("done", flush=True)
