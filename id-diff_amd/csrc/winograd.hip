@@ -37,9 +37,13 @@ constexpr int WG_TILES = 64;
 constexpr int WG_COUT = 64;
 constexpr int KC = 8;
 constexpr int NPOS = 16;
-constexpr int OPER_FLOATS = NPOS * 64 * KC;       // one operand of one stage: 8192 floats = 32 KB
-constexpr int STAGE_FLOATS = 2 * OPER_FLOATS;     // V then U
-constexpr size_t LDS_BYTES = (size_t)2 * STAGE_FLOATS * sizeof(float);   // 128 KB
+constexpr int OPER_FLOATS = NPOS * 64 * KC;       // one operand of one stage in HBM order: 8192 floats = 32 KB
+constexpr int V_SLOT = 64 * KC + 8;               // LDS floats per position slot of V: 32 bytes of padding rotate the
+                                                  // banks so that the four patch rows of a unit store conflict-free
+constexpr int U_SLOT = 64 * KC;
+constexpr int V_FLOATS = NPOS * V_SLOT;           // 8320
+constexpr int STAGE_FLOATS = V_FLOATS + NPOS * U_SLOT;   // V then U: 16512 floats
+constexpr size_t LDS_BYTES = (size_t)2 * STAGE_FLOATS * sizeof(float);   // 129 KB
 constexpr int64_t X_LIMIT = 0xFFFF0000ll;          // one buffer descriptor, with room for the invalid-pixel bias
 constexpr uint32_t INVALID_PIXEL = 0xFFFF8000u;    // + channel offset (< 32 KB) stays beyond any valid extent
 
@@ -61,8 +65,106 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t b
 }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float ror8(float v) {   // value of the lane 8 away inside the 16-lane DPP row
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+__device__ __forceinline__ float qperm(float v) {   // DPP quad_perm:[2,2,1,1]: lanes 0,1 of a quad read lane 2, lanes 2,3 read lane 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xf, 0xf, true));
+}
+
+struct TailCtx { int tile0, tile_m, n0, tb, cb, lane, tid; };
+
+// Inverse transform + fused epilogue for the wave of position half PH (rows {2PH, 2PH+1} of the transform domain):
+//   t0j = m0j + m1j + m2j, t1j = m1j - m2j - m3j;  Y[a][0] = ta0 + ta1 + ta2, Y[a][1] = ta1 - ta2 - ta3
+// acc[j] holds row 2PH, acc[4+j] row 2PH+1.  The wave finishes accumulator registers 8PH..8PH+7 (two runs of four
+// consecutive tiles) and hands its partial sums for the other eight to the partner wave through LDS.  PH is a
+// template parameter so that every accumulator index is a compile-time constant.
+template <int PH>
+__device__ __forceinline__ void winograd_tail(const WinoParams &p, floatx16 (&acc)[8], float *lds, const TailCtx &c) {
+  auto partial = [&](int reg) -> float4 {
+    float t0[4], t1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ma = acc[j][reg], mb = acc[4 + j][reg];
+      if (PH == 0) { t0[j] = ma + mb; t1[j] = mb; }
+      else { t0[j] = ma; t1[j] = -ma - mb; }
+    }
+    return make_float4(t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3], t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]);
+  };
+  float4 *xch = reinterpret_cast<float4 *>(lds);          // [pair 4][dst half 2][8][64 lanes] float4 = 64 KB
+  const int pair = c.tb + 2 * c.cb;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    xch[((pair * 2 + (1 - PH)) * 8 + k) * 64 + c.lane] = partial(8 * (1 - PH) + k);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+
+  const idiff_epilogue &ep = p.ep;
+  const bool want_stats = p.has_ep && ep.colstats != nullptr;
+  const int n = c.n0 + c.cb * 32 + (c.lane & 31);
+  const float bias = (p.has_ep && ep.bias) ? ep.bias[n] : 0.f;
+  const bool per_image = p.ep.rows_per_group == p.H * p.W;   // the usual per-sample bias / scale: group = image
+  const int tiles_y = p.tiles_per_img / p.tiles_x;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int run = 0; run < 2; ++run) {
+    // tiles of registers 8PH + 4run + (0..3): consecutive, starting at
+    int T = c.tile0 + c.tb * 32 + 16 * PH + 8 * run + 4 * (c.lane >> 5);
+    int img = T / p.tiles_per_img;
+    int rem = T - img * p.tiles_per_img;
+    int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 4 * run + kk;
+      float4 y = partial(8 * PH + k);
+      const float4 z = xch[((pair * 2 + PH) * 8 + k) * 64 + c.lane];
+      const float yv[4] = {y.x + z.x, y.y + z.y, y.z + z.z, y.w + z.w};
+      if (T < p.total_tiles) {
+        const int64_t m00 = ((int64_t)img * p.H + 2 * ty) * p.W + 2 * tx;
+        float rb = 0.f, rs = 1.f;
+        if (p.has_ep && per_image) {
+          if (ep.rowbias) rb = ep.rowbias[(int64_t)img * ep.ld_rowbias + n];
+          if (ep.rowscale) rs = ep.rowscale[img];
+        }
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+          const int64_t m = m00 + (ab >> 1) * p.W + (ab & 1);
+          float v = yv[ab] + bias;
+          if (p.has_ep) {
+            if (!per_image) {
+              const int64_t g = m / ep.rows_per_group;
+              rb = ep.rowbias ? ep.rowbias[g * ep.ld_rowbias + n] : 0.f;
+              rs = ep.rowscale ? ep.rowscale[g] : 1.f;
+            }
+            v = idiff::act_apply(v + rb, ep.act);
+            if (ep.residual) v += ep.residual[m * ep.ld_residual + n];
+            v *= ep.out_scale;
+            v *= rs;
+          }
+          p.out[m * p.Cout + n] = v;
+          if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ++T;
+      if (++tx == p.tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++img; } }
+    }
+  }
+  if (want_stats) {
+    double *red = reinterpret_cast<double *>(lds + 16384);   // behind the 64 KB exchange area: [4][64][2]
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (c.lane < 32) {
+      const int slot = ((c.tb * 2 + PH) * WG_COUT + c.cb * 32 + c.lane) * 2;
+      red[slot] = s1; red[slot + 1] = s2;
+    }
+    __syncthreads();
+    if (c.tid < WG_COUT) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += red[(w * WG_COUT + c.tid) * 2]; b += red[(w * WG_COUT + c.tid) * 2 + 1]; }
+      double *dst = ep.colstats + ((int64_t)c.tile_m * p.Cout + c.n0 + c.tid) * 2;
+      dst[0] = a; dst[1] = b;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(512)
@@ -86,76 +188,73 @@ winograd_kernel(const WinoParams p) {
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
 
-  // ---------------------------------------------------------------- loader state (role is uniform per wave)
-  const bool v_role = wave < 4;
-  uint32_t src_off[8];      // V: byte offsets of 2 patch rows x 4 columns (outer row first); U: float4 slots
-  int v_dst = 0, pos_outer = 0, pos_inner = 0;
-  float sgn = 1.f;
-  if (v_role) {
-    const int tt = tid & 3, q = (tid >> 2) & 1, half = (tid >> 3) & 1, g = tid >> 4;
-    const int tl = g * 4 + tt;
+  // ---------------------------------------------------------------- loader state
+  // Every thread owns one row r of the 4x4 patch of one (tile, 4-channel quad) unit -- 64 tiles x 2 quads x 4 rows = 512
+  // threads -- plus four 16-byte pieces of the U slab.  The four rows of a unit sit in the four lanes of a DPP quad:
+  // the column mixing of B^T d B is local, the row mixing needs one other row (rows 0,1 <- row 2; rows 2,3 <- row 1),
+  // fetched with quad_perm:[2,2,1,1] and folded in with one fma by the lane's sign (-1, +1, -1, -1).  That yields row 3
+  // negated; the packed U carries the same sign on its row 3, so the products are unchanged.
+  // Transform-domain position (i, j) lives in LDS slot 4j + i (and U is packed in that order).
+  const bool early = wave < 4;    // waves w and w+4 share a SIMD: one transforms while the other feeds the matrix pipe
+  uint32_t v_src[4];
+  int v_dst;
+  float sgn;
+  {
+    const int r = tid & 3, q = (tid >> 2) & 1, tl = tid >> 3;
     const int T = tile0 + tl;
     const bool tv = T < p.total_tiles;
     const int TT = tv ? T : 0;
     const int img = TT / p.tiles_per_img, rem = TT - img * p.tiles_per_img;
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-    const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-    const int r_outer = half ? 3 : 0, r_inner = half ? 2 : 1;
+    const int y = 2 * ty - 1 + r, x0 = 2 * tx - 1;
+    const bool yok = tv && y >= 0 && y < p.H;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int xx = x0 + j;
-      const bool xok = tv && xx >= 0 && xx < p.W;
-      const int yo = y0 + r_outer, yi = y0 + r_inner;
-      src_off[j] = (xok && yo >= 0 && yo < p.H) ? (uint32_t)(((img * p.H + yo) * p.W + xx) * p.Cin + q * 4) * 4u : INVALID_PIXEL;
-      src_off[4 + j] = (xok && yi >= 0 && yi < p.H) ? (uint32_t)(((img * p.H + yi) * p.W + xx) * p.Cin + q * 4) * 4u : INVALID_PIXEL;
+      v_src[j] = (yok && xx >= 0 && xx < p.W) ? (uint32_t)(((img * p.H + y) * p.W + xx) * p.Cin + q * 4) * 4u : INVALID_PIXEL;
     }
-    v_dst = tl * KC + 4 * (q ^ ((tl >> 3) & 1));
-    pos_outer = half ? 12 : 0;   // transform-domain row 3 / 0
-    pos_inner = half ? 8 : 4;    // transform-domain row 2 / 1
-    sgn = half ? -1.f : 1.f;
-  } else {
-    const int u_idx = tid - 256;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) src_off[i] = (uint32_t)(u_idx + 256 * i) * 16u;
+    v_dst = r * V_SLOT + tl * KC + 4 * (q ^ ((tl >> 3) & 1));
+    sgn = (r == 1) ? 1.f : -1.f;
   }
 
-  float4 ld[8];
+  float4 ldv[4], ldu[4];
   const int nsteps = p.Cin / KC;
   int f_step = 0;
+  uint32_t u_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u_src[i] = (uint32_t)tid * 16u + (uint32_t)i * 8192u;
+  // the per-step offsets are wave-uniform: they ride in the buffer instruction's scalar offset (not part of the range
+  // check of a raw buffer, so an out-of-range pixel stays out of range) instead of costing a VALU add per load
   auto fetch = [&]() {
-    if (v_role) {
-      const uint32_t choff = (uint32_t)f_step * (KC * 4u);
+    const int choff = f_step * (KC * 4);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) ld[i] = buf_load4(rX, src_off[i] + choff);
-    } else {
-      const uint32_t slab = (uint32_t)(f_step * p.tiles_n + tile_n) * (uint32_t)(OPER_FLOATS * 4);
+    for (int j = 0; j < 4; ++j) ldv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)v_src[j], choff, 0));
+    const int slab = (f_step * p.tiles_n + tile_n) * (OPER_FLOATS * 4);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) ld[i] = buf_load4(rU, slab + src_off[i]);
-    }
+    for (int i = 0; i < 4; ++i) ldu[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[i], slab, 0));
     ++f_step;
   };
 
   auto stage = [&](int buf) {
-    float *Vd = lds + buf * STAGE_FLOATS;
-    if (v_role) {
-      // column mixing of B^T d B inside each of this lane's two patch rows
-      float4 o[4], n[4];
-      o[0] = f4sub(ld[0], ld[2]); o[1] = f4add(ld[1], ld[2]); o[2] = f4sub(ld[2], ld[1]); o[3] = f4sub(ld[1], ld[3]);
-      n[0] = f4sub(ld[4], ld[6]); n[1] = f4add(ld[5], ld[6]); n[2] = f4sub(ld[6], ld[5]); n[3] = f4sub(ld[5], ld[7]);
+    float *Vd = lds + buf * STAGE_FLOATS + v_dst;
+    float4 c[4];
+    c[0] = f4sub(ldv[0], ldv[2]); c[1] = f4add(ldv[1], ldv[2]); c[2] = f4sub(ldv[2], ldv[1]); c[3] = f4sub(ldv[1], ldv[3]);
+    // c += sgn * quad_perm[2,2,1,1](c), the permute folded into the fma's DPP operand (hipcc keeps v_mov_b32_dpp + v_fmac
+    // apart).  s_nop 1: a VALU write of a VGPR needs two wait states before a DPP read of it, and the hazard
+    // recogniser does not look inside inline asm.
+#define IDIFF_QFMA(x) "v_fmac_f32_dpp " x ", " x ", %16 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    asm volatile("s_nop 1\n" IDIFF_QFMA("%0") IDIFF_QFMA("%1") IDIFF_QFMA("%2") IDIFF_QFMA("%3") IDIFF_QFMA("%4") IDIFF_QFMA("%5")
+                 IDIFF_QFMA("%6") IDIFF_QFMA("%7") IDIFF_QFMA("%8") IDIFF_QFMA("%9") IDIFF_QFMA("%10") IDIFF_QFMA("%11")
+                 IDIFF_QFMA("%12") IDIFF_QFMA("%13") IDIFF_QFMA("%14") IDIFF_QFMA("%15")
+                 : "+v"(c[0].x), "+v"(c[0].y), "+v"(c[0].z), "+v"(c[0].w), "+v"(c[1].x), "+v"(c[1].y), "+v"(c[1].z), "+v"(c[1].w),
+                   "+v"(c[2].x), "+v"(c[2].y), "+v"(c[2].z), "+v"(c[2].w), "+v"(c[3].x), "+v"(c[3].y), "+v"(c[3].z), "+v"(c[3].w)
+                 : "v"(sgn));
+#undef IDIFF_QFMA
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // row mixing: rows (0,1) live in one lane, rows (3,2) in its partner; each needs the partner's inner row
-        const float4 r = make_float4(ror8(n[j].x), ror8(n[j].y), ror8(n[j].z), ror8(n[j].w));
-        const float4 a = make_float4(sgn * (o[j].x - r.x), sgn * (o[j].y - r.y), sgn * (o[j].z - r.z), sgn * (o[j].w - r.w));
-        const float4 b = make_float4(n[j].x + sgn * r.x, n[j].y + sgn * r.y, n[j].z + sgn * r.z, n[j].w + sgn * r.w);
-        *reinterpret_cast<float4 *>(Vd + (pos_outer + j) * (64 * KC) + v_dst) = a;
-        *reinterpret_cast<float4 *>(Vd + (pos_inner + j) * (64 * KC) + v_dst) = b;
-      }
-    } else {
-      float *Ud = Vd + OPER_FLOATS + (tid - 256) * 4;
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(Vd + j * 4 * V_SLOT) = c[j];
+    float *Ud = lds + buf * STAGE_FLOATS + V_FLOATS + tid * 4;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(Ud + i * 1024) = ld[i];
-    }
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(Ud + i * 2048) = ldu[i];
   };
 
   floatx16 acc[8];
@@ -166,15 +265,16 @@ winograd_kernel(const WinoParams p) {
 
   const int fr = lane & 31, fh = lane >> 5;
   const int frag = fr * KC + 4 * (fh ^ ((fr >> 3) & 1));
-  const int a_frag = (ph * 8 * 64 + tb * 32) * KC + frag;
-  const int b_frag = OPER_FLOATS + (ph * 8 * 64 + cb * 32) * KC + frag;
+  const int a_frag = 2 * ph * V_SLOT + tb * 32 * KC + frag;             // slot of accumulator pp: 4 (pp & 3) + 2 ph + (pp >> 2)
+  const int b_frag = V_FLOATS + 2 * ph * U_SLOT + cb * 32 * KC + frag;
 
   auto compute = [&](int buf, int pp0) {
     const float *S = lds + buf * STAGE_FLOATS;
 #pragma unroll
     for (int pp = pp0; pp < pp0 + 4; ++pp) {
-      const float4 a = *reinterpret_cast<const float4 *>(S + a_frag + pp * (64 * KC));
-      const float4 b = *reinterpret_cast<const float4 *>(S + b_frag + pp * (64 * KC));
+      const int slot = 4 * (pp & 3) + (pp >> 2);
+      const float4 a = *reinterpret_cast<const float4 *>(S + a_frag + slot * V_SLOT);
+      const float4 b = *reinterpret_cast<const float4 *>(S + b_frag + slot * U_SLOT);
       acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[pp], 0, 0, 0);
       acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[pp], 0, 0, 0);
       acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[pp], 0, 0, 0);
@@ -189,96 +289,27 @@ winograd_kernel(const WinoParams p) {
 
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
+    // fp32 MFMAs and VALU work share the SIMD's fp32 lanes, and a wave's transform instructions trickle out slowly
+    // beside another wave's MFMA stream; so per SIMD one wave stages step s+1 at the START of step s under its
+    // partner's 32 MFMAs, the partner at the END under the first wave's MFMAs -- the pipe never waits for a transform
+    if (early) {
+      if (s + 1 < nsteps) stage(buf ^ 1);   // loaded one step ago
+      if (s + 2 < nsteps) fetch();
+    }
     compute(buf, 0);
-    if (s + 1 < nsteps) stage(buf ^ 1);   // step s+1: loaded one step ago
-    if (s + 2 < nsteps) fetch();          // step s+2: lands during the rest of this step and the next one's first half
+    __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of the two halves from being hoisted together
     compute(buf, 4);
+    if (!early) {
+      if (s + 1 < nsteps) stage(buf ^ 1);
+      if (s + 2 < nsteps) fetch();
+    }
     __syncthreads();
   }
 
-  // ---------------------------------------------------------------- inverse transform, halves exchanged through LDS
-  // this wave holds m[i][j] for i in {2ph, 2ph+1}: acc[j] (first row), acc[4+j] (second row).
-  //   t0j = m0j + m1j + m2j, t1j = m1j - m2j - m3j;  Y[a][0] = ta0 + ta1 + ta2, Y[a][1] = ta1 - ta2 - ta3
-  // Register indices must be compile-time constants: both 8-register halves are formed with static indices and
-  // the wave-uniform `ph` picks which one this wave finishes (`mine`) and which one it hands over (`other`).
-  auto partial = [&](const float (&ma)[4], const float (&mb)[4]) -> float4 {
-    float t0[4], t1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (ph == 0) { t0[j] = ma[j] + mb[j]; t1[j] = mb[j]; }
-      else { t0[j] = ma[j]; t1[j] = -ma[j] - mb[j]; }
-    }
-    return make_float4(t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3], t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]);
-  };
-  auto gather = [&](int k, bool own, float (&ma)[4], float (&mb)[4]) {
-    const bool hi = own ? (ph == 1) : (ph == 0);   // registers 8..15 belong to the ph = 1 wave
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ma[j] = hi ? acc[j][8 + k] : acc[j][k];
-      mb[j] = hi ? acc[4 + j][8 + k] : acc[4 + j][k];
-    }
-  };
-  float4 *xch = reinterpret_cast<float4 *>(lds);          // [pair 4][dst half 2][8][64 lanes] float4 = 64 KB
-  const int pair = tb + 2 * cb;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float ma[4], mb[4];
-    gather(k, false, ma, mb);                              // registers the partner wave finishes
-    xch[((pair * 2 + (1 - ph)) * 8 + k) * 64 + lane] = partial(ma, mb);
-  }
-  __syncthreads();
-
-  const idiff_epilogue &ep = p.ep;
-  const bool want_stats = p.has_ep && ep.colstats != nullptr;
-  const int n = n0 + cb * 32 + (lane & 31);
-  const float bias = (p.has_ep && ep.bias) ? ep.bias[n] : 0.f;
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int reg = 8 * ph + k;
-    float ma[4], mb[4];
-    gather(k, true, ma, mb);
-    float4 y = partial(ma, mb);
-    const float4 z = xch[((pair * 2 + ph) * 8 + k) * 64 + lane];
-    y = f4add(y, z);
-    const int tl = tb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    const int T = tile0 + tl;
-    if (T >= p.total_tiles) continue;
-    const int img = T / p.tiles_per_img, rem = T - img * p.tiles_per_img;
-    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-    const float yv[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-    for (int ab = 0; ab < 4; ++ab) {
-      const int64_t m = ((int64_t)img * p.H + 2 * ty + (ab >> 1)) * p.W + 2 * tx + (ab & 1);
-      float v = yv[ab] + bias;
-      if (p.has_ep) {
-        if (ep.rowbias) v += ep.rowbias[(m / ep.rows_per_group) * ep.ld_rowbias + n];
-        v = idiff::act_apply(v, ep.act);
-        if (ep.residual) v += ep.residual[m * ep.ld_residual + n];
-        v *= ep.out_scale;
-        if (ep.rowscale) v *= ep.rowscale[m / ep.rows_per_group];
-      }
-      p.out[m * p.Cout + n] = v;
-      if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
-    }
-  }
-  if (want_stats) {
-    double *red = reinterpret_cast<double *>(lds + 16384);   // behind the 64 KB exchange area: [4][64][2]
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    if (lane < 32) {
-      const int slot = ((tb * 2 + ph) * WG_COUT + cb * 32 + lane) * 2;
-      red[slot] = s1; red[slot + 1] = s2;
-    }
-    __syncthreads();
-    if (tid < WG_COUT) {
-      double a = 0.0, b = 0.0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[(w * WG_COUT + tid) * 2]; b += red[(w * WG_COUT + tid) * 2 + 1]; }
-      double *dst = ep.colstats + ((int64_t)tile_m * p.Cout + n0 + tid) * 2;
-      dst[0] = a; dst[1] = b;
-    }
-  }
+  TailCtx c;
+  c.tile0 = tile0; c.tile_m = tile_m; c.n0 = n0; c.tb = tb; c.cb = cb; c.lane = lane; c.tid = tid;
+  if (ph == 0) winograd_tail<0>(p, acc, lds, c);
+  else winograd_tail<1>(p, acc, lds, c);
 }
 
 // U = G g G^T in fp64, rounded once; g[ky][kx] = wt[cout][ky][kx][cin] (the K-contiguous panel of the direct kernel).
@@ -302,7 +333,8 @@ __global__ void winograd_pack_kernel(const float *wt, float *u, int Cin, int Cou
     for (int i = 0; i < 4; ++i) {
       const double r0 = gg[i][0], r1 = gg[i][1], r2 = gg[i][2];
       const double v[4] = {r0, 0.5 * (r0 + r1 + r2), 0.5 * (r0 - r1 + r2), r2};
-      for (int j = 0; j < 4; ++j) dst[(int64_t)(i * 4 + j) * 64 * KC] = (float)v[j];
+      const double sign = i == 3 ? -1.0 : 1.0;     // the kernel's input transform produces row 3 negated
+      for (int j = 0; j < 4; ++j) dst[(int64_t)(j * 4 + i) * 64 * KC] = (float)(sign * v[j]);
     }
   }
 }
