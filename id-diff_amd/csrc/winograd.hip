@@ -5,26 +5,36 @@
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        d: 4x4 input patch at (2ty-1, 2tx-1), Y: 2x2 outputs at (2ty, 2tx)
 //
-//   U = G g G^T is packed once per layer (idiff_winograd_pack_f32) as [Cin/8][Cout/64][16 positions][64 cout][8 cin].
+//   U = G g G^T is packed once per layer (idiff_winograd_pack_f32) as [Cin/8][Cout/64][16 slots][64 cout][8 cin].
 //   V = B^T d B is formed by the loader on its way from HBM/L2 to LDS and never written to memory.
-//   M_p = V_p U_p^T for the 16 positions p are 16 independent [tiles x Cin] x [Cin x Cout] contractions; a workgroup
-//   owns 64 tiles x 64 output channels of ALL 16 of them, so the inverse transform A^T M A is local to the
-//   workgroup and M never leaves registers either.
+//   M_p = V_p U_p^T for the 16 positions p = (i, j) are 16 independent [tiles x Cin] x [Cin x Cout] contractions; a
+//   workgroup owns 64 tiles x 64 output channels of ALL 16 of them, so the inverse transform A^T M A is local to the
+//   workgroup and M never leaves the CU either.  Position (i, j) lives in slot 4j + i (LDS and packed U alike).
 //
-// Workgroup: 512 threads = 8 waves = 2 (position halves: rows {0,1} / {2,3} of the 4x4 transform domain)
-//   x 2 (32-tile halves) x 2 (32-channel halves); a wave holds 8 positions x one 32x32 MFMA tile = 128 accumulators.
-// K loop: 8 input channels per step, two LDS stages of [16][64][8] floats for V and for U (128 KB together), one
-//   barrier per step; global loads run two steps ahead in registers, the transform + LDS writes of step s+1 sit
-//   between the two MFMA halves of step s.
+// Cost model this kernel is built on (measured with in-kernel stamps and PMC): a SIMD's time is
+//   64 cycles x (fp32 MFMAs) + ~6.5 cycles x (every other instruction its waves issue) -- fp32 MFMAs run on the
+//   same fp32 lanes as the VALU and nothing overlaps them -- so the design minimises non-MFMA instructions per MFMA.
+//
+// Workgroup: 512 threads = 8 waves = 4 (rows i of the 4x4 transform domain) x 2 (32-tile halves); a wave holds
+//   4 positions (i, 0..3) x [32 tiles x 64 channels] = 8 MFMA tiles = 128 accumulators, and per 8-channel step issues
+//   32 MFMAs from 4 + 8 sixteen-byte LDS reads (each lane half feeds four consecutive channels to four successive
+//   MFMAs, the order of the k-reduction being free; one V fragment serves both 32-channel halves).
+// K loop: 8 input channels per step, two LDS stages (V: 16 slots x [64 tiles][8] + 32 bytes of padding per slot, U: 16 x
+//   [64 cout][8]; 129 KB together), one barrier per step, global loads two steps ahead in registers.
+// Loader: every thread owns row r of the 4x4 patch of one (tile, 4-channel quad) unit -- 64 x 2 x 4 = 512 -- plus four
+//   16-byte pieces of the pre-swizzled U slab (LDS image = HBM image).  The four rows of a unit are the four lanes of a
+//   DPP quad: column mixing is local (16 VALU), row mixing is one v_fmac_f32_dpp per value (quad_perm:[2,2,1,1], signs
+//   -1,+1,-1,-1; row 3 comes out negated and the packed U carries the same sign).  Per-step address offsets ride in the
+//   buffer instructions' scalar offset.  Waves w and w+4 share a SIMD: one transforms at the start of a step, the other
+//   at the end, so the matrix pipe always has the partner's MFMAs.
 // LDS rows are 32 bytes (8 channels); the two 16-byte halves of row r are swapped when bit 3 of r is set, which
-//   makes the ds_read_b128 of a 32-row MFMA operand conflict-free (lane groups of ds_read_b128:
-//   MI355X_MICROARCH.md section LDS).  As in igemm.hip each lane half feeds four consecutive channels to four
-//   successive MFMAs (the order of the k-reduction is free), one 16-byte read per operand per 4 MFMAs.
-// Loader roles are per wave: waves 0-3 gather and transform V (a lane pair 8 lanes apart shares one (tile,
-//   4-channel) unit: each loads two rows of the 4x4 patch, mixes columns locally and swaps one row through DPP
-//   row_ror:8 for the row mixing), waves 4-7 copy the pre-swizzled U slab (fully coalesced, LDS image = HBM image).
-// Epilogue: partial A^T M A per position half, halves exchanged through LDS, then the same fused epilogue as
-//   igemm.hip (bias, per-sample bias, activation, residual, scales, optional per-tile column statistics).
+//   makes the ds_read_b128 of a 32-row MFMA operand conflict-free, and the V slot pitch of 520 floats makes the four
+//   rows' ds_write_b128 conflict-free (lane groups per instruction: MI355X_MICROARCH.md section LDS).
+// Tail: each wave mixes its row over j (z_ib), the four rows meet in LDS ([4 rows][64 tiles][2][64 cout], 128 KB over
+//   the dead stage buffers), and every thread finishes float4 runs of 4 channels: Y[0][b] = z0b + z1b + z2b,
+//   Y[1][b] = z1b - z2b - z3b, fused epilogue (bias, per-sample bias, activation, residual, scales, optional per-tile
+//   column statistics), 16-byte stores -- the one-dword-per-lane store tail of the first version was store-issue bound
+//   (29.8k of 131k cycles per workgroup at Cin = 128).
 #include "common.h"
 #include <stdlib.h>
 
@@ -38,14 +48,13 @@ constexpr int WG_COUT = 64;
 constexpr int KC = 8;
 constexpr int NPOS = 16;
 constexpr int OPER_FLOATS = NPOS * 64 * KC;       // one operand of one stage in HBM order: 8192 floats = 32 KB
-constexpr int V_SLOT = 64 * KC + 8;               // LDS floats per position slot of V: 32 bytes of padding rotate the
-                                                  // banks so that the four patch rows of a unit store conflict-free
+constexpr int V_SLOT = 64 * KC + 8;               // LDS floats per position slot of V (see above)
 constexpr int U_SLOT = 64 * KC;
 constexpr int V_FLOATS = NPOS * V_SLOT;           // 8320
 constexpr int STAGE_FLOATS = V_FLOATS + NPOS * U_SLOT;   // V then U: 16512 floats
 constexpr size_t LDS_BYTES = (size_t)2 * STAGE_FLOATS * sizeof(float);   // 129 KB
 constexpr int64_t X_LIMIT = 0xFFFF0000ll;          // one buffer descriptor, with room for the invalid-pixel bias
-constexpr uint32_t INVALID_PIXEL = 0xFFFF8000u;    // + channel offset (< 32 KB) stays beyond any valid extent
+constexpr uint32_t INVALID_PIXEL = 0xFFFF8000u;    // beyond any valid extent (the scalar step offset is not range-checked)
 
 struct WinoParams {
   const float *x;
@@ -59,113 +68,8 @@ struct WinoParams {
   int has_ep;
 };
 
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
-  const uintx4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
-  return __builtin_bit_cast(float4, v);
-}
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float qperm(float v) {   // DPP quad_perm:[2,2,1,1]: lanes 0,1 of a quad read lane 2, lanes 2,3 read lane 1
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xf, 0xf, true));
-}
-
-struct TailCtx { int tile0, tile_m, n0, tb, cb, lane, tid; };
-
-// Inverse transform + fused epilogue for the wave of position half PH (rows {2PH, 2PH+1} of the transform domain):
-//   t0j = m0j + m1j + m2j, t1j = m1j - m2j - m3j;  Y[a][0] = ta0 + ta1 + ta2, Y[a][1] = ta1 - ta2 - ta3
-// acc[j] holds row 2PH, acc[4+j] row 2PH+1.  The wave finishes accumulator registers 8PH..8PH+7 (two runs of four
-// consecutive tiles) and hands its partial sums for the other eight to the partner wave through LDS.  PH is a
-// template parameter so that every accumulator index is a compile-time constant.
-template <int PH>
-__device__ __forceinline__ void winograd_tail(const WinoParams &p, floatx16 (&acc)[8], float *lds, const TailCtx &c) {
-  auto partial = [&](int reg) -> float4 {
-    float t0[4], t1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float ma = acc[j][reg], mb = acc[4 + j][reg];
-      if (PH == 0) { t0[j] = ma + mb; t1[j] = mb; }
-      else { t0[j] = ma; t1[j] = -ma - mb; }
-    }
-    return make_float4(t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3], t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]);
-  };
-  float4 *xch = reinterpret_cast<float4 *>(lds);          // [pair 4][dst half 2][8][64 lanes] float4 = 64 KB
-  const int pair = c.tb + 2 * c.cb;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    xch[((pair * 2 + (1 - PH)) * 8 + k) * 64 + c.lane] = partial(8 * (1 - PH) + k);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __syncthreads();
-
-  const idiff_epilogue &ep = p.ep;
-  const bool want_stats = p.has_ep && ep.colstats != nullptr;
-  const int n = c.n0 + c.cb * 32 + (c.lane & 31);
-  const float bias = (p.has_ep && ep.bias) ? ep.bias[n] : 0.f;
-  const bool per_image = p.ep.rows_per_group == p.H * p.W;   // the usual per-sample bias / scale: group = image
-  const int tiles_y = p.tiles_per_img / p.tiles_x;
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-  for (int run = 0; run < 2; ++run) {
-    // tiles of registers 8PH + 4run + (0..3): consecutive, starting at
-    int T = c.tile0 + c.tb * 32 + 16 * PH + 8 * run + 4 * (c.lane >> 5);
-    int img = T / p.tiles_per_img;
-    int rem = T - img * p.tiles_per_img;
-    int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int k = 4 * run + kk;
-      float4 y = partial(8 * PH + k);
-      const float4 z = xch[((pair * 2 + PH) * 8 + k) * 64 + c.lane];
-      const float yv[4] = {y.x + z.x, y.y + z.y, y.z + z.z, y.w + z.w};
-      if (T < p.total_tiles) {
-        const int64_t m00 = ((int64_t)img * p.H + 2 * ty) * p.W + 2 * tx;
-        float rb = 0.f, rs = 1.f;
-        if (p.has_ep && per_image) {
-          if (ep.rowbias) rb = ep.rowbias[(int64_t)img * ep.ld_rowbias + n];
-          if (ep.rowscale) rs = ep.rowscale[img];
-        }
-#pragma unroll
-        for (int ab = 0; ab < 4; ++ab) {
-          const int64_t m = m00 + (ab >> 1) * p.W + (ab & 1);
-          float v = yv[ab] + bias;
-          if (p.has_ep) {
-            if (!per_image) {
-              const int64_t g = m / ep.rows_per_group;
-              rb = ep.rowbias ? ep.rowbias[g * ep.ld_rowbias + n] : 0.f;
-              rs = ep.rowscale ? ep.rowscale[g] : 1.f;
-            }
-            v = idiff::act_apply(v + rb, ep.act);
-            if (ep.residual) v += ep.residual[m * ep.ld_residual + n];
-            v *= ep.out_scale;
-            v *= rs;
-          }
-          p.out[m * p.Cout + n] = v;
-          if (want_stats) { s1 += (double)v; s2 += (double)v * (double)v; }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      ++T;
-      if (++tx == p.tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++img; } }
-    }
-  }
-  if (want_stats) {
-    double *red = reinterpret_cast<double *>(lds + 16384);   // behind the 64 KB exchange area: [4][64][2]
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    if (c.lane < 32) {
-      const int slot = ((c.tb * 2 + PH) * WG_COUT + c.cb * 32 + c.lane) * 2;
-      red[slot] = s1; red[slot + 1] = s2;
-    }
-    __syncthreads();
-    if (c.tid < WG_COUT) {
-      double a = 0.0, b = 0.0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[(w * WG_COUT + c.tid) * 2]; b += red[(w * WG_COUT + c.tid) * 2 + 1]; }
-      double *dst = ep.colstats + ((int64_t)c.tile_m * p.Cout + c.n0 + c.tid) * 2;
-      dst[0] = a; dst[1] = b;
-    }
-  }
-}
 
 __global__ void __launch_bounds__(512)
 winograd_kernel(const WinoParams p) {
@@ -181,22 +85,16 @@ winograd_kernel(const WinoParams p) {
   const int tile0 = tile_m * WG_TILES, n0 = tile_n * WG_COUT;
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave index in an SGPR: roles, operand halves and buffer descriptors stay provably wave-uniform (no waterfall
-  // loops around the buffer loads, scalar branches for the role split)
+  // loops around the buffer loads, scalar branches)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ph = wave & 1, tb = (wave >> 1) & 1, cb = wave >> 2;
+  const int wi = wave & 3, tb = wave >> 2;   // transform-domain row, 32-tile half
 
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
 
   // ---------------------------------------------------------------- loader state
-  // Every thread owns one row r of the 4x4 patch of one (tile, 4-channel quad) unit -- 64 tiles x 2 quads x 4 rows = 512
-  // threads -- plus four 16-byte pieces of the U slab.  The four rows of a unit sit in the four lanes of a DPP quad:
-  // the column mixing of B^T d B is local, the row mixing needs one other row (rows 0,1 <- row 2; rows 2,3 <- row 1),
-  // fetched with quad_perm:[2,2,1,1] and folded in with one fma by the lane's sign (-1, +1, -1, -1).  That yields row 3
-  // negated; the packed U carries the same sign on its row 3, so the products are unchanged.
-  // Transform-domain position (i, j) lives in LDS slot 4j + i (and U is packed in that order).
   const bool early = wave < 4;    // waves w and w+4 share a SIMD: one transforms while the other feeds the matrix pipe
-  uint32_t v_src[4];
+  uint32_t v_src[4], u_src[4];
   int v_dst;
   float sgn;
   {
@@ -212,6 +110,7 @@ winograd_kernel(const WinoParams p) {
     for (int j = 0; j < 4; ++j) {
       const int xx = x0 + j;
       v_src[j] = (yok && xx >= 0 && xx < p.W) ? (uint32_t)(((img * p.H + y) * p.W + xx) * p.Cin + q * 4) * 4u : INVALID_PIXEL;
+      u_src[j] = (uint32_t)tid * 16u + (uint32_t)j * 8192u;
     }
     v_dst = r * V_SLOT + tl * KC + 4 * (q ^ ((tl >> 3) & 1));
     sgn = (r == 1) ? 1.f : -1.f;
@@ -220,9 +119,6 @@ winograd_kernel(const WinoParams p) {
   float4 ldv[4], ldu[4];
   const int nsteps = p.Cin / KC;
   int f_step = 0;
-  uint32_t u_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) u_src[i] = (uint32_t)tid * 16u + (uint32_t)i * 8192u;
   // the per-step offsets are wave-uniform: they ride in the buffer instruction's scalar offset (not part of the range
   // check of a raw buffer, so an out-of-range pixel stays out of range) instead of costing a VALU add per load
   auto fetch = [&]() {
@@ -257,7 +153,7 @@ winograd_kernel(const WinoParams p) {
     for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(Ud + i * 2048) = ldu[i];
   };
 
-  floatx16 acc[8];
+  floatx16 acc[8];   // [j][channel half]
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -265,20 +161,24 @@ winograd_kernel(const WinoParams p) {
 
   const int fr = lane & 31, fh = lane >> 5;
   const int frag = fr * KC + 4 * (fh ^ ((fr >> 3) & 1));
-  const int a_frag = 2 * ph * V_SLOT + tb * 32 * KC + frag;             // slot of accumulator pp: 4 (pp & 3) + 2 ph + (pp >> 2)
-  const int b_frag = V_FLOATS + 2 * ph * U_SLOT + cb * 32 * KC + frag;
+  const int a_frag = wi * V_SLOT + tb * 32 * KC + frag;       // slot of position (wi, j): 4j + wi
+  const int b_frag = V_FLOATS + wi * U_SLOT + frag;
 
-  auto compute = [&](int buf, int pp0) {
+  auto compute = [&](int buf, int j0) {
     const float *S = lds + buf * STAGE_FLOATS;
 #pragma unroll
-    for (int pp = pp0; pp < pp0 + 4; ++pp) {
-      const int slot = 4 * (pp & 3) + (pp >> 2);
-      const float4 a = *reinterpret_cast<const float4 *>(S + a_frag + slot * V_SLOT);
-      const float4 b = *reinterpret_cast<const float4 *>(S + b_frag + slot * U_SLOT);
-      acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[pp], 0, 0, 0);
-      acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[pp], 0, 0, 0);
-      acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[pp], 0, 0, 0);
-      acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[pp], 0, 0, 0);
+    for (int j = j0; j < j0 + 2; ++j) {
+      const float4 a = *reinterpret_cast<const float4 *>(S + a_frag + 4 * j * V_SLOT);
+      const float4 b0 = *reinterpret_cast<const float4 *>(S + b_frag + 4 * j * U_SLOT);
+      const float4 b1 = *reinterpret_cast<const float4 *>(S + b_frag + 4 * j * U_SLOT + 32 * KC);
+      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[2 * j], 0, 0, 0);
+      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[2 * j + 1], 0, 0, 0);
+      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[2 * j], 0, 0, 0);
+      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[2 * j + 1], 0, 0, 0);
+      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[2 * j], 0, 0, 0);
+      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[2 * j + 1], 0, 0, 0);
+      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[2 * j], 0, 0, 0);
+      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[2 * j + 1], 0, 0, 0);
     }
   };
 
@@ -289,16 +189,13 @@ winograd_kernel(const WinoParams p) {
 
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
-    // fp32 MFMAs and VALU work share the SIMD's fp32 lanes, and a wave's transform instructions trickle out slowly
-    // beside another wave's MFMA stream; so per SIMD one wave stages step s+1 at the START of step s under its
-    // partner's 32 MFMAs, the partner at the END under the first wave's MFMAs -- the pipe never waits for a transform
     if (early) {
       if (s + 1 < nsteps) stage(buf ^ 1);   // loaded one step ago
       if (s + 2 < nsteps) fetch();
     }
     compute(buf, 0);
     __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of the two halves from being hoisted together
-    compute(buf, 4);
+    compute(buf, 2);
     if (!early) {
       if (s + 1 < nsteps) stage(buf ^ 1);
       if (s + 2 < nsteps) fetch();
@@ -306,10 +203,109 @@ winograd_kernel(const WinoParams p) {
     __syncthreads();
   }
 
-  TailCtx c;
-  c.tile0 = tile0; c.tile_m = tile_m; c.n0 = n0; c.tb = tb; c.cb = cb; c.lane = lane; c.tid = tid;
-  if (ph == 0) winograd_tail<0>(p, acc, lds, c);
-  else winograd_tail<1>(p, acc, lds, c);
+  // ---------------------------------------------------------------- tail
+  // z_ib for this wave's row i: z_i0 = m_i0 + m_i1 + m_i2, z_i1 = m_i1 - m_i2 - m_i3 -> LDS [i][tile][b][cout]
+  {
+    float *zp = lds + ((wi * 64 + tb * 32 + 4 * (lane >> 5)) * 2) * 64 + (lane & 31);
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const float m0 = acc[ch][reg], m1 = acc[2 + ch][reg], m2 = acc[4 + ch][reg], m3 = acc[6 + ch][reg];
+        const int trow = (reg & 3) + 8 * (reg >> 2);        // + 4 * (lane >> 5): row of the 32x32 accumulator tile
+        zp[(trow * 2) * 64 + ch * 32] = m0 + m1 + m2;
+        zp[(trow * 2 + 1) * 64 + ch * 32] = m1 - m2 - m3;
+      }
+  }
+  __syncthreads();
+
+  const idiff_epilogue &ep = p.ep;
+  const bool want_stats = p.has_ep && ep.colstats != nullptr;
+  const int cq = tid & 15, g = tid >> 4;                     // 4 channels n0 + 4cq .., items (tile, b) 4g .. 4g+3
+  const int n = n0 + 4 * cq;
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.has_ep && ep.bias) bias = *reinterpret_cast<const float4 *>(ep.bias + n);
+  const bool per_image = p.ep.rows_per_group == p.H * p.W;   // the usual per-sample bias / scale: group = image
+  const int tiles_y = p.tiles_per_img / p.tiles_x;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  int T = tile0 + 2 * g;
+  int img = T / p.tiles_per_img;
+  int rem = T - img * p.tiles_per_img;
+  int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int tl = 2 * g + (it >> 1), b = it & 1;
+    const float *zr = lds + (tl * 2 + b) * 64 + 4 * cq;
+    const float4 z0 = *reinterpret_cast<const float4 *>(zr);
+    const float4 z1 = *reinterpret_cast<const float4 *>(zr + 1 * 64 * 2 * 64);
+    const float4 z2 = *reinterpret_cast<const float4 *>(zr + 2 * 64 * 2 * 64);
+    const float4 z3 = *reinterpret_cast<const float4 *>(zr + 3 * 64 * 2 * 64);
+    if (T < p.total_tiles) {
+      float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
+      float rs = 1.f;
+      if (p.has_ep && per_image) {
+        if (ep.rowbias) rb = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)img * ep.ld_rowbias + n);
+        if (ep.rowscale) rs = ep.rowscale[img];
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int64_t m = ((int64_t)img * p.H + 2 * ty + a) * p.W + 2 * tx + b;
+        float v[4];
+        if (a == 0) { v[0] = z0.x + z1.x + z2.x; v[1] = z0.y + z1.y + z2.y; v[2] = z0.z + z1.z + z2.z; v[3] = z0.w + z1.w + z2.w; }
+        else { v[0] = z1.x - z2.x - z3.x; v[1] = z1.y - z2.y - z3.y; v[2] = z1.z - z2.z - z3.z; v[3] = z1.w - z2.w - z3.w; }
+        v[0] += bias.x; v[1] += bias.y; v[2] += bias.z; v[3] += bias.w;
+        if (p.has_ep) {
+          if (!per_image) {
+            const int64_t grp = m / ep.rows_per_group;
+            rb = ep.rowbias ? *reinterpret_cast<const float4 *>(ep.rowbias + grp * ep.ld_rowbias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rs = ep.rowscale ? ep.rowscale[grp] : 1.f;
+          }
+          v[0] = idiff::act_apply(v[0] + rb.x, ep.act); v[1] = idiff::act_apply(v[1] + rb.y, ep.act);
+          v[2] = idiff::act_apply(v[2] + rb.z, ep.act); v[3] = idiff::act_apply(v[3] + rb.w, ep.act);
+          if (ep.residual) {
+            const float4 res = *reinterpret_cast<const float4 *>(ep.residual + m * ep.ld_residual + n);
+            v[0] += res.x; v[1] += res.y; v[2] += res.z; v[3] += res.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] *= ep.out_scale; v[e] *= rs; }
+        }
+        *reinterpret_cast<float4 *>(p.out + m * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (want_stats) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1[e] += (double)v[e]; s2[e] += (double)v[e] * (double)v[e]; }
+        }
+      }
+    }
+    if (it == 1) {   // next tile
+      ++T;
+      if (++tx == p.tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++img; } }
+    }
+  }
+  if (want_stats) {
+    // lanes l, l+16, l+32, l+48 hold the same four channels; then one slot per (wave, channel)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s1[e] += __shfl_xor(s1[e], 16, 64); s1[e] += __shfl_xor(s1[e], 32, 64);
+      s2[e] += __shfl_xor(s2[e], 16, 64); s2[e] += __shfl_xor(s2[e], 32, 64);
+    }
+    __syncthreads();                                          // every z has been read: the area is free again
+    double *red = reinterpret_cast<double *>(lds);           // [8 waves][64][2]
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[((wave * WG_COUT) + 4 * cq + e) * 2] = s1[e];
+        red[((wave * WG_COUT) + 4 * cq + e) * 2 + 1] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < WG_COUT) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { a += red[(w * WG_COUT + tid) * 2]; b += red[(w * WG_COUT + tid) * 2 + 1]; }
+      double *dst = ep.colstats + ((int64_t)tile_m * p.Cout + n0 + tid) * 2;
+      dst[0] = a; dst[1] = b;
+    }
+  }
 }
 
 // U = G g G^T in fp64, rounded once; g[ky][kx] = wt[cout][ky][kx][cin] (the K-contiguous panel of the direct kernel).
