@@ -47,6 +47,7 @@ struct IgemmParams {
   idiff_epilogue ep;
   int has_ep;
   uint32_t a_bytes, b_bytes;  // extent of one batch slice of A / Bt for the buffer-addressed kernel
+  int vec_ep;                 // epilogue operands allow 16-byte accesses (set by the launcher)
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -283,6 +284,7 @@ int launch_cfg(IgemmParams &p, int batch, hipStream_t st) {
 // takes the general kernel above.
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t OOB = 0xFFFFFFFFu;
+bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
   const uintx4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
@@ -461,6 +463,73 @@ igemm_pipe_kernel(const IgemmParams p) {
   // consumes this tensor then needs no pass of its own over HBM (idiff_epilogue.colstats)
   const bool want_stats = p.has_ep && ep.colstats != nullptr;
   double *red = reinterpret_cast<double *>(lds);   // [WARPS_M][BN][2]; operand staging is finished
+  if (p.vec_ep) {
+    // One dword per lane per store makes short-K contractions store-issue bound (a 128x128 tile is 256 wave-level
+    // stores, ~100 cycles each through the CU's one address unit: 0.8 of the 1.24 ms of the K = 128 shortcut GEMMs).
+    // Each wave turns its 32-row blocks through a private 8 KB LDS patch instead and finishes runs of four columns:
+    // 16-byte loads of bias / residual, 16-byte stores, a quarter of the store instructions.
+    constexpr int C4 = WTN / 4;                      // float4 per row of the wave tile
+    constexpr int RPP = 64 / C4;                     // rows per pass of 64 lanes
+    constexpr int PASSES = 32 / RPP;
+    float *tr = lds + (tid >> 6) * (32 * WTN);
+    const int c4 = lane % C4, r0 = lane / C4;
+    const int n = n0 + wn0 + c4 * 4;
+    const bool n_ok = n < p.N;                       // N % 4 == 0: a run of four is inside or outside as a whole
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n_ok && p.has_ep && ep.bias) bias4 = *reinterpret_cast<const float4 *>(ep.bias + n);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + row_l) * WTN + j * 32 + col_l] = acc[i][j][r];
+#pragma unroll
+      for (int t = 0; t < PASSES; ++t) {
+        const int row = r0 + RPP * t;
+        const float4 a4 = *reinterpret_cast<const float4 *>(tr + row * WTN + c4 * 4);
+        const int m = m0 + wm0 + i * 32 + row;
+        if (m >= p.M || !n_ok) continue;
+        float v[4] = {a4.x + bias4.x, a4.y + bias4.y, a4.z + bias4.z, a4.w + bias4.w};
+        if (p.has_ep) {
+          const int grp = (ep.rowbias || ep.rowscale) ? m / ep.rows_per_group : 0;
+          if (ep.rowbias) {
+            const float4 rb = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)grp * ep.ld_rowbias + n);
+            v[0] += rb.x; v[1] += rb.y; v[2] += rb.z; v[3] += rb.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = idiff::act_apply(v[e], ep.act);
+          if (ep.residual) {
+            const float4 rs = *reinterpret_cast<const float4 *>(ep.residual + (int64_t)m * ep.ld_residual + n);
+            v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+          }
+          const float rsc = ep.rowscale ? ep.rowscale[grp] : 1.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] *= ep.out_scale; if (ep.rowscale) v[e] *= rsc; }
+        }
+        *reinterpret_cast<float4 *>(Cb + (int64_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (want_stats) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1[e] += (double)v[e]; s2[e] += (double)v[e] * (double)v[e]; }
+        }
+      }
+    }
+    if (want_stats) {
+      // lanes sharing c4 hold the same four columns
+#pragma unroll
+      for (int off = C4; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
+      __syncthreads();                               // every wave is done with its patch
+      if (lane < C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int slot = ((wave / WARPS_N) * BN + wn0 + c4 * 4 + e) * 2;
+          red[slot] = s1[e]; red[slot + 1] = s2[e];
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + j * 32 + col_l;
@@ -495,6 +564,7 @@ igemm_pipe_kernel(const IgemmParams p) {
       }
     }
   }
+  }
   if (want_stats) {
     __syncthreads();
     for (int c = tid; c < BN; c += T) {
@@ -524,6 +594,13 @@ int launch_pipe(IgemmParams &p, int batch, hipStream_t st) {
       return (int)e;
     }
     attr_set = true;
+  }
+  {
+    const idiff_epilogue &e = p.ep;
+    const bool al = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.strideC % 4 == 0) && aligned16(p.C) &&
+                    (!p.has_ep || ((!e.bias || aligned16(e.bias)) && (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) &&
+                                   (!e.residual || (aligned16(e.residual) && e.ld_residual % 4 == 0))));
+    p.vec_ep = al && !getenv("IDIFF_SCALAR_EPILOGUE");
   }
   dim3 grid(p.tiles_m * p.tiles_n, batch);
   hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds_bytes, st, p);
@@ -573,8 +650,6 @@ void fill_epilogue(IgemmParams &p, const idiff_epilogue *ep) {
     p.ep.rowscale = nullptr;
   }
 }
-
-bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 // The fast kernel addresses an operand through one 32-bit-offset buffer descriptor (< 4 GiB).  Larger problems
 // are cut into row ranges on the host (rows are independent): this returns the epilogue of the range that

@@ -35,8 +35,10 @@ def d_gemm(a, bt, out=None, epilogue=None, M=None, N=None, K=None, batch=1, **k)
         M, K = a.shape; N = bt.shape[0]
     return (f"b{batch} M{M} N{N} K{K}", 2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N))
 def d_conv(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue=None, pad_hi=None):
-    Ho, Wo = out.shape[1], out.shape[2]
-    return (f"B{B} {H}x{W} {Cin}->{Cout} k{KH} s{stride}", 2.0 * B * Ho * Wo * Cout * Cin * KH * KW,
+    return (f"B{B} {H}x{W} {Cin}->{Cout} k{KH} s{stride}", 2.0 * out.numel() * Cin * KH * KW,
+            4.0 * (B * H * W * Cin + out.numel()))
+def d_wino(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+    return (f"B{B} {H}x{W} {Cin}->{Cout} (F(2x2,3x3); TF = direct-equivalent)", 2.0 * out.numel() * Cin * 9,
             4.0 * (B * H * W * Cin + out.numel()))
 def d_gnapply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None):
     return (f"B{B} HW{HW} C{C}+{C2} act={act}", 0.0, 8.0 * B * HW * (C + C2))
@@ -50,7 +52,7 @@ def d_generic(*a, **k):
     n = sum(4.0 * v.numel() for v in list(a) + list(k.values()) if torch.is_tensor(v))
     return ("", 0.0, n)
 
-wrap("gemm", d_gemm); wrap("conv2d_nhwc", d_conv); wrap("groupnorm_apply", d_gnapply); wrap("groupnorm_stats", d_gnstats)
+wrap("gemm", d_gemm); wrap("conv2d_nhwc", d_conv); wrap("conv2d_winograd", d_wino); wrap("groupnorm_apply", d_gnapply); wrap("groupnorm_stats", d_gnstats)
 wrap("upfirdn2d_raw", d_ufd); wrap("softmax_rows", d_soft)
 for nm in ("groupnorm_finalize", "affine_act", "add_scale", "fourier_embed", "positional_embed", "concat_cols", "nchw_to_nhwc",
            "nhwc_to_nchw", "resample2x_nhwc"):
