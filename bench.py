@@ -34,31 +34,33 @@ WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=
 
 
 class ConvProbe:
-    """HIP events around a sample of the dominant kernel's launches (3x3 implicit-GEMM convs) on the launch stream."""
+    """HIP events around a sample of the dominant kernel's launches (the F(2x2,3x3) Winograd convs of csrc/winograd.hip:
+    71 % of the kernel time of a forward pass) on the launch stream."""
+
+    TRAFFIC = os.path.join("profiles", "r01_wino_traffic.json")
 
     def __init__(self):
         self.active = False
         self.records = []
-        self._orig = _lib.conv2d_nhwc
+        self._orig = _lib.conv2d_winograd
 
     def install(self):
         probe = self
 
-        def timed(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue=None, pad_hi=None):
-            # only launches that dispatch to the dominant 128x128 template (csrc/igemm.hip: dispatch())
-            rows_out = out.numel() // Cout
-            big = Cout > 64 and ((rows_out + 127) // 128) * ((Cout + 127) // 128) >= 1024 and Cin % 32 == 0
-            if not (probe.active and KH == 3 and big):
-                return probe._orig(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue, pad_hi)
+        def timed(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+            if not probe.active:
+                return probe._orig(x, u, out, B, H, W, Cin, Cout, epilogue)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            r = probe._orig(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue, pad_hi)
+            r = probe._orig(x, u, out, B, H, W, Cin, Cout, epilogue)
             b.record()
-            flops = 2.0 * out.numel() * KH * KW * Cin
+            # executed (algorithmic) flops of the Winograd form: 16 positions x [tiles x Cin] x [Cin x Cout] multiply-adds,
+            # tiles = output pixels / 4; the implicit GEMM it replaces would be 2.25x that (9 taps per pixel)
+            flops = 2.0 * 16 * (out.numel() // Cout // 4) * Cin * Cout
             probe.records.append((a, b, flops, f"{B}x{H}x{W}x{Cin}->{Cout}"))
             return r
 
-        _lib.conv2d_nhwc = timed
+        _lib.conv2d_winograd = timed
 
     def summary(self):
         if not self.records:
@@ -70,8 +72,8 @@ class ConvProbe:
 
     def traffic(self):
         """HBM bytes per launch of the sampled shapes, from the committed PMC table (FETCH_SIZE / WRITE_SIZE passes,
-        gfx950 corrections applied; profiles/r01_conv_traffic.json); None if a sampled shape is not in the table."""
-        path = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+        gfx950 corrections applied; profiles/r01_wino_traffic.json); None if a sampled shape is not in the table."""
+        path = os.path.join(ROOT, self.TRAFFIC)
         if not os.path.exists(path):
             return None
         table = json.load(open(path))["shapes"]
@@ -80,7 +82,7 @@ class ConvProbe:
             return None
         return {"bytes_per_launch": sum(table[k]["total_bytes"] for k in keys) / len(keys),
                 "algorithmic_bytes_per_launch": sum(table[k]["algorithmic_bytes"] for k in keys) / len(keys),
-                "source": "profiles/r01_conv_traffic.json"}
+                "source": self.TRAFFIC}
 
 
 def cpu_baseline(cfg, rows_per_point, D):
@@ -222,9 +224,12 @@ def main():
         conv = probe.summary()
         roofline = None
         if conv:
-            roofline = {"bound": "mfma", "kernel": "igemm_pipe_kernel<128,128,2,2,CONV,single-buffer> (3x3 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+            roofline = {"bound": "mfma", "kernel": "winograd_kernel (3x3 conv as F(2x2,3x3): 16 [tiles x Cin] x [Cin x Cout] contractions "
+                                                   "per launch, v_mfma_f32_32x32x2_f32)",
                         "achieved": conv["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": conv["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                        "flops_counted": "executed Winograd-domain multiply-adds (the implicit GEMM of the same conv is 2.25x more)",
+                        "direct_conv_equivalent_tflops": conv["tflops"] * 2.25,
                         "traffic": conv["traffic"]["bytes_per_launch"] if conv["traffic"] else None,
                         "traffic_detail": conv["traffic"],
                         "launches_sampled": conv["launches"], "avg_launch_us": conv["avg_us"]}

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "idiff_fused_bias_act_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "idiff_gemm_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i,
                              ctypes.POINTER(Epilogue), c_p]),
+    "idiff_gemm_2src_f32": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_i64, c_p, c_i64, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),
     "idiff_conv2d_nhwc_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 10 + [ctypes.POINTER(Epilogue), c_p]),
     "idiff_gemm_colstats_split": (c_i, [c_i, c_i, c_i, c_i64, c_i64, c_i]),
     "idiff_conv2d_colstats_split": (c_i, [c_i] * 10),
@@ -200,6 +201,19 @@ def gemm(a, bt, out=None, epilogue=None, M=None, N=None, K=None, lda=None, ldb=N
     ep = ctypes.byref(epilogue) if epilogue is not None else None
     _check(lib().idiff_gemm_f32(a.data_ptr(), lda, stride_a, bt.data_ptr(), ldb, stride_b, out.data_ptr(), ldc, stride_c,
                                 M, N, K, batch, ep, _stream()), "idiff_gemm_f32")
+    return out
+
+
+def gemm_2src(a1, a2, bt, out, epilogue=None):
+    """out = epilogue([a1 | a2] @ bt.T) for two [M, K/2]-shaped sources of equal row pitch (concatenation never formed)."""
+    _dev(a1, "a1"); _dev(a2, "a2"); _dev(bt, "bt"); _dev(out, "out")
+    M, K1 = a1.shape
+    K = K1 + a2.shape[1]
+    if a2.shape[0] != M or a1.stride(0) != a2.stride(0) or bt.shape[1] != K:
+        raise RuntimeError(f"gemm_2src: shapes {tuple(a1.shape)} | {tuple(a2.shape)} x {tuple(bt.shape)}^T")
+    ep = ctypes.byref(epilogue) if epilogue is not None else None
+    _check(lib().idiff_gemm_2src_f32(a1.data_ptr(), a2.data_ptr(), a1.stride(0), K1, bt.data_ptr(), bt.stride(0), out.data_ptr(),
+                                     out.stride(0), M, bt.shape[0], K, ep, _stream()), "idiff_gemm_2src_f32")
     return out
 
 

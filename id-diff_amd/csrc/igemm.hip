@@ -48,6 +48,9 @@ struct IgemmParams {
   int has_ep;
   uint32_t a_bytes, b_bytes;  // extent of one batch slice of A / Bt for the buffer-addressed kernel
   int vec_ep;                 // epilogue operands allow 16-byte accesses (set by the launcher)
+  const float *A2;            // LINEAR, optional: columns K1.. of A live in a second matrix with the same row pitch
+  int K1;                     // (the concatenation [A | A2] is never materialised); 0 = single source
+  uint32_t a2_bytes;
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -321,6 +324,8 @@ igemm_pipe_kernel(const IgemmParams p) {
       __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + (int64_t)batch * p.strideA), 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB =
       __builtin_amdgcn_make_buffer_rsrc((void *)(p.Bt + (int64_t)batch * p.strideB), 0, (int)p.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(p.K1 > 0 ? p.A2 : p.A), 0, (int)(p.K1 > 0 ? p.a2_bytes : p.a_bytes), 0x00020000);
 
   const int kc = (tid & 7) * 4;
   const int row_base = tid >> 3;
@@ -385,9 +390,15 @@ igemm_pipe_kernel(const IgemmParams p) {
       if (++f_kx == p.KW) { f_kx = 0; ++f_ky; }
       if (f_tap == ntaps) { f_tap = 0; f_kx = 0; f_ky = 0; f_c0 += BK; }
     } else {
-      const uint32_t koff = (uint32_t)f_kt * (BK * 4u);
+      if (p.K1 > 0 && f_kt * BK >= p.K1) {   // wave-uniform: second source, same row offsets
+        const uint32_t koff = (uint32_t)(f_kt * BK - p.K1) * 4u;
 #pragma unroll
-      for (int i = 0; i < A_PER_T; ++i) a_reg[i] = buf_load4(rA, (a_mask[i] && kok) ? a_base[i] + koff : OOB);
+        for (int i = 0; i < A_PER_T; ++i) a_reg[i] = buf_load4(rA2, (a_mask[i] && kok) ? a_base[i] + koff : OOB);
+      } else {
+        const uint32_t koff = (uint32_t)f_kt * (BK * 4u);
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) a_reg[i] = buf_load4(rA, (a_mask[i] && kok) ? a_base[i] + koff : OOB);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) b_reg[i] = buf_load4(rB, (b_ok[i] && kok) ? b_base[i] + koffb : OOB);
@@ -703,6 +714,26 @@ IDIFF_API int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const
   if (ep && ep->colstats) return fail("gemm: colstats requested for a problem the pipelined kernel does not take "
                                       "(ask idiff_gemm_colstats_split first)");
   return vec ? dispatch<false, true>(p, batch, st) : dispatch<false, false>(p, batch, st);
+}
+
+IDIFF_API int idiff_gemm_2src_f32(const float *A1, const float *A2, int64_t lda, int K1, const float *Bt, int64_t ldb,
+                                  float *C, int64_t ldc, int M, int N, int K, const idiff_epilogue *ep, void *stream) {
+  using namespace idiff;
+  if (M < 0 || N < 0 || K <= 0 || K1 <= 0 || K1 >= K) return fail("gemm_2src: bad sizes M=%d N=%d K=%d K1=%d", M, N, K, K1);
+  if (M == 0 || N == 0) return 0;
+  if (!A1 || !A2 || !Bt || !C) return fail("gemm_2src: null pointer");
+  if (K1 % BK) return fail("gemm_2src: the split column K1 = %d must be a multiple of %d", K1, BK);
+  if (lda < K1 || lda < K - K1 || ldb < K || ldc < N) return fail("gemm_2src: leading dimension smaller than the row length");
+  const int64_t a1_bytes = ((int64_t)(M - 1) * lda + K1) * 4, a2_bytes = ((int64_t)(M - 1) * lda + (K - K1)) * 4;
+  const int64_t b_bytes = ((int64_t)(N - 1) * ldb + K) * 4;
+  const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A1) && aligned16(A2) && aligned16(Bt);
+  if (!vec || a1_bytes >= BUF_LIMIT || a2_bytes >= BUF_LIMIT || b_bytes >= BUF_LIMIT || getenv("IDIFF_NO_PIPE"))
+    return fail("gemm_2src: operands must be 16-byte aligned, K %% 4 == 0 and each below 4 GiB (use two idiff_gemm_f32 calls)");
+  IgemmParams p = {};
+  p.A = A1; p.A2 = A2; p.K1 = K1; p.Bt = Bt; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.a_bytes = (uint32_t)a1_bytes; p.a2_bytes = (uint32_t)a2_bytes; p.b_bytes = (uint32_t)b_bytes;
+  fill_epilogue(p, ep);
+  return dispatch_pipe<false>(p, 1, (hipStream_t)stream);
 }
 
 IDIFF_API int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out, int B, int H, int W, int Cin,

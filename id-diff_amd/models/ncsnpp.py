@@ -455,7 +455,9 @@ class NCSNpp(HipScoreModel):
         h = self._gn_act(h, mod.GroupNorm_1, self.act_name)
         # shortcut
         if hasattr(mod, "Conv_2") or hasattr(mod, "NIN_0"):
-            split = x.C if x2 is not None else None
+            # cat[x, x2] with equal row pitch: one two-source contraction; otherwise two K-slices through the residual epilogue
+            fused = x2 is not None and x.C == x2.C and x.C % 32 == 0
+            split = x.C if (x2 is not None and not fused) else None
             if hasattr(mod, "Conv_2"):
                 ws, bs = self._conv_w(pk, (idx, 2), mod.Conv_2, split)
                 ws = [w.view(w.shape[0], -1) for w in ws] if split is not None else ws.view(ws.shape[0], -1)
@@ -463,6 +465,10 @@ class NCSNpp(HipScoreModel):
                 ws, bs = self._nin_w(pk, (idx, "nin"), mod.NIN_0, split)
             if x2 is None:
                 sc = self._pointwise(x, ws, bs)
+            elif fused:
+                sc = self._new(x.buf.shape[0], x.H, x.W, ws.shape[0], x.buf)
+                _lib.gemm_2src(x.buf.view(-1, x.C), x2.buf.view(-1, x2.C), ws, sc.buf.view(-1, ws.shape[0]),
+                               epilogue=_lib.make_epilogue(bias=bs))
             else:
                 part = self._pointwise(x, ws[0], bs)
                 sc = self._pointwise(x2, ws[1], None, residual=part.buf)

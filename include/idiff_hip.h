@@ -88,6 +88,12 @@ int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt
                    float *C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch,
                    const idiff_epilogue *ep, void *stream);
 
+/* The same contraction with A given as two row-major matrices of equal row pitch, A = [A1 (M x K1) | A2 (M x (K - K1))]:
+ * the 1x1 shortcut of a residual block whose input is torch.cat([h, skip], dim=1) (models/ncsnpp.py:376-385 with
+ * layerspp.py:271-274) without materialising the concatenation or an intermediate partial product.  K1 % 32 == 0. */
+int idiff_gemm_2src_f32(const float *A1, const float *A2, int64_t lda, int K1, const float *Bt, int64_t ldb, float *C,
+                        int64_t ldc, int M, int N, int K, const idiff_epilogue *ep, void *stream);
+
 /* 2-D convolution, NHWC activations: x [B, H, W, Cin] (Cin % 4 == 0), weights packed as
  * wt [Cout, KH, KW, Cin] (= the reference's [Cout, Cin, KH, KW] nn.Conv2d weight permuted once at load),
  * out [B, OH, OW, Cout] with OH = (H + pad_lo + pad_hi - KH)/stride + 1 (pad_lo on top/left, pad_hi on

@@ -1,0 +1,39 @@
+"""Runs every distinct Winograd-conv call of the benchmark NCSN++ forward twice in isolation; used under
+`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) to tabulate HBM traffic per launch
+(profiles/r01_wino_traffic.json, built by scripts/parse_wino_traffic.py).  Prints the shape keys in launch order."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import id_diff_amd
+from id_diff_amd import _lib, sde_lib
+from id_diff_amd.configs.utils import read_config
+from id_diff_amd.models import utils as mutils
+
+cfg = read_config('configs/dimension_estimation/paper/image_data/cifar_shaped/ncsnpp.py')
+torch.manual_seed(0)
+model = mutils.create_model(cfg).to("cuda").eval()
+sde, eps = sde_lib.configure_sde(cfg)
+score_fn = mutils.get_score_fn(sde, model)
+calls = []
+orig = _lib.conv2d_winograd
+
+def rec(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+    calls.append((B, H, W, Cin, Cout))
+    return orig(x, u, out, B, H, W, Cin, Cout, epilogue)
+
+_lib.conv2d_winograd = rec
+with torch.no_grad():
+    ROWS = int(sys.argv[1]) if len(sys.argv) > 1 else 2240
+    score_fn(torch.rand(ROWS, 3, 32, 32, device="cuda"), torch.full((ROWS,), 1e-5, device="cuda"))
+_lib.conv2d_winograd = orig
+torch.cuda.synchronize()
+for (B, H, W, Cin, Cout) in sorted(set(calls)):
+    x = torch.randn(B, H * W, Cin, device="cuda")
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda") * 0.02
+    u = _lib.winograd_pack(w, Cin, Cout)
+    out = torch.empty(B, H * W, Cout, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):
+        _lib.conv2d_winograd(x, u, out, B, H, W, Cin, Cout)
+    torch.cuda.synchronize()
+    print("KEY", f"{B}x{H}x{W}x{Cin}->{Cout}", calls.count((B, H, W, Cin, Cout)), flush=True)

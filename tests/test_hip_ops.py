@@ -244,6 +244,22 @@ def test_winograd_colstats_feed_groupnorm(B, H, Cin, Cout):
     assert _lib.conv2d_winograd_colstats_split(64, 8, 8, Cin, Cout) == 0     # 16 tiles per sample < one workgroup
 
 
+@pytest.mark.parametrize("M,K1,K2,N", [(1000, 128, 128, 128), (4100, 256, 256, 64), (77, 32, 32, 200)])
+def test_gemm_two_sources(M, K1, K2, N):
+    """[A1 | A2] @ W^T with the concatenation never formed (the split shortcut of the up path)."""
+    g = torch.Generator().manual_seed(M)
+    a1, a2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)
+    w = torch.randn(N, K1 + K2, generator=g) / (K1 + K2) ** 0.5
+    b = torch.randn(N, generator=g)
+    out = torch.empty(M, N, device=DEV)
+    _lib.gemm_2src(a1.to(DEV), a2.to(DEV), w.to(DEV), out, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
+    ref = torch.cat([a1, a2], 1).double() @ w.double().T + b.double()
+    assert rel_err(out.cpu(), ref) < 2e-6
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        _lib.gemm_2src(torch.zeros(8, 16, device=DEV), torch.zeros(8, 16, device=DEV), torch.zeros(4, 32, device=DEV),
+                       torch.zeros(8, 4, device=DEV))
+
+
 def test_operands_beyond_4gib_are_split_on_the_host():
     """The fast kernel addresses operands through 32-bit-offset buffer descriptors; larger problems are cut into
     row / image ranges (igemm.hip: shift_epilogue).  Checked on the rows / images around the cut."""
