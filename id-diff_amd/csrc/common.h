@@ -47,7 +47,9 @@ static inline int streaming_grid(int64_t work_items, int block) {
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
-    case IDIFF_ACT_SILU: return v / (1.0f + expf(-v));
+    // v_exp_f32 / v_rcp_f32 (1-2 ulp each) instead of libm's expf and an IEEE division: 4 instructions, not ~25, which
+    // is what kept the GroupNorm-apply pass below the HBM rate; |error| <= 3e-7 |silu(v)|, far inside the 2e-5 parity bar
+    case IDIFF_ACT_SILU: return v * __frcp_rn(1.0f + __expf(-v));
     case IDIFF_ACT_ELU: return v > 0.f ? v : (expf(v) - 1.0f);  // exp(x)-1 as ATen's elu does
     case IDIFF_ACT_RELU: return v > 0.f ? v : 0.f;
     case IDIFF_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
