@@ -204,6 +204,48 @@ winograd_kernel(const WinoParams p) {
   }
 
   // ---------------------------------------------------------------- tail
+  // This thread finishes 4 channels (n .. n+3) of tiles 2g and 2g+1: output pixels (2ty + a, 2tx + b).  Their addresses
+  // and every epilogue operand that comes from memory (bias, per-sample bias and scale, the eight 16-byte residual
+  // pieces) are requested BEFORE the transform-domain exchange, so their latency hides under it (the residual read
+  // issued at its point of use cost 0.3 ms of a 3.1 ms launch).
+  const idiff_epilogue &ep = p.ep;
+  const bool want_stats = p.has_ep && ep.colstats != nullptr;
+  const int cq = tid & 15, g = tid >> 4;
+  const int n = n0 + 4 * cq;
+  const bool per_image = p.ep.rows_per_group == p.H * p.W;   // the usual per-sample bias / scale: group = image
+  const int tiles_y = p.tiles_per_img / p.tiles_x;
+  int64_t m_of[2][4];          // [tile][2a + b]
+  bool t_ok[2];
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), rb[2], res[2][4];
+  float rs[2] = {1.f, 1.f};
+  {
+    int T = tile0 + 2 * g;
+    int img = T / p.tiles_per_img;
+    int rem = T - img * p.tiles_per_img;
+    int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    if (p.has_ep && ep.bias) bias = *reinterpret_cast<const float4 *>(ep.bias + n);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      t_ok[t] = T < p.total_tiles;
+      const int64_t m00 = ((int64_t)img * p.H + 2 * ty) * p.W + 2 * tx;
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) m_of[t][ab] = m00 + (ab >> 1) * p.W + (ab & 1);
+      rb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t_ok[t] && p.has_ep) {
+        if (per_image) {
+          if (ep.rowbias) rb[t] = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)img * ep.ld_rowbias + n);
+          if (ep.rowscale) rs[t] = ep.rowscale[img];
+        }
+        if (ep.residual) {
+#pragma unroll
+          for (int ab = 0; ab < 4; ++ab) res[t][ab] = *reinterpret_cast<const float4 *>(ep.residual + m_of[t][ab] * ep.ld_residual + n);
+        }
+      }
+      ++T;
+      if (++tx == p.tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++img; } }
+    }
+  }
+
   // z_ib for this wave's row i: z_i0 = m_i0 + m_i1 + m_i2, z_i1 = m_i1 - m_i2 - m_i3 -> LDS [i][tile][b][cout]
   {
     float *zp = lds + ((wi * 64 + tb * 32 + 4 * (lane >> 5)) * 2) * 64 + (lane & 31);
@@ -219,55 +261,40 @@ winograd_kernel(const WinoParams p) {
   }
   __syncthreads();
 
-  const idiff_epilogue &ep = p.ep;
-  const bool want_stats = p.has_ep && ep.colstats != nullptr;
-  const int cq = tid & 15, g = tid >> 4;                     // 4 channels n0 + 4cq .., items (tile, b) 4g .. 4g+3
-  const int n = n0 + 4 * cq;
-  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.has_ep && ep.bias) bias = *reinterpret_cast<const float4 *>(ep.bias + n);
-  const bool per_image = p.ep.rows_per_group == p.H * p.W;   // the usual per-sample bias / scale: group = image
-  const int tiles_y = p.tiles_per_img / p.tiles_x;
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-  int T = tile0 + 2 * g;
-  int img = T / p.tiles_per_img;
-  int rem = T - img * p.tiles_per_img;
-  int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int tl = 2 * g + (it >> 1), b = it & 1;
-    const float *zr = lds + (tl * 2 + b) * 64 + 4 * cq;
-    const float4 z0 = *reinterpret_cast<const float4 *>(zr);
-    const float4 z1 = *reinterpret_cast<const float4 *>(zr + 1 * 64 * 2 * 64);
-    const float4 z2 = *reinterpret_cast<const float4 *>(zr + 2 * 64 * 2 * 64);
-    const float4 z3 = *reinterpret_cast<const float4 *>(zr + 3 * 64 * 2 * 64);
-    if (T < p.total_tiles) {
-      float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
-      float rs = 1.f;
-      if (p.has_ep && per_image) {
-        if (ep.rowbias) rb = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)img * ep.ld_rowbias + n);
-        if (ep.rowscale) rs = ep.rowscale[img];
-      }
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float *zr = lds + ((2 * g + t) * 2 + b) * 64 + 4 * cq;
+      const float4 z0 = *reinterpret_cast<const float4 *>(zr);
+      const float4 z1 = *reinterpret_cast<const float4 *>(zr + 1 * 64 * 2 * 64);
+      const float4 z2 = *reinterpret_cast<const float4 *>(zr + 2 * 64 * 2 * 64);
+      const float4 z3 = *reinterpret_cast<const float4 *>(zr + 3 * 64 * 2 * 64);
+      if (!t_ok[t]) continue;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const int64_t m = ((int64_t)img * p.H + 2 * ty + a) * p.W + 2 * tx + b;
+        const int64_t m = m_of[t][2 * a + b];
         float v[4];
         if (a == 0) { v[0] = z0.x + z1.x + z2.x; v[1] = z0.y + z1.y + z2.y; v[2] = z0.z + z1.z + z2.z; v[3] = z0.w + z1.w + z2.w; }
         else { v[0] = z1.x - z2.x - z3.x; v[1] = z1.y - z2.y - z3.y; v[2] = z1.z - z2.z - z3.z; v[3] = z1.w - z2.w - z3.w; }
         v[0] += bias.x; v[1] += bias.y; v[2] += bias.z; v[3] += bias.w;
         if (p.has_ep) {
+          float4 rbv = rb[t];
+          float rsv = rs[t];
           if (!per_image) {
             const int64_t grp = m / ep.rows_per_group;
-            rb = ep.rowbias ? *reinterpret_cast<const float4 *>(ep.rowbias + grp * ep.ld_rowbias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rs = ep.rowscale ? ep.rowscale[grp] : 1.f;
+            rbv = ep.rowbias ? *reinterpret_cast<const float4 *>(ep.rowbias + grp * ep.ld_rowbias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rsv = ep.rowscale ? ep.rowscale[grp] : 1.f;
           }
-          v[0] = idiff::act_apply(v[0] + rb.x, ep.act); v[1] = idiff::act_apply(v[1] + rb.y, ep.act);
-          v[2] = idiff::act_apply(v[2] + rb.z, ep.act); v[3] = idiff::act_apply(v[3] + rb.w, ep.act);
+          v[0] = idiff::act_apply(v[0] + rbv.x, ep.act); v[1] = idiff::act_apply(v[1] + rbv.y, ep.act);
+          v[2] = idiff::act_apply(v[2] + rbv.z, ep.act); v[3] = idiff::act_apply(v[3] + rbv.w, ep.act);
           if (ep.residual) {
-            const float4 res = *reinterpret_cast<const float4 *>(ep.residual + m * ep.ld_residual + n);
-            v[0] += res.x; v[1] += res.y; v[2] += res.z; v[3] += res.w;
+            const float4 r4 = res[t][2 * a + b];
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] *= ep.out_scale; v[e] *= rs; }
+          for (int e = 0; e < 4; ++e) { v[e] *= ep.out_scale; v[e] *= rsv; }
         }
         *reinterpret_cast<float4 *>(p.out + m * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
         if (want_stats) {
@@ -275,10 +302,6 @@ winograd_kernel(const WinoParams p) {
           for (int e = 0; e < 4; ++e) { s1[e] += (double)v[e]; s2[e] += (double)v[e] * (double)v[e]; }
         }
       }
-    }
-    if (it == 1) {   // next tile
-      ++T;
-      if (++tx == p.tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++img; } }
     }
   }
   if (want_stats) {
