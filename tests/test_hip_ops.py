@@ -210,6 +210,28 @@ def test_conv2d_winograd_vs_cpu(B, H, W, Cin, Cout):
     assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref2) < 3e-6
 
 
+def test_conv2d_winograd_splits_inputs_beyond_one_descriptor():
+    """Inputs past the 32-bit buffer descriptor are cut into image ranges on the host (winograd.hip); checked on the
+    images around the cut with the per-sample epilogue operands that have to be shifted with it."""
+    g = torch.Generator(device=DEV).manual_seed(1)
+    B, H, Cin, Cout = 4200, 32, 256, 64                      # x = 4.4 GB
+    x = torch.randn(B, H * H, Cin, device=DEV, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device=DEV, generator=g) / (9 * Cin) ** 0.5
+    u = _lib.winograd_pack(w, Cin, Cout)
+    temb = torch.randn(B, Cout, device=DEV, generator=g)
+    rsc = torch.rand(B, device=DEV, generator=g) + 0.5
+    out = torch.empty(B, H * H, Cout, device=DEV)
+    _lib.conv2d_winograd(x, u, out, B, H, H, Cin, Cout, epilogue=_lib.make_epilogue(rowbias=temb, rows_per_group=H * H, rowscale=rsc))
+    for b0 in (0, B // 2 - 1, B // 2, B - 1):
+        ref = torch.empty(1, H * H, Cout, device=DEV)
+        _lib.conv2d_winograd(x[b0:b0 + 1].contiguous(), u, ref, 1, H, H, Cin, Cout,
+                             epilogue=_lib.make_epilogue(rowbias=temb[b0:b0 + 1].contiguous(), rows_per_group=H * H,
+                                                         rowscale=rsc[b0:b0 + 1].contiguous()))
+        assert torch.equal(out[b0:b0 + 1], ref), b0
+    del x, out
+    torch.cuda.empty_cache()
+
+
 def test_conv2d_winograd_rejects_what_it_cannot_take():
     assert not _lib.conv2d_winograd_ok(2, 7, 8, 32, 64)      # odd height
     assert not _lib.conv2d_winograd_ok(2, 8, 8, 4, 64)       # Cin % 8
