@@ -11,7 +11,7 @@ import sys as _sys
 
 __version__ = "0.1.0"
 
-_DROPIN = ("op", "sde_lib", "models", "dim_reduction", "plot_utils", "configs")
+_DROPIN = ("op", "sde_lib", "models", "dim_reduction", "plot_utils", "configs", "lightning_callbacks")
 
 
 def install_dropin():

@@ -143,3 +143,63 @@ def test_bessel_ratio_asymptotics():
             approx = 1 - (p - 1) / (2 * kappa) + (p - 1) * (p - 3) / (8 * kappa ** 2) + (p - 1) * (p - 3) / (8 * kappa ** 3)
             exact = ive(p / 2, kappa) / ive(p / 2 - 1, kappa)
             assert abs(approx - exact) < 5e-9, (p, kappa, approx, exact)  # O(p^4 / kappa^4)
+
+
+def test_plot_spectrum_and_distribution_render():
+    """§8-f rank 1: the figures either side of the path (plot_utils.py:111-139, :158-195)."""
+    rng = np.random.default_rng(0)
+    spectra = [np.sort(rng.random(40))[::-1].tolist() for _ in range(3)]
+    svd = {'singular_values': spectra}
+    fig = plot_utils.plot_spectrum(svd, mode='all', ground_truth=[10, 12])
+    ax = fig.axes[0]
+    assert len(ax.lines) == 3 + 2                       # three spectra + two ground-truth markers
+    assert list(ax.lines[0].get_xdata()) == [30, 30]    # x = len - ground_truth
+    np.testing.assert_allclose(ax.lines[2].get_ydata(), spectra[0])
+    import matplotlib.pyplot as plt
+    plt.close(fig)
+    img = plot_utils.plot_spectrum(svd, return_tensor=True, mode='first')
+    assert img.dtype == torch.float32 and img.shape[0] == 3 and img.shape[1] > 100 and 0.0 <= float(img.min()) <= float(img.max()) <= 1.0
+    image, dims = plot_utils.plot_distribution(svd, return_tensor=True, mode='all')
+    assert image.shape[0] == 3 and dims == [plot_utils.estimate_dim(s) for s in spectra]
+    assert plot_utils.plot_distribution(svd, mode='all') == dims
+
+
+def test_score_spectrum_visualization_callback(monkeypatch, tmp_path):
+    """lightning_callbacks/callbacks.py:403-432: every svd_frequency epochs -> two images and the mean dimension."""
+    from id_diff_amd.lightning_callbacks import utils as cutils
+    cb = cutils.get_callback_by_name('ScoreSpectrumVisualization')(show_evolution=True)
+    rng = np.random.default_rng(1)
+    svd = {'singular_values': [np.sort(rng.random(30))[::-1].tolist() for _ in range(4)]}
+    calls = {}
+
+    def fake_gmd(config, name=None, return_svd=False):
+        calls['args'] = (config.model.checkpoint_path, name, return_svd)
+        return svd
+
+    monkeypatch.setattr(dim_reduction, "get_manifold_dimension", fake_gmd)
+
+    class Experiment:
+        def __init__(self): self.images = []
+        def add_image(self, tag, img, step): self.images.append((tag, tuple(img.shape), step))
+
+    class Module:
+        def __init__(self, epoch):
+            self.config = ConfigDict(logging=ConfigDict(svd_frequency=5, save_svd=False, log_path=str(tmp_path), log_name='run'),
+                                     model=ConfigDict(checkpoint_path=None))
+            self.current_epoch = epoch
+            self.logger = type("L", (), {})()
+            self.logger.experiment = Experiment()
+            self.logged = {}
+        def log(self, key, value, **kw): self.logged[key] = value
+
+    quiet = Module(2)
+    cb.on_validation_epoch_end(None, quiet)
+    assert not quiet.logger.experiment.images and 'args' not in calls
+    due = Module(4)
+    cb.on_validation_epoch_end(None, due)
+    assert calls['args'] == (str(tmp_path / 'run' / 'checkpoints/best/last.ckpt'), 'svd_4', True)
+    tags = [t for t, _, _ in due.logger.experiment.images]
+    assert tags == ['score specturm', 'dim_distribution'] and all(s[0] == 3 for _, s, _ in due.logger.experiment.images)
+    assert due.logged['dim'] == pytest.approx(np.mean([plot_utils.estimate_dim(s) for s in svd['singular_values']]))
+    with pytest.raises(ValueError):
+        cutils.register_callback(name='ScoreSpectrumVisualization')(type(cb))
