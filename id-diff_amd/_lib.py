@@ -360,3 +360,41 @@ def spectrum(S, workspace=None, return_eig=False):
         sv = sv[0]
         eig = eig[0] if eig is not None else None
     return (sv, eig) if return_eig else sv
+
+
+# ---- the stages of the spectrum, for the row-sharded single-point pipeline (dim_reduction.row_sharded_spectrum)
+def column_sums(S):
+    """fp64 column sums [D] of S [M, D] (two-stage, deterministic: idiff_colmean_f64 times M)."""
+    _dev(S, "scores")
+    M, D = S.shape
+    if M == 0:
+        return torch.zeros(D, dtype=torch.float64, device=S.device)
+    mean = torch.empty(D, dtype=torch.float64, device=S.device)
+    scratch = torch.empty(32 * D, dtype=torch.float64, device=S.device)
+    _check(lib().idiff_colmean_f64(S.data_ptr(), 1, M, D, mean.data_ptr(), scratch.data_ptr(), _stream()), "idiff_colmean_f64")
+    return mean * M
+
+
+def centered_gram(S, mean):
+    """fp64 Gram [D, D] of the rows of S [M, D] after subtracting ``mean`` [D] (fp64): sum_i (s_i - mean)(s_i - mean)^T."""
+    _dev(S, "scores"); _dev(mean, "mean", dtype=torch.float64)
+    M, D = S.shape
+    if M == 0:
+        return torch.zeros(D, D, dtype=torch.float64, device=S.device)
+    G = torch.empty(D, D, dtype=torch.float64, device=S.device)
+    _check(lib().idiff_centered_gram_f64(S.data_ptr(), mean.data_ptr(), 1, M, D, G.data_ptr(), _stream()), "idiff_centered_gram_f64")
+    return G
+
+
+def sym_eigvals(G):
+    """Eigenvalues (ascending, fp64) of a symmetric fp64 matrix [D, D]; G is overwritten (Householder + Sturm bisection)."""
+    _dev(G, "G", dtype=torch.float64)
+    D = G.shape[0]
+    diag = torch.empty(D, dtype=torch.float64, device=G.device)
+    offd = torch.empty(D, dtype=torch.float64, device=G.device)
+    scratch = torch.empty(4 * D + 16 + ((D + 511) // 512 + 1) * D, dtype=torch.float64, device=G.device)
+    eig = torch.empty(D, dtype=torch.float64, device=G.device)
+    _check(lib().idiff_symtridiag_f64(G.data_ptr(), 1, D, diag.data_ptr(), offd.data_ptr(), scratch.data_ptr(), _stream()),
+           "idiff_symtridiag_f64")
+    _check(lib().idiff_tridiag_eigvals_f64(diag.data_ptr(), offd.data_ptr(), 1, D, eig.data_ptr(), _stream()), "idiff_tridiag_eigvals_f64")
+    return eig

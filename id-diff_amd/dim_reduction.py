@@ -65,19 +65,24 @@ class ScoreMatrixBuilder:
             return rows
         return min(rows, max(128, (2240 * 3072) // sample_numel))
 
-    def build(self, x, batchsize, t=None, noise=None, generator=None, seed=None):
-        """x: one sample on the device; returns S [M, D] fp32 (rows in the reference's order).
+    def build(self, x, batchsize, t=None, noise=None, generator=None, seed=None, row_range=None):
+        """x: one sample on the device; returns S [M, D] fp32 (rows in the reference's order), or only the rows
+        ``row_range = (lo, hi)`` of it (row-sharded pipeline: with ``seed`` the draws of a row do not depend on who
+        computes it).
 
         Noise: ``noise`` (explicit draws, for parity tests) > ``seed`` (in-kernel Philox stream, the default of the
         drivers: independent of the launch-set size) > ``generator`` (torch.randn)."""
         _, _, rows = batching(tuple(x.shape), batchsize)
         D = x.numel()
         t = self.eps if t is None else t
-        S = torch.empty(rows, D, device=self.device, dtype=torch.float32)
+        r_lo, r_hi = (0, rows) if row_range is None else row_range
+        if row_range is not None and noise is None and (seed is None or D % 4):
+            raise RuntimeError("a row range needs position-keyed noise: pass `seed` (and D % 4 == 0) or explicit `noise`")
+        S = torch.empty(r_hi - r_lo, D, device=self.device, dtype=torch.float32)
         step = self.rows_per_launch(rows, D)
         xf = x.reshape(-1).contiguous()
-        for lo in range(0, rows, step):
-            n = min(step, rows - lo)
+        for lo in range(r_lo, r_hi, step):
+            n = min(step, r_hi - lo)
             vec_t = torch.full((n,), float(t), device=self.device, dtype=torch.float32)
             mean_unit, std = self.sde.marginal_prob(torch.ones((), device=self.device), vec_t)
             coeff = None if mean_unit.ndim == 0 else mean_unit.reshape(-1).contiguous()
@@ -91,7 +96,7 @@ class ScoreMatrixBuilder:
                     z = torch.randn(n, D, device=self.device, dtype=torch.float32, generator=generator)
                 _lib.perturb(xf, z, std.contiguous(), coeff, batch, n, D)
             score = self.score_fn(batch.view(n, *x.shape), vec_t)
-            S[lo:lo + n].copy_(score.reshape(n, D))
+            S[lo - r_lo:lo - r_lo + n].copy_(score.reshape(n, D))
         return S
 
 
@@ -123,6 +128,25 @@ class SpectrumPipeline:
             torch.cuda.current_stream().wait_stream(self.side)
         out, self.pending = self.pending, []
         return out
+
+
+def row_sharded_spectrum(S_local, total_rows, ops=None):
+    """Singular values (descending, fp32, [D]) of the column-centred [total_rows, D] matrix whose rows are spread over
+    the ranks of the default process group (this rank holds ``S_local``); every rank returns the full spectrum.
+
+    SURVEY.md 8(f) rank 2 / DESIGN.md 6: two collectives -- all-reduce of the fp64 column sums [D], all-reduce of the
+    fp64 centred Gram [D, D] -- then the Householder + bisection eigensolve, run redundantly on every rank (60 ms at
+    D = 3072, cheaper than shipping the result).  With one rank this is the same arithmetic as ``_lib.spectrum``.
+    ``ops`` = (column_sums, centered_gram, sym_eigvals) defaults to the HIP stages; the CPU process-group test injects
+    plain-torch stand-ins to check the reduction logic without a GPU."""
+    col_sums, gram, eigvals = ops if ops is not None else (_lib.column_sums, _lib.centered_gram, _lib.sym_eigvals)
+    if total_rows < S_local.shape[1]:
+        raise RuntimeError(f"row_sharded_spectrum: needs total_rows >= D (got {total_rows} x {S_local.shape[1]})")
+    sums = parallel.all_reduce_sum(col_sums(S_local))
+    mean = sums / float(total_rows)
+    G = parallel.all_reduce_sum(gram(S_local, mean))
+    eig = eigvals(G)
+    return eig.clamp_min(0.0).sqrt().flip(0).to(torch.float32)
 
 
 def build_many(builder, xs, batchsize, seeds):
@@ -196,11 +220,28 @@ def get_manifold_dimension(config, name=None, return_svd=False):
 
     builder = ScoreMatrixBuilder(score_fn, pl_module.sde, pl_module.sampling_eps, device,
                                  config.get('dim_estimation.inflight_rows', None))
+    def point_seed(p):
+        return seed + 1000003 * (p + 1)
+
+    if str(config.get('dim_estimation.shard', 'points')) == 'rows' and world > 1:
+        # one point at a time on ALL ranks, each computing a slice of its rows (latency of a single large point)
+        spectra = []
+        with torch.no_grad():
+            for p, (x, batchsize) in enumerate(points):
+                rows = batching(tuple(x.shape), batchsize)[2]
+                S_local = builder.build(x.to(device), batchsize, seed=point_seed(p), row_range=parallel.my_rows(rows, rank, world))
+                spectra.append(row_sharded_spectrum(S_local, rows))
+        info = {'singular_values': [s.tolist() for s in torch.stack(spectra).cpu()]}
+        if return_svd:
+            return info
+        if rank == 0:
+            with open(os.path.join(save_path, f'{name}.pkl'), 'wb') as f:
+                pickle.dump(info, f)
+        return None
+
     mine = parallel.my_points(len(points), rank, world)
     n_sv = None
     pipe = SpectrumPipeline(device, overlap=bool(config.get('dim_estimation.overlap_spectrum', True)))
-    def point_seed(p):
-        return seed + 1000003 * (p + 1)
 
     with torch.no_grad():
         small = bool(mine) and points[mine[0]][0].numel() <= 4096 and len({points[p][1] for p in mine}) == 1

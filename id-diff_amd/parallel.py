@@ -5,6 +5,11 @@ tests).  Data points are independent (dim_reduction.py:162-202 appends independe
 to rank ``p % world`` and the only collective on the path is one all-gather of the per-rank singular spectra
 (``[points_per_rank, n_sv]`` fp32, a few MB at most: latency-bound on the xGMI mesh).  The reference has no
 multi-device path; this file is new work scoped by SURVEY.md 8(e).
+
+Second, optional axis: the rows of ONE point's score matrix are split over the ranks
+(``my_rows``) and the spectrum is assembled from an all-reduce of the fp64 column sums ([D]) and of the fp64
+centred Gram ([D, D]: 75 MB at D = 3072, 1.2 GB at D = 12288, bandwidth-bound on the xGMI ring) --
+``dim_reduction.row_sharded_spectrum``.
 """
 import os
 
@@ -62,3 +67,17 @@ def gather_spectra(local, num_points, n_sv, device):
         if idx:
             out[idx] = recv[r, : len(idx)]
     return out
+
+
+def my_rows(total_rows, rank, world):
+    """Contiguous row range [lo, hi) of one point's score matrix owned by ``rank`` (sizes differ by at most one)."""
+    base, extra = divmod(total_rows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_reduce_sum(tensor):
+    """In-place sum over the default process group; identity when there is none."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return tensor

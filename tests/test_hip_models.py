@@ -271,3 +271,51 @@ def test_score_matrix_does_not_depend_on_launch_set_size():
     assert mats[0].shape == (5224, 3072)
     for other in mats[1:]:
         assert rel_err(other.cpu(), mats[0].cpu()) < 2e-6
+
+
+def _rows_driver_worker(rank, world, port, log_path, q):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    import id_diff_amd  # noqa: F401
+    from id_diff_amd import dim_reduction as dr
+    from id_diff_amd.configs.utils import read_config as rc
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    cfg = rc('configs/dimension_estimation/paper/euclidean_data/ksphere/10dim.py')
+    cfg.model.name = 'ksphere_exact'
+    cfg.data.data_samples = 2000
+    cfg.device = "cuda"
+    cfg.logging.log_path = log_path
+    cfg.dim_estimation = type(cfg)(shard='rows')
+    svd = dr.get_manifold_dimension(cfg, return_svd=True)
+    q.put((rank, svd['singular_values']))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_driver_row_sharded_matches_point_sharded(tmp_path):
+    """`config.dim_estimation.shard = 'rows'`: two ranks split the rows of every point; spectra
+    and IDs equal the ordinary single-process run (per-row Philox noise does not depend on the split)."""
+    import os
+    import torch.multiprocessing as mp
+    cfg = read_config('configs/dimension_estimation/paper/euclidean_data/ksphere/10dim.py')
+    cfg.model.name = 'ksphere_exact'
+    cfg.data.data_samples = 2000
+    cfg.device = DEV
+    cfg.logging.log_path = str(tmp_path)
+    ref = dim_reduction.get_manifold_dimension(cfg, return_svd=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rows_driver_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        np.testing.assert_allclose(np.array(got[rank]), np.array(ref['singular_values']), rtol=2e-5, atol=1e-5)
+        assert plot_utils.plot_dims({'singular_values': got[rank]})[1] == [10] * 4

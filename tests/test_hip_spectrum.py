@@ -123,3 +123,76 @@ def test_errors():
         _lib.spectrum(torch.zeros(3, 5, device=DEV))
     with pytest.raises(RuntimeError, match="no CPU path"):
         _lib.spectrum(torch.zeros(5, 3))
+
+
+# ---- row-sharded single point
+def test_row_sharded_spectrum_single_rank_and_emulated_halves():
+    from id_diff_amd import dim_reduction
+    g = torch.Generator().manual_seed(11)
+    M, D = 900, 384
+    S = (torch.randn(M, D, generator=g) * torch.linspace(0.1, 3.0, D) + 0.7).to(DEV)
+    ref = _lib.spectrum(S)
+    sv = dim_reduction.row_sharded_spectrum(S, M)
+    torch.testing.assert_close(sv, ref, rtol=2e-6, atol=1e-6)
+    # what two ranks would each contribute, summed by hand: same spectrum
+    a, b = S[:500].contiguous(), S[500:].contiguous()
+    mean = (_lib.column_sums(a) + _lib.column_sums(b)) / M
+    G = _lib.centered_gram(a, mean) + _lib.centered_gram(b, mean)
+    sv2 = _lib.sym_eigvals(G).clamp_min(0).sqrt().flip(0).float()
+    torch.testing.assert_close(sv2, ref, rtol=2e-6, atol=1e-6)
+    assert float(_lib.column_sums(S[:0]).abs().sum()) == 0.0 and float(_lib.centered_gram(S[:0], mean).abs().sum()) == 0.0
+    with pytest.raises(RuntimeError, match="total_rows >= D"):
+        dim_reduction.row_sharded_spectrum(S[:100].contiguous(), 100)
+
+
+def _rows_gpu_worker(rank, world, port, q):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    import id_diff_amd  # noqa: F401
+    from id_diff_amd import _lib as lib, dim_reduction, parallel, sde_lib
+    from id_diff_amd.models import utils as mutils
+    from helpers import fcn_config
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # two processes on the one card: gloo moves
+    dev = torch.device("cuda:0")                                           # the device tensors, RCCL needs a GPU per rank
+    cfg = fcn_config()
+    torch.manual_seed(0)
+    model = mutils.create_model(cfg).to(dev).eval()
+    sde, eps = sde_lib.configure_sde(cfg)
+    score_fn = mutils.get_score_fn(sde, model)
+    builder = dim_reduction.ScoreMatrixBuilder(score_fn, sde, eps, dev)
+    x = torch.randn(cfg.data.shape[0], generator=torch.Generator().manual_seed(3)).to(dev)
+    bs = 100
+    rows = dim_reduction.batching(tuple(x.shape), bs)[2]
+    with torch.no_grad():
+        lo, hi = parallel.my_rows(rows, rank, world)
+        S_local = builder.build(x, bs, seed=77, row_range=(lo, hi))
+        sv = dim_reduction.row_sharded_spectrum(S_local, rows)
+        S_full = builder.build(x, bs, seed=77)
+        ok_rows = bool(torch.equal(S_full[lo:hi], S_local))
+        ref = lib.spectrum(S_full)
+    q.put((rank, ok_rows, float((sv - ref).abs().max() / ref.abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_pipeline_two_processes_one_gpu():
+    """Two ranks (two processes on this card, gloo moving the device tensors) each evaluate half of the rows of one
+    point's score matrix; the all-reduced spectrum equals the single-rank one and the rows do not depend on the split."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rows_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok_rows, err in got:
+        assert ok_rows, rank
+        assert err < 5e-6, (rank, err)

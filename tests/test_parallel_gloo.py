@@ -49,3 +49,47 @@ def test_gather_two_ranks_even():
 def test_gather_two_ranks_ragged_and_idle_rank():
     _run(2, 3)   # rank 1 owns one point fewer
     _run(2, 1)   # rank 1 owns nothing but still joins the collective
+
+
+# ---- row-sharded single point: the two all-reduces, with plain-torch stand-ins for the HIP stages
+def _torch_ops():
+    col_sums = lambda S: S.double().sum(0)
+    gram = lambda S, mean: (S.double() - mean).T @ (S.double() - mean)
+    eigvals = lambda G: torch.linalg.eigvalsh(G)
+    return col_sums, gram, eigvals
+
+
+def _rows_worker(rank, world, port, M, D, q):
+    sys.path.insert(0, ROOT)
+    import id_diff_amd  # noqa: F401
+    from id_diff_amd import dim_reduction, parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    S = torch.randn(M, D, generator=torch.Generator().manual_seed(5)) + 3.0      # every rank draws the same matrix
+    lo, hi = parallel.my_rows(M, rank, world)
+    sv = dim_reduction.row_sharded_spectrum(S[lo:hi].contiguous(), M, ops=_torch_ops())
+    q.put((rank, (lo, hi), sv))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_spectrum_two_and_three_ranks():
+    M, D = 37, 12
+    S = torch.randn(M, D, generator=torch.Generator().manual_seed(5)) + 3.0
+    ref = torch.linalg.svdvals((S - S.mean(0)).double()).float()
+    for world in (2, 3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 31500 + (os.getpid() % 2000) + world
+        procs = [ctx.Process(target=_rows_worker, args=(r, world, port, M, D, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=120) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        ranges = sorted(g[1] for g in got)
+        assert ranges[0][0] == 0 and ranges[-1][1] == M and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        for _, _, sv in got:
+            torch.testing.assert_close(sv, ref, rtol=1e-5, atol=1e-6)
