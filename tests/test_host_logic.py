@@ -203,3 +203,39 @@ def test_score_spectrum_visualization_callback(monkeypatch, tmp_path):
     assert due.logged['dim'] == pytest.approx(np.mean([plot_utils.estimate_dim(s) for s in svd['singular_values']]))
     with pytest.raises(ValueError):
         cutils.register_callback(name='ScoreSpectrumVisualization')(type(cb))
+
+
+def test_image_folder_datamodule(tmp_path):
+    """§8-f rank 4: the 'image' data module (ImageDatasets.py:25-105) on a folder of PNGs, both transform recipes."""
+    from PIL import Image
+    from id_diff_amd.lightning_data_modules import utils as dutils
+    rng = np.random.default_rng(0)
+    folder = tmp_path / 'faces'
+    folder.mkdir()
+    frames = []
+    for i in range(10):
+        a = rng.integers(0, 256, size=(218, 178, 3), dtype=np.uint8)
+        frames.append(a)
+        Image.fromarray(a).save(folder / f'{i:03d}.png')
+    cfg = ConfigDict(data=ConfigDict(datamodule='image', base_dir=str(tmp_path), dataset='faces', shape=[3, 32, 32], crop=True,
+                                     split=[0.8, 0.1, 0.1]),
+                     training=ConfigDict(batch_size=4), eval=ConfigDict(batch_size=2))
+    dm = dutils.create_lightning_datamodule(cfg)
+    dm.setup()
+    assert (len(dm.train_data), len(dm.valid_data), len(dm.test_data)) == (8, 1, 1)
+    batch = next(iter(dm.train_dataloader()))
+    assert batch.shape == (4, 3, 32, 32) and batch.dtype == torch.float32 and -1.0 <= float(batch.min()) and float(batch.max()) <= 1.0
+    # the crop recipe, re-derived: centre 108x108 window, bicubic to 32x32, [-1, 1]
+    x0 = dm.dataset[0]
+    win = frames[0][55:163, 35:143]
+    ref = np.asarray(Image.fromarray(win).resize((32, 32), Image.BICUBIC), dtype=np.float32) / 255.0
+    np.testing.assert_allclose(x0.permute(1, 2, 0).numpy(), (ref - 0.5) / 0.5, atol=1e-6)
+    cfg.data.crop = False
+    cfg.data.shape = [3, 109, 89]
+    plain = dutils.create_lightning_datamodule(cfg)
+    plain.setup()
+    y0 = plain.dataset[0]
+    assert y0.shape == (3, 109, 89) and 0.0 <= float(y0.min()) and float(y0.max()) <= 1.0
+    cfg.data.dataset = 'mnist'
+    with pytest.raises(FileNotFoundError, match="no network"):
+        dutils.create_lightning_datamodule(cfg).setup()
