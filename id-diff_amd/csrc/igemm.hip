@@ -634,6 +634,8 @@ int dispatch_pipe(IgemmParams &p, int batch, hipStream_t st) {
   // (measured 135-142 TFLOP/s vs 124-135 for the double-buffered two-workgroup form)
   if (p.N > 64 && wg_big >= 1024 && !getenv("IDIFF_DBUF_ONLY")) return launch_pipe<128, 128, 2, 2, CONV, false>(p, batch, st);
   if (p.N > 64 && wg_big >= 256) return launch_pipe<128, 128, 2, 2, CONV>(p, batch, st);
+  // narrow outputs (the 3-channel image conv at the end of the U-Nets): one 32-wide MFMA column instead of two
+  if (p.N <= 32 && p.M >= 4096) return launch_pipe<128, 32, 4, 1, CONV>(p, batch, st);
   const int64_t wg_mid = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 64) * batch;
   if (wg_mid >= 256 || p.M >= 4096) return launch_pipe<128, 64, 2, 2, CONV>(p, batch, st);
   return launch_pipe<64, 64, 2, 2, CONV>(p, batch, st);
