@@ -729,8 +729,22 @@ IDIFF_API int idiff_gemm_2src_f32(const float *A1, const float *A2, int64_t lda,
   const int64_t a1_bytes = ((int64_t)(M - 1) * lda + K1) * 4, a2_bytes = ((int64_t)(M - 1) * lda + (K - K1)) * 4;
   const int64_t b_bytes = ((int64_t)(N - 1) * ldb + K) * 4;
   const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A1) && aligned16(A2) && aligned16(Bt);
+  if (vec && (a1_bytes >= BUF_LIMIT || a2_bytes >= BUF_LIMIT) && b_bytes < BUF_LIMIT && M > 1 && !getenv("IDIFF_NO_PIPE")) {
+    // rows are independent: cut them until each half fits one buffer descriptor (as idiff_gemm_f32 does)
+    if (ep && ep->colstats) return fail("gemm_2src: colstats is not available for operands beyond 4 GiB");
+    const int rpg = (ep && ep->rows_per_group > 0) ? ep->rows_per_group : 1;
+    int mid = (M / 2 / rpg) * rpg;
+    if (mid <= 0) mid = M / 2;
+    if (mid % rpg) return fail("gemm_2src: cannot split %d rows inside an epilogue row group of %d", M, rpg);
+    idiff_epilogue lo, hi;
+    if (ep) { lo = *ep; hi = shift_epilogue(*ep, mid); }
+    int rc = idiff_gemm_2src_f32(A1, A2, lda, K1, Bt, ldb, C, ldc, mid, N, K, ep ? &lo : nullptr, stream);
+    if (rc) return rc;
+    return idiff_gemm_2src_f32(A1 + (int64_t)mid * lda, A2 + (int64_t)mid * lda, lda, K1, Bt, ldb, C + (int64_t)mid * ldc, ldc,
+                               M - mid, N, K, ep ? &hi : nullptr, stream);
+  }
   if (!vec || a1_bytes >= BUF_LIMIT || a2_bytes >= BUF_LIMIT || b_bytes >= BUF_LIMIT || getenv("IDIFF_NO_PIPE"))
-    return fail("gemm_2src: operands must be 16-byte aligned, K %% 4 == 0 and each below 4 GiB (use two idiff_gemm_f32 calls)");
+    return fail("gemm_2src: operands must be 16-byte aligned with K %% 4 == 0 and lda %% 4 == 0 (use two idiff_gemm_f32 calls)");
   IgemmParams p = {};
   p.A = A1; p.A2 = A2; p.K1 = K1; p.Bt = Bt; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
   p.a_bytes = (uint32_t)a1_bytes; p.a2_bytes = (uint32_t)a2_bytes; p.b_bytes = (uint32_t)b_bytes;

@@ -56,12 +56,12 @@ class ScoreMatrixBuilder:
         self.score_fn, self.sde, self.eps, self.device = score_fn, sde, sampling_eps, device
         self.inflight_rows = inflight_rows
 
-    def rows_per_launch(self, rows, sample_numel):
+    def rows_per_launch(self, rows, sample_numel, vector=False):
         if self.inflight_rows:
             return max(1, min(rows, int(self.inflight_rows)))
-        # default: all rows of a vector point; for images 2240 rows of 32x32x3 (measured best of 512..4480 on the
-        # nf=128 NCSN++: small-resolution levels reach the four-workgroup GEMM form) scaled by the sample size
-        if sample_numel <= 4096 and rows <= 65536:
+        # default: all rows of a vector point (the k-sphere MLPs); for images 2240 rows of 32x32x3 (measured best of
+        # 1120 / 2240 / 4480 on the nf=128 NCSN++: whole numbers of workgroups per CU at every level) scaled by the sample size
+        if vector and rows <= 65536:
             return rows
         return min(rows, max(128, (2240 * 3072) // sample_numel))
 
@@ -79,7 +79,7 @@ class ScoreMatrixBuilder:
         if row_range is not None and noise is None and (seed is None or D % 4):
             raise RuntimeError("a row range needs position-keyed noise: pass `seed` (and D % 4 == 0) or explicit `noise`")
         S = torch.empty(r_hi - r_lo, D, device=self.device, dtype=torch.float32)
-        step = self.rows_per_launch(rows, D)
+        step = self.rows_per_launch(rows, D, vector=x.ndim == 1)
         xf = x.reshape(-1).contiguous()
         for lo in range(r_lo, r_hi, step):
             n = min(step, r_hi - lo)

@@ -282,6 +282,23 @@ def test_gemm_two_sources(M, K1, K2, N):
                        torch.zeros(8, 4, device=DEV))
 
 
+def test_gemm_two_sources_beyond_4gib():
+    """Both sources past one buffer descriptor (a 4480-row launch set at 32x32x256 is 4.7 GB): rows are cut on the host."""
+    g = torch.Generator(device=DEV).manual_seed(2)
+    M, K1, N, grp = 4_300_000, 256, 64, 1000
+    a1 = torch.randn(M, K1, device=DEV, generator=g)
+    a2 = torch.randn(M, K1, device=DEV, generator=g)
+    w = torch.randn(N, 2 * K1, device=DEV, generator=g) / 23
+    rb = torch.randn(M // grp, N, device=DEV, generator=g)
+    out = torch.empty(M, N, device=DEV)
+    _lib.gemm_2src(a1, a2, w, out, epilogue=_lib.make_epilogue(rowbias=rb, rows_per_group=grp))
+    rows = torch.tensor([0, 1, M // 2 - 1, M // 2, M // 2 + 1, 3_000_000, M - 1], device=DEV)
+    ref = torch.cat([a1[rows], a2[rows]], 1).double().cpu() @ w.double().cpu().T + rb[rows // grp].double().cpu()
+    assert rel_err(out[rows].cpu(), ref) < 2e-6
+    del a1, a2, out
+    torch.cuda.empty_cache()
+
+
 def test_operands_beyond_4gib_are_split_on_the_host():
     """The fast kernel addresses operands through 32-bit-offset buffer descriptors; larger problems are cut into
     row / image ranges (igemm.hip: shift_epilogue).  Checked on the rows / images around the cut."""
