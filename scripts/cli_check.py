@@ -5,4 +5,8 @@ import id_diff_amd
 from id_diff_amd import plot_utils
 for f in glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "id-diff_amd", "logs", "**", "*.pkl"), recursive=True):
     d = pickle.load(open(f, "rb"))
-    print(f, len(d["singular_values"]), len(d["singular_values"][0]), plot_utils.plot_dims(d)[1])
+    try:
+        dims = plot_utils.plot_dims(d)[1]
+    except ZeroDivisionError:   # an all-zero spectrum (zero-initialised output conv of a random-weight BeatGANs U-Net): the
+        dims = "rule undefined"   # reference's rule divides by s[1] - s[2] too (plot_utils.py:175)
+    print(f, len(d["singular_values"]), len(d["singular_values"][0]), dims)
