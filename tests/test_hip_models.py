@@ -319,3 +319,26 @@ def test_driver_row_sharded_matches_point_sharded(tmp_path):
     for rank in (0, 1):
         np.testing.assert_allclose(np.array(got[rank]), np.array(ref['singular_values']), rtol=2e-5, atol=1e-5)
         assert plot_utils.plot_dims({'singular_values': got[rank]})[1] == [10] * 4
+
+
+def test_winograd_and_implicit_gemm_paths_agree_on_the_spectrum(monkeypatch):
+    """The benchmark network (nf = 128) on one data point, 3x3 convs once through Winograd F(2x2,3x3) and once through
+    the implicit GEMM (IDIFF_NO_WINOGRAD): score matrix, singular values (the 1e-4 bar of the north star) and ID."""
+    cfg = read_config('configs/dimension_estimation/paper/image_data/cifar_shaped/ncsnpp.py')
+    torch.manual_seed(0)
+    model = mutils.create_model(cfg).to(DEV).eval()
+    sde, eps = sde_lib.configure_sde(cfg)
+    builder = dim_reduction.ScoreMatrixBuilder(mutils.get_score_fn(sde, model), sde, eps, torch.device(DEV))
+    x = torch.rand(3, 32, 32, generator=torch.Generator().manual_seed(4)).to(DEV)
+    with torch.no_grad():
+        S_w = builder.build(x, 128, seed=9)
+        monkeypatch.setenv("IDIFF_NO_WINOGRAD", "1")
+        S_d = builder.build(x, 128, seed=9)
+        monkeypatch.delenv("IDIFF_NO_WINOGRAD")
+    assert S_w.shape == (4480, 3072)
+    assert not torch.equal(S_w, S_d)                      # different arithmetic ...
+    assert rel_err(S_w.cpu(), S_d.double().cpu()) < 2e-5  # ... same numbers
+    sv_w, sv_d = _lib.spectrum(S_w), _lib.spectrum(S_d)
+    big = sv_d > 1e-3 * sv_d[0]                          # the part of the spectrum the estimator can see
+    assert float(((sv_w - sv_d).abs() / sv_d)[big].max()) < 1e-4
+    assert plot_utils.estimate_dim(sv_w.tolist()) == plot_utils.estimate_dim(sv_d.tolist())
