@@ -34,6 +34,9 @@ def d_gemm(a, bt, out=None, epilogue=None, M=None, N=None, K=None, batch=1, **k)
     if M is None:
         M, K = a.shape; N = bt.shape[0]
     return (f"b{batch} M{M} N{N} K{K}", 2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N))
+def d_gemm2(a1, a2, bt, out, epilogue=None):
+    M, K, N = a1.shape[0], a1.shape[1] + a2.shape[1], bt.shape[0]
+    return (f"two-source M{M} N{N} K{K}", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N))
 def d_conv(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue=None, pad_hi=None):
     return (f"B{B} {H}x{W} {Cin}->{Cout} k{KH} s{stride}", 2.0 * out.numel() * Cin * KH * KW,
             4.0 * (B * H * W * Cin + out.numel()))
@@ -52,7 +55,7 @@ def d_generic(*a, **k):
     n = sum(4.0 * v.numel() for v in list(a) + list(k.values()) if torch.is_tensor(v))
     return ("", 0.0, n)
 
-wrap("gemm", d_gemm); wrap("conv2d_nhwc", d_conv); wrap("conv2d_winograd", d_wino); wrap("groupnorm_apply", d_gnapply); wrap("groupnorm_stats", d_gnstats)
+wrap("gemm", d_gemm); wrap("gemm_2src", d_gemm2); wrap("conv2d_nhwc", d_conv); wrap("conv2d_winograd", d_wino); wrap("groupnorm_apply", d_gnapply); wrap("groupnorm_stats", d_gnstats)
 wrap("upfirdn2d_raw", d_ufd); wrap("softmax_rows", d_soft)
 for nm in ("groupnorm_finalize", "affine_act", "add_scale", "fourier_embed", "positional_embed", "concat_cols", "nchw_to_nhwc",
            "nhwc_to_nchw", "resample2x_nhwc"):
