@@ -185,7 +185,9 @@ winograd_kernel(const WinoParams p) {
       acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[2 * j + 1], 0, 0, 0);
       acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[2 * j], 0, 0, 0);
       acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[2 * j + 1], 0, 0, 0);
-      if (s + 1 < nsteps) load_b(j, s + 1);      // the registers are free once these MFMAs have read them
+      // the registers are free once these MFMAs have read them; the last step re-requests its own slab (clamped, not
+      // skipped: no branch per position, and the scalar offset of a raw buffer is not range-checked, so it must stay valid)
+      load_b(j, min(s + 1, nsteps - 1));
     }
   };
 
