@@ -343,12 +343,12 @@ __global__ void tridiag_fused_tail_kernel(const double *__restrict__ A, int D, d
 // The stream pass touches every element once with 16-byte accesses and needs no LDS for the vectors (a thread
 // keeps the 3 x 2 vector entries of its two columns in registers), so it also serves D = 12288 (config 5), where
 // the Gram matrix (1.2 GB) no longer fits the Infinity Cache and three LDS-resident vectors would not fit a CU.
-constexpr int SEG_COLS = 512;
-constexpr int PREP_THREADS = 1024;
-constexpr int PREP_MAX_PER_THREAD = 12;          // D <= 12288
-constexpr int STREAM_D_MAX = PREP_THREADS * PREP_MAX_PER_THREAD;
+constexpr int SEG_CHUNKS = 8;                    // 512-column chunks per workgroup of the stream pass
+constexpr int SEG_COLS = 512 * SEG_CHUNKS;
+constexpr int PREP_THREADS = 512;
+constexpr int STREAM_D_MAX = 12288;              // config 5; nothing in the two kernels depends on it any more
 
-__device__ __forceinline__ double block_sum_1024(double v, double *buf /* >= 16 */) {
+__device__ __forceinline__ double block_sum_prep(double v, double *buf /* >= PREP_THREADS / 64 */) {
   v = wave_sum_d(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
@@ -359,59 +359,53 @@ __device__ __forceinline__ double block_sum_1024(double v, double *buf /* >= 16 
   return s;
 }
 
+// One 512-thread workgroup (two waves per SIMD at 34 registers: inside the 80 the convolutions leave free), two strided passes over the live indices, every per-index value re-read from memory instead
+// of being held in per-thread arrays: ~40 registers and 100 bytes of LDS.  That matters more than its own speed: the
+// spectrum runs on a side stream beside the score evaluations, whose convolution workgroups leave 80 registers per SIMD
+// and 32 KB of LDS free on every CU.  The former 1024-thread / 95-register form needed an EMPTY CU and got one only
+// when a convolution kernel drained: each of the 3072 steps then waited ~100 us and the spectrum of one point took as
+// long as all the score evaluations of the next (550 ms instead of 68), i.e. it set the pace of the whole pipeline.
 __global__ void __launch_bounds__(PREP_THREADS)
 tridiag_prep_kernel(const double *__restrict__ A, int D, int k, const double *__restrict__ v, const double *__restrict__ part,
                     int nseg, int direct_p, const double *__restrict__ tau_in, double *__restrict__ w,
                     double *__restrict__ v_next, double *__restrict__ tau_next, double *__restrict__ diag,
                     double *__restrict__ offd) {
-  __shared__ double red[16];
-  __shared__ double bc[2];
+  __shared__ double red[PREP_THREADS / 64];
+  __shared__ double bc[3];
   const int base = k + 1, tid = threadIdx.x;
   const double tau = *tau_in;
-  double pv[PREP_MAX_PER_THREAD], vv[PREP_MAX_PER_THREAD];
+  // pass 1: p = tau * (sum of the column-segment partials), parked in w[]; dot = p.v
   double dot = 0.0;
-#pragma unroll
-  for (int u = 0; u < PREP_MAX_PER_THREAD; ++u) {
-    const int g = base + tid + u * PREP_THREADS;
-    pv[u] = 0.0; vv[u] = 0.0;
-    if (g < D) {
-      double s = 0.0;
-      if (direct_p) s = part[g];
-      else { for (int sg = 0; sg < nseg; ++sg) s += part[(int64_t)sg * D + g]; s *= tau; }
-      pv[u] = s; vv[u] = v[g];
-      dot += s * vv[u];
-    }
+  for (int g = base + tid; g < D; g += PREP_THREADS) {
+    double sum = 0.0;
+    if (direct_p) sum = part[g];
+    else { for (int sg = 0; sg < nseg; ++sg) sum += part[(int64_t)sg * D + g]; sum *= tau; }
+    const double vg = v[g];
+    w[g] = sum;
+    dot += sum * vg;
+    if (g == base) { bc[0] = vg; bc[1] = sum; }
   }
-  const double K = 0.5 * tau * block_sum_1024(dot, red);
-  if (tid == 0) { bc[0] = vv[0]; bc[1] = pv[0] - K * vv[0]; }   // v[base], w[base]
-  __syncthreads();
-  const double v0 = bc[0], w0 = bc[1];
+  const double K = 0.5 * tau * block_sum_prep(dot, red);     // (its barriers also publish bc[0..1])
+  const double v0 = bc[0], w0 = bc[1] - K * v0;               // v[base], w[base]
+  // pass 2: w = p - K v; the updated first row of the block rv = A[base][g] - v0 w_g - w0 v_g becomes the next
+  // reflector's tail (parked in v_next[]); its squared norm beyond the leading element
   const double *row0 = A + (int64_t)base * D;
-  double rv[PREP_MAX_PER_THREAD];
   double tail = 0.0;
-#pragma unroll
-  for (int u = 0; u < PREP_MAX_PER_THREAD; ++u) {
-    const int g = base + tid + u * PREP_THREADS;
-    rv[u] = 0.0;
-    if (g < D) {
-      const double wg = pv[u] - K * vv[u];
-      w[g] = wg;
-      if (g > base) {
-        rv[u] = row0[g] - v0 * wg - w0 * vv[u];
-        if (g > base + 1) tail += rv[u] * rv[u];
-      }
+  for (int g = base + tid; g < D; g += PREP_THREADS) {
+    const double vg = v[g];
+    const double wg = w[g] - K * vg;                          // the same thread wrote w[g] in pass 1
+    w[g] = wg;
+    if (g > base) {
+      const double r = row0[g] - v0 * wg - w0 * vg;
+      v_next[g] = r;
+      if (g > base + 1) tail += r * r;
+      else bc[2] = r;                                         // g == base + 1: the leading element
     }
   }
-  const double tail_sq = block_sum_1024(tail, red);
-  if (tid == 1) bc[0] = rv[0];                                   // thread 1, u = 0 holds g = base + 1
-  __syncthreads();
-  const Reflector h = make_reflector(bc[0], tail_sq);
-#pragma unroll
-  for (int u = 0; u < PREP_MAX_PER_THREAD; ++u) {
-    const int g = base + tid + u * PREP_THREADS;
-    if (g < D && g > base) v_next[g] = (g == base + 1) ? h.v0 : rv[u];
-  }
+  const double tail_sq = block_sum_prep(tail, red);
   if (tid == 0) {
+    const Reflector h = make_reflector(base + 1 < D ? bc[2] : 0.0, tail_sq);
+    if (base + 1 < D) v_next[base + 1] = h.v0;
     *tau_next = h.tau;
     diag[k + 1] = row0[base] - 2.0 * v0 * w0;
     offd[k + 1] = h.alpha;
@@ -426,25 +420,32 @@ tridiag_stream_kernel(double *__restrict__ A, int D, int k, const double *__rest
   const int lo = k + 2;                       // first live row / column of the shrunken block
   const int galign = lo & ~1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g0 = galign + blockIdx.y * SEG_COLS + 2 * tid;   // this thread's column pair (g0, g0+1), g0 even
-  const bool in0 = g0 >= lo && g0 < D, in1 = g0 + 1 >= lo && g0 + 1 < D;
-  double vj0 = 0, vj1 = 0, wj0 = 0, wj1 = 0, xj0 = 0, xj1 = 0;
-  if (in0) { vj0 = v[g0]; wj0 = w[g0]; xj0 = x[g0]; }
-  if (in1) { vj1 = v[g0 + 1]; wj1 = w[g0 + 1]; xj1 = x[g0 + 1]; }
   const int i0 = lo + blockIdx.x * R;
   double acc[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    acc[r] = 0.0;
-    const int gi = i0 + r;
-    if (gi < D && (in0 || in1)) {
-      const double vi = v[gi], wi = w[gi];
-      double2 *ap = reinterpret_cast<double2 *>(A + (int64_t)gi * D + g0);
-      double2 a = *ap;
-      a.x -= vi * wj0 + wi * vj0;             // masked columns carry zeros: the element is rewritten unchanged
-      a.y -= vi * wj1 + wi * vj1;
-      *ap = a;
-      acc[r] = a.x * xj0 + a.y * xj1;
+  for (int r = 0; r < R; ++r) acc[r] = 0.0;
+  // a workgroup sweeps SEG_CHUNKS chunks of 512 columns for its R rows: one partial per (segment, row) instead of one
+  // per 512 columns, i.e. four times fewer values for the single-workgroup prep pass to gather
+#pragma unroll 1
+  for (int c = 0; c < SEG_CHUNKS; ++c) {
+    const int g0 = galign + (blockIdx.y * SEG_CHUNKS + c) * 512 + 2 * tid;   // this thread's column pair (g0, g0+1), g0 even
+    if (g0 >= D) break;
+    const bool in0 = g0 >= lo, in1 = g0 + 1 >= lo && g0 + 1 < D;
+    double vj0 = 0, vj1 = 0, wj0 = 0, wj1 = 0, xj0 = 0, xj1 = 0;
+    if (in0) { vj0 = v[g0]; wj0 = w[g0]; xj0 = x[g0]; }
+    if (in1) { vj1 = v[g0 + 1]; wj1 = w[g0 + 1]; xj1 = x[g0 + 1]; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int gi = i0 + r;
+      if (gi < D && (in0 || in1)) {
+        const double vi = v[gi], wi = w[gi];
+        double2 *ap = reinterpret_cast<double2 *>(A + (int64_t)gi * D + g0);
+        double2 a = *ap;
+        a.x -= vi * wj0 + wi * vj0;             // masked columns carry zeros: the element is rewritten unchanged
+        a.y -= vi * wj1 + wi * vj1;
+        *ap = a;
+        acc[r] += a.x * xj0 + a.y * xj1;
+      }
     }
   }
 #pragma unroll

@@ -47,16 +47,19 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 
-constexpr int WG_TILES = 64;
+constexpr int WG_TILES = 32;                      // 32: two workgroups per CU (see the header); 64 also builds
+constexpr int THREADS = WG_TILES * 8;
+constexpr int NWAVES = THREADS / 64;
 constexpr int WG_COUT = 64;
 constexpr int KC = 8;
 constexpr int NPOS = 16;
 constexpr int OPER_FLOATS = NPOS * 64 * KC;       // one operand of one stage in HBM order: 8192 floats = 32 KB
-constexpr int V_SLOT = 64 * KC + 8;               // LDS floats per position slot of V (see above)
+constexpr int V_SLOT = WG_TILES * KC + 8;         // LDS floats per position slot of V (see above); = 8 mod 32
 constexpr int U_SLOT = 64 * KC;
 constexpr int V_FLOATS = NPOS * V_SLOT;           // 8320
-constexpr int STAGE_FLOATS = V_FLOATS + NPOS * U_SLOT;   // V then U: 16512 floats
-constexpr size_t LDS_BYTES = (size_t)2 * STAGE_FLOATS * sizeof(float);   // 129 KB
+constexpr int STAGE_FLOATS = V_FLOATS;            // U never touches LDS
+constexpr int TAIL_FLOATS = 4 * WG_TILES * 2 * 64;     // the tail's exchange: [4 rows][tiles][2][64 cout]
+constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(2 * STAGE_FLOATS > TAIL_FLOATS ? 2 * STAGE_FLOATS : TAIL_FLOATS);   // 64 KB
 constexpr int64_t X_LIMIT = 0xFFFF0000ll;          // one buffer descriptor, with room for the invalid-pixel bias
 constexpr uint32_t INVALID_PIXEL = 0xFFFF8000u;    // beyond any valid extent (the scalar step offset is not range-checked)
 
@@ -75,7 +78,7 @@ struct WinoParams {
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(THREADS, 2)   // two waves per SIMD (256 VGPRs): two 256-thread workgroups per CU
 winograd_kernel(const WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -97,7 +100,7 @@ winograd_kernel(const WinoParams p) {
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
 
   // ---------------------------------------------------------------- loader state
-  const bool early = wave < 4;    // waves w and w+4 share a SIMD: one transforms while the other feeds the matrix pipe
+  const bool early = wave < NWAVES / 2;    // waves w and w+4 share a SIMD: one transforms while the other feeds the matrix pipe
   uint32_t v_src[4], u_src[4];
   int v_dst;
   float sgn;
@@ -259,7 +262,7 @@ winograd_kernel(const WinoParams p) {
 
   // z_ib for this wave's row i: z_i0 = m_i0 + m_i1 + m_i2, z_i1 = m_i1 - m_i2 - m_i3 -> LDS [i][tile][b][cout]
   {
-    float *zp = lds + ((wi * 64 + tb * 32 + 4 * (lane >> 5)) * 2) * 64 + (lane & 31);
+    float *zp = lds + ((wi * WG_TILES + tb * 32 + 4 * (lane >> 5)) * 2) * 64 + (lane & 31);
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
@@ -279,9 +282,9 @@ winograd_kernel(const WinoParams p) {
     for (int b = 0; b < 2; ++b) {
       const float *zr = lds + ((2 * g + t) * 2 + b) * 64 + 4 * cq;
       const float4 z0 = *reinterpret_cast<const float4 *>(zr);
-      const float4 z1 = *reinterpret_cast<const float4 *>(zr + 1 * 64 * 2 * 64);
-      const float4 z2 = *reinterpret_cast<const float4 *>(zr + 2 * 64 * 2 * 64);
-      const float4 z3 = *reinterpret_cast<const float4 *>(zr + 3 * 64 * 2 * 64);
+      const float4 z1 = *reinterpret_cast<const float4 *>(zr + 1 * WG_TILES * 2 * 64);
+      const float4 z2 = *reinterpret_cast<const float4 *>(zr + 2 * WG_TILES * 2 * 64);
+      const float4 z3 = *reinterpret_cast<const float4 *>(zr + 3 * WG_TILES * 2 * 64);
       if (!t_ok[t]) continue;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -323,7 +326,7 @@ winograd_kernel(const WinoParams p) {
       s2[e] += __shfl_xor(s2[e], 16, 64); s2[e] += __shfl_xor(s2[e], 32, 64);
     }
     __syncthreads();                                          // every z has been read: the area is free again
-    double *red = reinterpret_cast<double *>(lds);           // [8 waves][64][2]
+    double *red = reinterpret_cast<double *>(lds);           // [NWAVES][64][2]
     if (lane < 16) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -335,7 +338,7 @@ winograd_kernel(const WinoParams p) {
     if (tid < WG_COUT) {
       double a = 0.0, b = 0.0;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) { a += red[(w * WG_COUT + tid) * 2]; b += red[(w * WG_COUT + tid) * 2 + 1]; }
+      for (int w = 0; w < NWAVES; ++w) { a += red[(w * WG_COUT + tid) * 2]; b += red[(w * WG_COUT + tid) * 2 + 1]; }
       double *dst = ep.colstats + ((int64_t)tile_m * p.Cout + n0 + tid) * 2;
       dst[0] = a; dst[1] = b;
     }
@@ -452,6 +455,6 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
     if (e != hipSuccess) { set_error("conv2d_winograd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(winograd_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(winograd_kernel, dim3(p.tiles_m * p.tiles_n), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, p);
   return launch_status("conv2d_winograd");
 }

@@ -248,7 +248,7 @@ def test_winograd_colstats_feed_groupnorm(B, H, Cin, Cout):
     w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(DEV)
     bias = torch.randn(Cout, generator=g).to(DEV)
     ns = _lib.conv2d_winograd_colstats_split(B, H, H, Cin, Cout)
-    assert ns == H * H // 256
+    assert ns in (H * H // 256, H * H // 128)          # 64 or 32 output tiles (of 2x2 pixels) per workgroup
     cs = torch.empty(B * ns * Cout * 2, device=DEV, dtype=torch.float64)
     out = torch.empty(B, H * H, Cout, device=DEV)
     _lib.conv2d_winograd(x, _lib.winograd_pack(w, Cin, Cout), out, B, H, H, Cin, Cout,
@@ -263,7 +263,7 @@ def test_winograd_colstats_feed_groupnorm(B, H, Cin, Cout):
     tot = cs.view(B, ns, Cout, 2).sum(1)
     np.testing.assert_allclose(tot[..., 0].cpu().numpy(), out.double().sum(1).cpu().numpy(), rtol=1e-12, atol=1e-9)
     np.testing.assert_allclose(tot[..., 1].cpu().numpy(), (out.double() ** 2).sum(1).cpu().numpy(), rtol=1e-12, atol=1e-9)
-    assert _lib.conv2d_winograd_colstats_split(64, 8, 8, Cin, Cout) == 0     # 16 tiles per sample < one workgroup
+    assert _lib.conv2d_winograd_colstats_split(64, 4, 4, Cin, Cout) == 0     # 4 tiles per sample < one workgroup
 
 
 @pytest.mark.parametrize("M,K1,K2,N", [(1000, 128, 128, 128), (4100, 256, 256, 64), (77, 32, 32, 200)])
