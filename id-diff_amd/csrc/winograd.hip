@@ -15,7 +15,10 @@
 //   64 cycles x (fp32 MFMAs) + ~6.5 cycles x (every other instruction its waves issue) -- fp32 MFMAs run on the
 //   same fp32 lanes as the VALU and nothing overlaps them -- so the design minimises non-MFMA instructions per MFMA.
 //
-// Workgroup: 512 threads = 8 waves = 4 (rows i of the 4x4 transform domain) x 2 (32-tile halves); a wave holds
+// Workgroup (WG_TILES = 32): 256 threads = 4 waves = the 4 rows i of the 4x4 transform domain, 32 tiles x 64 channels,
+//   64 KB of LDS, 216 registers -> TWO workgroups per CU, each one's prologue and tail running under the other's K loop
+//   (WG_TILES = 64, 8 waves with 2 tile halves and one workgroup per CU, also builds: 2-4 % slower, 10 % on 4x4 maps, but
+//   half as many workgroups stream each filter slab).  A wave holds
 //   4 positions (i, 0..3) x [32 tiles x 64 channels] = 8 MFMA tiles = 128 accumulators, and per 8-channel step issues
 //   32 MFMAs from 4 sixteen-byte LDS reads of V and 8 sixteen-byte global loads of U (each lane half feeds four
 //   consecutive channels to four successive MFMAs, the order of the k-reduction being free; one V fragment serves both
@@ -25,17 +28,17 @@
 //   32 channels x 32 bytes a half wave needs for one MFMA operand are contiguous, and each lane loads its own fragments
 //   (8 x 16 bytes per step) straight into the registers the MFMAs read, re-requesting a position's pair for the next
 //   step as soon as that position's MFMAs have issued (4 + 4 LDS writes and 8 LDS reads per wave-step fewer than the
-//   staged form: +4 %).  The allocation stays 129 KB because the tail's exchange needs 128 KB.
-// Loader: every thread owns row r of the 4x4 patch of one (tile, 4-channel quad) unit -- 64 x 2 x 4 = 512.  The four
+//   staged form: +4 %).  The allocation is what the tail's exchange needs (64 KB at 32 tiles).
+// Loader: every thread owns row r of the 4x4 patch of one (tile, 4-channel quad) unit -- tiles x 2 x 4 threads.  The four
 //   rows of a unit are the four lanes of a DPP quad: column mixing is local (16 VALU), row mixing is one v_fmac_f32_dpp per value (quad_perm:[2,2,1,1], signs
 //   -1,+1,-1,-1; row 3 comes out negated and the packed U carries the same sign).  Per-step address offsets ride in the
-//   buffer instructions' scalar offset.  Waves w and w+4 share a SIMD: one transforms at the start of a step, the other
-//   at the end, so the matrix pipe always has the partner's MFMAs.
+//   buffer instructions' scalar offset.  Half of the waves transform at the start of a step, the other half at the end,
+//   so that the matrix pipe of a SIMD always has some wave's MFMAs.
 // LDS rows are 32 bytes (8 channels); the two 16-byte halves of row r are swapped when bit 3 of r is set (in LDS for V,
 //   in the packed slab for U), which makes the ds_read_b128 of a 32-row MFMA operand conflict-free, and the V slot pitch
 //   of 520 floats makes the four rows' ds_write_b128 conflict-free (lane groups per instruction: MI355X_MICROARCH.md section LDS).
-// Tail: each wave mixes its row over j (z_ib), the four rows meet in LDS ([4 rows][64 tiles][2][64 cout], 128 KB over
-//   the dead stage buffers), and every thread finishes float4 runs of 4 channels: Y[0][b] = z0b + z1b + z2b,
+// Tail: each wave mixes its row over j (z_ib), the four rows meet in LDS ([4 rows][tiles][2][64 cout], over the dead
+//   stage buffers), and every thread finishes float4 runs of 4 channels: Y[0][b] = z0b + z1b + z2b,
 //   Y[1][b] = z1b - z2b - z3b, fused epilogue (bias, per-sample bias, activation, residual, scales, optional per-tile
 //   column statistics), 16-byte stores -- the one-dword-per-lane store tail of the first version was store-issue bound
 //   (29.8k of 131k cycles per workgroup at Cin = 128).
