@@ -715,8 +715,10 @@ IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double
                            nseg_prev, k == 0 ? 1 : 0, tb + cur, wv, vb[nxt], tb + nxt, dg, od);
         const int lo = k + 2, galign = lo & ~1;
         const int rows = D - lo, nseg = ceil_div(D - galign, SEG_COLS);
-        if (rows >= 8 * 96)
-          hipLaunchKernelGGL(tridiag_stream_kernel<8>, dim3(ceil_div(rows, 8), nseg), dim3(256), 0, st, A, D, k, vb[cur], wv, vb[nxt], part);
+        // rows per workgroup: 4 while the block is tall, 2 near the end (8 rows per workgroup left too few workgroups in
+        // flight for a bandwidth-bound pass: 63.8 -> 57.4 ms at D = 3072, 2.62 -> 2.48 s at D = 12288)
+        if (rows >= 768)
+          hipLaunchKernelGGL(tridiag_stream_kernel<4>, dim3(ceil_div(rows, 4), nseg), dim3(256), 0, st, A, D, k, vb[cur], wv, vb[nxt], part);
         else
           hipLaunchKernelGGL(tridiag_stream_kernel<2>, dim3(ceil_div(rows, 2), nseg), dim3(256), 0, st, A, D, k, vb[cur], wv, vb[nxt], part);
         nseg_prev = nseg;
