@@ -542,7 +542,7 @@ __device__ __forceinline__ void sturm_renorm(SturmState &s) {
   }
 }
 
-template <bool LDS>
+template <bool LDS, int G>
 __global__ void __launch_bounds__(256)
 bisect_kernel(const double *__restrict__ diag, const double *__restrict__ offd, int D, double *__restrict__ eig,
               float *__restrict__ sv) {
@@ -574,15 +574,17 @@ bisect_kernel(const double *__restrict__ diag, const double *__restrict__ offd, 
     }
     __syncthreads();
   }
-  const int j = blockIdx.x * 256 + tid;
+  // G = 1: one thread per eigenvalue, plain bisection (the batched k-sphere case already fills the chip).
+  // G = 8: eight adjacent lanes share an eigenvalue and probe the bracket at a + (b - a) * (1..8) / 8 in one sweep: three
+  //        bits per sweep instead of one.  A sweep is ISSUE bound (3 fp64 + 4 integer instructions per step), so when one
+  //        matrix leaves most SIMDs idle, 8x the threads cost nothing and the 45 dependent sweeps become ~16.
+  const int j = (blockIdx.x * 256 + tid) / G, sub = tid % G;
   if (j >= D) return;
   // normalised bracket, widened by the rounding of the Gershgorin sums
   double a = lo * inv - 2.3e-16 * (double)D, b = hi * inv + 2.3e-16 * (double)D;
-  for (int it = 0; it < 120; ++it) {
-    const double mid = 0.5 * (a + b);
-    if (mid <= a || mid >= b) break;
+  auto count_below = [&](double x) -> int {
     SturmState s;
-    s.pm = 1.0; s.pc = (LDS ? sh2[0].x : d[0] * inv) - mid; s.count = (unsigned)__double2hiint(s.pc) >> 31;
+    s.pm = 1.0; s.pc = (LDS ? sh2[0].x : d[0] * inv) - x; s.count = (unsigned)__double2hiint(s.pc) >> 31;
     int i = 1;
     if (LDS) {
       double2 cur[8], nxt[8];
@@ -597,23 +599,48 @@ bisect_kernel(const double *__restrict__ diag, const double *__restrict__ offd, 
           for (int u = 0; u < 8; ++u) nxt[u] = sh2[i + 8 + u];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sturm_step(s, cur[u].x, cur[u].y, mid);
+        for (int u = 0; u < 8; ++u) sturm_step(s, cur[u].x, cur[u].y, x);
         sturm_renorm(s);
         if (more) {
 #pragma unroll
           for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
         }
       }
-      for (; i < D; ++i) sturm_step(s, sh2[i].x, sh2[i].y, mid);
+      for (; i < D; ++i) sturm_step(s, sh2[i].x, sh2[i].y, x);
     } else {
       for (; i < D; ++i) {
         const double ev = e[i - 1] * inv;
-        sturm_step(s, d[i] * inv, ev * ev, mid);
+        sturm_step(s, d[i] * inv, ev * ev, x);
         if ((i & 7) == 0) sturm_renorm(s);
       }
     }
-    if (s.count > j) b = mid; else a = mid;
-    if (b - a <= 1e-13 * fmax(fabs(a), fabs(b)) + 1e-22) break;
+    return s.count;
+  };
+  if (G == 1) {
+    for (int it = 0; it < 120; ++it) {
+      const double mid = 0.5 * (a + b);
+      if (mid <= a || mid >= b) break;
+      if (count_below(mid) > j) b = mid; else a = mid;
+      if (b - a <= 1e-13 * fmax(fabs(a), fabs(b)) + 1e-22) break;
+    }
+  } else {
+    const int lane = tid & 63;
+    bool done = false;
+    for (int it = 0; it < 48; ++it) {
+      const double w8 = (b - a) * (1.0 / G);
+      const double x = sub == G - 1 ? b : a + w8 * (double)(sub + 1);
+      const bool above = count_below(x) > j;                     // lambda_j < x
+      const unsigned long long m = __ballot(above);
+      const unsigned bits = (unsigned)(m >> (lane & ~(G - 1))) & ((1u << G) - 1u);
+      const int f = bits ? __ffs(bits) - 1 : G - 1;              // counts are monotone in x: first probe above lambda_j
+      const double na = f == 0 ? a : a + w8 * (double)f;
+      const double nb = f == G - 1 ? b : a + w8 * (double)(f + 1);
+      if (!(nb - na < b - a)) done = true;                       // no representable progress left
+      a = na; b = nb;
+      if (b - a <= 1e-13 * fmax(fabs(a), fabs(b)) + 1e-22) done = true;
+      if (__all(done)) break;                                    // the groups of a wave leave together (ballot needs them)
+    }
+    if (sub != 0) return;
   }
   const double lam = 0.5 * (a + b) * span;
   if (eig) eig[(int64_t)p * D + j] = lam;
@@ -629,17 +656,23 @@ int bisect_launch(const double *diag, const double *offd, int P, int D, double *
   const size_t lds = use_lds ? (size_t)D * sizeof(double2) : 0;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel<true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel<true, 1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(double2));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel<true, 8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(double2));
     if (e != hipSuccess) { idiff::set_error("bisect: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
   // 64 eigenvalues per workgroup would spread the work over more CUs, but the chain length (D steps per
   // bisection) is the latency; 256 threads keep the broadcast LDS traffic low.
-  if (use_lds)
-    hipLaunchKernelGGL(bisect_kernel<true>, dim3(idiff::ceil_div(D, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv);
-  else
-    hipLaunchKernelGGL(bisect_kernel<false>, dim3(idiff::ceil_div(D, 256), P), dim3(256), 0, st, diag, offd, D, eig, sv);
+  const bool few = (int64_t)P * idiff::ceil_div(D, 256) <= 64;     // most SIMDs would idle: 8 lanes per eigenvalue
+  if (use_lds && few)
+    hipLaunchKernelGGL((bisect_kernel<true, 8>), dim3(idiff::ceil_div(D * 8, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv);
+  else if (use_lds)
+    hipLaunchKernelGGL((bisect_kernel<true, 1>), dim3(idiff::ceil_div(D, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv);
+  else   // D > 8192 streams (d, e) from L2 per thread: eight times the threads made it slower (2.48 -> 2.58 s at D = 12288)
+    hipLaunchKernelGGL((bisect_kernel<false, 1>), dim3(idiff::ceil_div(D, 256), P), dim3(256), 0, st, diag, offd, D, eig, sv);
   return idiff::launch_status("bisect");
 }
 

@@ -58,7 +58,6 @@ constexpr int KC = 8;
 constexpr int NPOS = 16;
 constexpr int OPER_FLOATS = NPOS * 64 * KC;       // one operand of one stage in HBM order: 8192 floats = 32 KB
 constexpr int V_SLOT = WG_TILES * KC + 8;         // LDS floats per position slot of V (see above); = 8 mod 32
-constexpr int U_SLOT = 64 * KC;
 constexpr int V_FLOATS = NPOS * V_SLOT;           // 8320
 constexpr int STAGE_FLOATS = V_FLOATS;            // U never touches LDS
 constexpr int TAIL_FLOATS = 4 * WG_TILES * 2 * 64;     // the tail's exchange: [4 rows][tiles][2][64 cout]
@@ -170,7 +169,6 @@ winograd_kernel(const WinoParams p) {
   const int fr = lane & 31, fh = lane >> 5;
   const int frag = fr * KC + 4 * (fh ^ ((fr >> 3) & 1));
   const int a_frag = wi * V_SLOT + tb * 32 * KC + frag;       // slot of position (wi, j): 4j + wi
-  const int b_frag = V_FLOATS + wi * U_SLOT + frag;
 
   auto load_b = [&](int j, int step) {
     const int slab = (step * p.tiles_n + tile_n) * (OPER_FLOATS * 4);
