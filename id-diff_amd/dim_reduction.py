@@ -102,29 +102,43 @@ class ScoreMatrixBuilder:
 
 class SpectrumPipeline:
     """Runs the spectrum of point p on a side HIP stream while the score evaluations of point p+1 fill the
-    main stream: the tridiagonalisation is a chain of ~D short bandwidth-bound launches that leaves most CUs
-    idle, the convolutions are MFMA-bound -- the two overlap almost for free."""
+    main stream: the tridiagonalisation is a chain of ~2D short bandwidth-bound launches that leaves most CUs
+    idle, the convolutions are MFMA-bound -- the two overlap almost for free.
+
+    The spectrum of a point is ENQUEUED one ``submit`` late, i.e. after the next point's score evaluations have been
+    queued: its ~6000 launches do not fit the side stream's hardware queue, so the enqueueing host thread blocks until
+    the spectrum is nearly done -- and while it did that right after point p, nothing of point p+1 had been queued yet and
+    the main stream sat idle for the length of a spectrum at every point boundary (72 ms gaps in the rocprofv3 trace)."""
 
     def __init__(self, device, overlap=True):
         self.device = device
         self.side = torch.cuda.Stream(device=device) if overlap else None
         self.pending = []
+        self.deferred = None      # (S, ready event) of the last submitted point, not yet enqueued
+
+    def _launch(self, S, ready):
+        self.side.wait_event(ready)                      # S is complete on the producing stream
+        with torch.cuda.stream(self.side):
+            sv = _lib.spectrum(S)
+        S.record_stream(self.side)                       # keep S alive until the side stream is done with it
+        self.pending.append(sv)
 
     def submit(self, S):
         if self.side is None:
             self.pending.append(_lib.spectrum(S))
             return
         ready = torch.cuda.Event()
-        ready.record()                                   # S is complete on the producing stream
-        self.side.wait_event(ready)
-        with torch.cuda.stream(self.side):
-            sv = _lib.spectrum(S)
-        S.record_stream(self.side)                       # keep S alive until the side stream is done with it
-        self.pending.append(sv)
+        ready.record()
+        previous, self.deferred = self.deferred, (S, ready)
+        if previous is not None:
+            self._launch(*previous)
 
     def results(self):
         """All submitted spectra, in order; joins the side stream into the current one."""
         if self.side is not None:
+            if self.deferred is not None:
+                self._launch(*self.deferred)
+                self.deferred = None
             torch.cuda.current_stream().wait_stream(self.side)
         out, self.pending = self.pending, []
         return out
