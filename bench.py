@@ -154,7 +154,7 @@ def main():
     pipe = dim_reduction.SpectrumPipeline(dev, overlap=not args.no_overlap)
 
     def one_point(i, timed):
-        # sample the dominant kernel on the first launch set of every timed step
+        # sample the dominant kernel's launches of every timed step
         if timed:
             probe.active = True
         S = builder.build(images[i], B, seed=1234 + 1000003 * (i + 1) + rank)
@@ -166,14 +166,10 @@ def main():
     state = {"calls": 0}
 
     def sampled_score_fn(x, t):
-        # sample one launch set per step: the last one (the first overlaps the previous point's spectrum)
-        first = state["calls"] == n_chunks - 1
+        # every launch set of a timed step is sampled (the first runs beside the previous point's spectrum, the last
+        # mostly alone), so that the average is over the same launches rocprofv3 --stats averages
         state["calls"] += 1
-        was = probe.active
-        probe.active = was and first
-        out = orig_score_fn(x, t)
-        probe.active = was
-        return out
+        return orig_score_fn(x, t)
 
     builder.score_fn = sampled_score_fn
     n_chunks = (rows + builder.rows_per_launch(rows, D) - 1) // builder.rows_per_launch(rows, D)
