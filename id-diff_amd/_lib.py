@@ -30,6 +30,7 @@ class Epilogue(ctypes.Structure):
 _SIGNATURES = {
     "idiff_abi_version": (c_i, []),
     "idiff_last_error": (ctypes.c_char_p, []),
+    "idiff_set_option": (c_i, [ctypes.c_char_p, c_i]),
     "idiff_upfirdn2d_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 14 + [c_p]),
     "idiff_fused_bias_act_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "idiff_gemm_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i,
@@ -99,6 +100,14 @@ def lib():
             raise RuntimeError("libidiff_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib
+
+
+def set_option(name, value):
+    """Flip a library debug switch (``IDIFF_NO_WINOGRAD`` ...); returns the previous value."""
+    prev = lib().idiff_set_option(name.encode(), int(bool(value)))
+    if prev < 0:
+        raise KeyError(f"unknown libidiff_hip option {name!r}")
+    return bool(prev)
 
 
 def _check(rc, what):

@@ -33,6 +33,17 @@ inline int launch_status(const char *what) {
   return 0;
 }
 
+// ---- process-level debug switches (A/B experiments, parity tests).  Read from the environment ONCE, when the library
+// is loaded (no getenv on any launch path); idiff_set_option() flips them afterwards.
+enum Option { OPT_NO_WINOGRAD, OPT_NO_COLSTATS, OPT_NO_PIPE, OPT_SCALAR_EPILOGUE, OPT_DBUF_ONLY, OPT_TRIDIAG_ONESTAGE,
+              OPT_UFD_ROWS, OPT_COUNT };
+bool option(Option o);
+
+// hipFuncSetAttribute is per DEVICE: one bit per device ordinal, so a process that drives several GPUs sets the
+// attribute on each of them (a process-wide `static bool` would leave the second device at the 64 KB default).
+struct AttrGuard { unsigned long long done_mask = 0; };
+int set_dynamic_lds_once(AttrGuard &g, const void *const *fns, int n_fns, int bytes, const char *what);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -250,15 +250,10 @@ int launch_cfg(IgemmParams &p, int batch, hipStream_t st) {
   p.tiles_n = idiff::ceil_div(p.N, BN);
   constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * LDS_PITCH * sizeof(float);
   auto kern = igemm_kernel<BM, BN, WARPS_M, WARPS_N, CONV, VEC>;
-  static bool attr_set = false;  // idempotent; a benign race sets it twice at worst
-  if (lds_bytes > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) {
-      idiff::set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return (int)e;
-    }
-    attr_set = true;
+  if (lds_bytes > 64 * 1024) {
+    static idiff::AttrGuard guard;                 // one per template instantiation, one bit per device
+    const void *fn = reinterpret_cast<const void *>(kern);
+    if (int rc = idiff::set_dynamic_lds_once(guard, &fn, 1, (int)lds_bytes, "igemm")) return rc;
   }
   dim3 grid(p.tiles_m * p.tiles_n, batch);
   hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds_bytes, st, p);
@@ -596,22 +591,17 @@ int launch_pipe(IgemmParams &p, int batch, hipStream_t st) {
   p.tiles_n = idiff::ceil_div(p.N, BN);
   constexpr size_t lds_bytes = (size_t)(DBUF ? 2 : 1) * (BM + BN) * LDS_PITCH * sizeof(float);
   auto kern = igemm_pipe_kernel<BM, BN, WARPS_M, WARPS_N, CONV, DBUF>;
-  static bool attr_set = false;
-  if (lds_bytes > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) {
-      idiff::set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return (int)e;
-    }
-    attr_set = true;
+  if (lds_bytes > 64 * 1024) {
+    static idiff::AttrGuard guard;                 // one per template instantiation, one bit per device
+    const void *fn = reinterpret_cast<const void *>(kern);
+    if (int rc = idiff::set_dynamic_lds_once(guard, &fn, 1, (int)lds_bytes, "igemm")) return rc;
   }
   {
     const idiff_epilogue &e = p.ep;
     const bool al = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.strideC % 4 == 0) && aligned16(p.C) &&
                     (!p.has_ep || ((!e.bias || aligned16(e.bias)) && (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) &&
                                    (!e.residual || (aligned16(e.residual) && e.ld_residual % 4 == 0))));
-    p.vec_ep = al && !getenv("IDIFF_SCALAR_EPILOGUE");
+    p.vec_ep = al && !idiff::option(idiff::OPT_SCALAR_EPILOGUE);
   }
   dim3 grid(p.tiles_m * p.tiles_n, batch);
   hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds_bytes, st, p);
@@ -632,7 +622,7 @@ int dispatch_pipe(IgemmParams &p, int batch, hipStream_t st) {
   const int64_t wg_big = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 128) * batch;
   // >= 4 workgroups per CU available: single LDS buffer, 128 registers, four resident workgroups per CU
   // (measured 135-142 TFLOP/s vs 124-135 for the double-buffered two-workgroup form)
-  if (p.N > 64 && wg_big >= 1024 && !getenv("IDIFF_DBUF_ONLY")) return launch_pipe<128, 128, 2, 2, CONV, false>(p, batch, st);
+  if (p.N > 64 && wg_big >= 1024 && !idiff::option(idiff::OPT_DBUF_ONLY)) return launch_pipe<128, 128, 2, 2, CONV, false>(p, batch, st);
   if (p.N > 64 && wg_big >= 256) return launch_pipe<128, 128, 2, 2, CONV>(p, batch, st);
   // narrow outputs (the 3-channel image conv at the end of the U-Nets): one 32-wide MFMA column instead of two
   if (p.N <= 32 && p.M >= 4096) return launch_pipe<128, 32, 4, 1, CONV>(p, batch, st);
@@ -696,7 +686,7 @@ IDIFF_API int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const
                    aligned16(A) && aligned16(Bt);
   hipStream_t st = (hipStream_t)stream;
   const int64_t a_bytes = ((int64_t)(M - 1) * lda + K) * 4, b_bytes = ((int64_t)(N - 1) * ldb + K) * 4;
-  if (vec && batch == 1 && a_bytes >= BUF_LIMIT && b_bytes < BUF_LIMIT && !getenv("IDIFF_NO_PIPE")) {
+  if (vec && batch == 1 && a_bytes >= BUF_LIMIT && b_bytes < BUF_LIMIT && !idiff::option(idiff::OPT_NO_PIPE)) {
     if (ep && ep->colstats) return fail("gemm: colstats is not available for operands beyond 4 GiB");
     const int rpg = (ep && ep->rows_per_group > 0) ? ep->rows_per_group : 1;
     const int mid = (M / 2 / rpg) * rpg;
@@ -709,7 +699,7 @@ IDIFF_API int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const
                             ep ? &hi : nullptr, stream);
     }
   }
-  if (vec && a_bytes < BUF_LIMIT && b_bytes < BUF_LIMIT && !getenv("IDIFF_NO_PIPE")) {
+  if (vec && a_bytes < BUF_LIMIT && b_bytes < BUF_LIMIT && !idiff::option(idiff::OPT_NO_PIPE)) {
     p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
     return dispatch_pipe<false>(p, batch, st);
   }
@@ -729,7 +719,7 @@ IDIFF_API int idiff_gemm_2src_f32(const float *A1, const float *A2, int64_t lda,
   const int64_t a1_bytes = ((int64_t)(M - 1) * lda + K1) * 4, a2_bytes = ((int64_t)(M - 1) * lda + (K - K1)) * 4;
   const int64_t b_bytes = ((int64_t)(N - 1) * ldb + K) * 4;
   const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A1) && aligned16(A2) && aligned16(Bt);
-  if (vec && (a1_bytes >= BUF_LIMIT || a2_bytes >= BUF_LIMIT) && b_bytes < BUF_LIMIT && M > 1 && !getenv("IDIFF_NO_PIPE")) {
+  if (vec && (a1_bytes >= BUF_LIMIT || a2_bytes >= BUF_LIMIT) && b_bytes < BUF_LIMIT && M > 1 && !idiff::option(idiff::OPT_NO_PIPE)) {
     // rows are independent: cut them until each half fits one buffer descriptor (as idiff_gemm_f32 does)
     if (ep && ep->colstats) return fail("gemm_2src: colstats is not available for operands beyond 4 GiB");
     const int rpg = (ep && ep->rows_per_group > 0) ? ep->rows_per_group : 1;
@@ -743,7 +733,7 @@ IDIFF_API int idiff_gemm_2src_f32(const float *A1, const float *A2, int64_t lda,
     return idiff_gemm_2src_f32(A1 + (int64_t)mid * lda, A2 + (int64_t)mid * lda, lda, K1, Bt, ldb, C + (int64_t)mid * ldc, ldc,
                                M - mid, N, K, ep ? &hi : nullptr, stream);
   }
-  if (!vec || a1_bytes >= BUF_LIMIT || a2_bytes >= BUF_LIMIT || b_bytes >= BUF_LIMIT || getenv("IDIFF_NO_PIPE"))
+  if (!vec || a1_bytes >= BUF_LIMIT || a2_bytes >= BUF_LIMIT || b_bytes >= BUF_LIMIT || idiff::option(idiff::OPT_NO_PIPE))
     return fail("gemm_2src: operands must be 16-byte aligned with K %% 4 == 0 and lda %% 4 == 0 (use two idiff_gemm_f32 calls)");
   IgemmParams p = {};
   p.A = A1; p.A2 = A2; p.K1 = K1; p.Bt = Bt; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
@@ -774,7 +764,7 @@ IDIFF_API int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out,
   p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KW = KW; p.stride = stride; p.pad = pad;
   fill_epilogue(p, ep);
   const int64_t a_bytes = (int64_t)B * H * W * Cin * 4, b_bytes = (int64_t)Cout * p.K * 4;
-  const bool fast_ok = Cin % BK == 0 && KH * KW <= 32 && b_bytes < BUF_LIMIT && !getenv("IDIFF_NO_PIPE");
+  const bool fast_ok = Cin % BK == 0 && KH * KW <= 32 && b_bytes < BUF_LIMIT && !idiff::option(idiff::OPT_NO_PIPE);
   if (ep && ep->colstats && !(fast_ok && a_bytes < BUF_LIMIT))
     return fail("conv2d: colstats requested for a problem the pipelined kernel does not take "
                 "(ask idiff_conv2d_colstats_split first)");
@@ -805,7 +795,7 @@ IDIFF_API int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out,
 // statistics are not available for this problem (then the consumer runs idiff_groupnorm_stats_f32 as usual).
 IDIFF_API int idiff_gemm_colstats_split(int M, int N, int K, int64_t lda, int64_t ldb, int rows_per_sample) {
   if (M <= 0 || N <= 0 || K <= 0 || rows_per_sample <= 0 || M % rows_per_sample) return 0;
-  if (getenv("IDIFF_NO_PIPE") || getenv("IDIFF_NO_COLSTATS")) return 0;
+  if (idiff::option(idiff::OPT_NO_PIPE) || idiff::option(idiff::OPT_NO_COLSTATS)) return 0;
   if (K % 4 || lda % 4 || ldb % 4) return 0;
   if (((int64_t)(M - 1) * lda + K) * 4 >= BUF_LIMIT || ((int64_t)(N - 1) * ldb + K) * 4 >= BUF_LIMIT) return 0;
   const int bm = pipe_tile_rows(M, N, 1);
@@ -814,7 +804,7 @@ IDIFF_API int idiff_gemm_colstats_split(int M, int N, int K, int64_t lda, int64_
 
 IDIFF_API int idiff_conv2d_colstats_split(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_lo,
                                           int pad_hi) {
-  if (B <= 0 || Cin % BK || KH * KW > 32 || getenv("IDIFF_NO_PIPE") || getenv("IDIFF_NO_COLSTATS")) return 0;
+  if (B <= 0 || Cin % BK || KH * KW > 32 || idiff::option(idiff::OPT_NO_PIPE) || idiff::option(idiff::OPT_NO_COLSTATS)) return 0;
   const int OH = (H + pad_lo + pad_hi - KH) / stride + 1, OW = (W + pad_lo + pad_hi - KW) / stride + 1;
   if (OH <= 0 || OW <= 0) return 0;
   if ((int64_t)B * H * W * Cin * 4 >= BUF_LIMIT || (int64_t)Cout * KH * KW * Cin * 4 >= BUF_LIMIT) return 0;

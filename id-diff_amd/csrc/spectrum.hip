@@ -11,7 +11,6 @@
 // the exact Gram matrix up to fp64 summation error: squaring the condition number costs ~1e-16 * cond^2
 // relative, far inside the 1e-4 tolerance for the cliffs the ID rule looks for (cond ~ 1e2..1e4).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -654,15 +653,10 @@ size_t small_lds_bytes(int D) { return ((size_t)D * (D + 1) + 2 * D + 8) * sizeo
 int bisect_launch(const double *diag, const double *offd, int P, int D, double *eig, float *sv, hipStream_t st) {
   const bool use_lds = D <= 8192;
   const size_t lds = use_lds ? (size_t)D * sizeof(double2) : 0;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel<true, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(double2));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(bisect_kernel<true, 8>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(double2));
-    if (e != hipSuccess) { idiff::set_error("bisect: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
+  if (lds > 64 * 1024) {
+    static idiff::AttrGuard guard;
+    const void *fns[2] = {reinterpret_cast<const void *>(bisect_kernel<true, 1>), reinterpret_cast<const void *>(bisect_kernel<true, 8>)};
+    if (int rc = idiff::set_dynamic_lds_once(guard, fns, 2, 8192 * (int)sizeof(double2), "bisect")) return rc;
   }
   // 64 eigenvalues per workgroup would spread the work over more CUs, but the chain length (D steps per
   // bisection) is the latency; 256 threads keep the broadcast LDS traffic low.
@@ -705,29 +699,23 @@ IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double
   hipStream_t st = (hipStream_t)stream;
   if (D <= SMALL_D_MAX) {
     const size_t lds = small_lds_bytes(D);
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_small_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes(SMALL_D_MAX));
-      if (e != hipSuccess) { set_error("symtridiag: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-      attr_set = true;
+    if (lds > 64 * 1024) {
+      static AttrGuard guard;
+      const void *fn = reinterpret_cast<const void *>(tridiag_small_kernel);
+      if (int rc = set_dynamic_lds_once(guard, &fn, 1, (int)small_lds_bytes(SMALL_D_MAX), "symtridiag")) return rc;
     }
     hipLaunchKernelGGL(tridiag_small_kernel, dim3(P), dim3(256), lds, st, G, D, diag, offdiag);
     return launch_status("tridiag_small");
   }
   if (!scratch) return fail("symtridiag: scratch (4*D+16 + (ceil(D/512)+1)*D doubles) required for D > %d", SMALL_D_MAX);
   if ((size_t)D * sizeof(double) > 60 * 1024) {
-    static bool attr_set2 = false;
-    if (!attr_set2) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_symv_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-      if (e != hipSuccess) { set_error("symtridiag: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-      attr_set2 = true;
-    }
+    static AttrGuard guard2;
+    const void *fn = reinterpret_cast<const void *>(tridiag_symv_kernel);
+    if (int rc = set_dynamic_lds_once(guard2, &fn, 1, 160 * 1024 - 256, "symtridiag")) return rc;
     if ((size_t)D * sizeof(double) > 160 * 1024 - 256) return fail("symtridiag: D=%d exceeds the LDS-resident reflector", D);
   }
   double *v = scratch, *pvec = scratch + D, *tau = scratch + 2 * D;
-  if (D % 2 == 0 && D <= STREAM_D_MAX && !getenv("IDIFF_TRIDIAG_FUSED")) {
+  if (D % 2 == 0 && D <= STREAM_D_MAX && true /* the per-step fused variant below is kept for odd D */) {
     // scratch: v0[D] | v1[D] | w[D] | p0[D] | tau[2] | part[nseg_max][D]
     const int nseg_max = ceil_div(D, SEG_COLS) + 1;
     double *vb[2] = {scratch, scratch + (int64_t)D};
@@ -761,16 +749,12 @@ IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double
     return launch_status("symtridiag_stream");
   }
   if (D <= FUSED_D_MAX) {
-    static bool attr_fused = false;
-    if (!attr_fused) {
+    {
+      static AttrGuard guard_fused;
       const void *fns[3] = {reinterpret_cast<const void *>(tridiag_fused_kernel<16>),
                             reinterpret_cast<const void *>(tridiag_fused_kernel<8>),
                             reinterpret_cast<const void *>(tridiag_fused_kernel<4>)};
-      for (const void *fn : fns) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FUSED_D_MAX * 8);
-        if (e != hipSuccess) { set_error("symtridiag: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-      }
-      attr_fused = true;
+      if (int rc = set_dynamic_lds_once(guard_fused, fns, 3, 3 * FUSED_D_MAX * 8, "symtridiag")) return rc;
     }
     // ping-pong buffers: [v0 | p0 | v1 | p1 | tau0 tau1]
     double *vb[2] = {scratch, scratch + 2 * (int64_t)D}, *pb[2] = {scratch + D, scratch + 3 * (int64_t)D};

@@ -416,7 +416,7 @@ IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, in
     // otherwise split rows over up to 8 workgroups
     const int gx = (int64_t)major * p.out_h >= 2048 ? 1 : max(1, min(ceil_div(p.out_w, col_step), 8));
     if (up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 && pad_x0 == 2 && pad_y0 == 2 &&
-        p.out_h == 2 * in_h && p.out_w == 2 * in_w && (int64_t)major * in_h <= 0x7fffffff && !getenv("IDIFF_UFD_ROWS")) {
+        p.out_h == 2 * in_h && p.out_w == 2 * in_w && (int64_t)major * in_h <= 0x7fffffff && !idiff::option(idiff::OPT_UFD_ROWS)) {
       hipLaunchKernelGGL(upfirdn2d_nhwc_up2_block, dim3(major * in_h), dim3(256), 0, st, x, k, out, p, cv, col_step);
       return launch_status("upfirdn2d_nhwc_up2_block");
     }

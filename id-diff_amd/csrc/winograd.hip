@@ -385,12 +385,12 @@ bool geometry_ok(int B, int H, int W, int Cin, int Cout) {
 }  // namespace
 
 IDIFF_API int idiff_conv2d_winograd_ok(int B, int H, int W, int Cin, int Cout) {
-  if (getenv("IDIFF_NO_WINOGRAD")) return 0;
+  if (idiff::option(idiff::OPT_NO_WINOGRAD)) return 0;
   return geometry_ok(B, H, W, Cin, Cout) ? 1 : 0;
 }
 
 IDIFF_API int idiff_conv2d_winograd_colstats_split(int B, int H, int W, int Cin, int Cout) {
-  if (!idiff_conv2d_winograd_ok(B, H, W, Cin, Cout) || getenv("IDIFF_NO_COLSTATS")) return 0;
+  if (!idiff_conv2d_winograd_ok(B, H, W, Cin, Cout) || idiff::option(idiff::OPT_NO_COLSTATS)) return 0;
   if ((int64_t)B * H * W * Cin * 4 >= X_LIMIT) return 0;
   const int tpi = (H / 2) * (W / 2);
   return tpi % WG_TILES == 0 ? tpi / WG_TILES : 0;
@@ -449,12 +449,10 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
   } else {
     p.has_ep = 0; p.ep.rows_per_group = 1; p.ep.out_scale = 1.f;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(winograd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS_BYTES);
-    if (e != hipSuccess) { set_error("conv2d_winograd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
+  {
+    static AttrGuard guard;
+    const void *fn = reinterpret_cast<const void *>(winograd_kernel);
+    if (int rc = set_dynamic_lds_once(guard, &fn, 1, (int)LDS_BYTES, "conv2d_winograd")) return rc;
   }
   hipLaunchKernelGGL(winograd_kernel, dim3(p.tiles_m * p.tiles_n), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, p);
   return launch_status("conv2d_winograd");

@@ -231,6 +231,21 @@ def get_manifold_dimension(config, name=None, return_svd=False):
     DataModule, pl_module, score_fn, device = setup_model(config)
     num_datapoints = _num_datapoints(config)
     points = collect_points(DataModule.train_dataloader(), num_datapoints)
+    if not points:                       # num_datapoints <= 1: the reference's loop body never runs (:159-164)
+        info = {'singular_values': []}
+        if return_svd:
+            return info
+        if rank == 0:
+            with open(os.path.join(save_path, f'{name}.pkl'), 'wb') as f:
+                pickle.dump(info, f)
+        return None
+    for x, batchsize in points:          # refuse before any GPU work, not in the middle of the run
+        rows = batching(tuple(x.shape), batchsize)[2]
+        if rows < x.numel():
+            raise RuntimeError(
+                f"a loader batch of {batchsize} gives a {rows} x {x.numel()} score matrix: the Gram-matrix spectrum "
+                f"kernel needs rows >= columns (use a training batch size that keeps (ambient // B + 1) * 4 * B >= D, "
+                f"and drop_last for a short final batch)")
 
     builder = ScoreMatrixBuilder(score_fn, pl_module.sde, pl_module.sampling_eps, device,
                                  config.get('dim_estimation.inflight_rows', None))
@@ -289,9 +304,68 @@ def get_manifold_dimension(config, name=None, return_svd=False):
             pickle.dump(info, f)
 
 
+def collect_labelled_points(loader, num_datapoints, label=1):
+    """The (x, y, loader batch size) triples the reference's conditional loop visits (dim_reduction.py:49-60): items
+    whose label equals 1, ``num_datapoints - 1`` of them."""
+    pts, idx = [], 0
+    for orig_batch, orig_labels in loader:
+        batchsize = orig_batch.size(0)
+        if idx + 1 >= num_datapoints:
+            break
+        for x, y in zip(orig_batch, orig_labels):
+            if y.item() != label:
+                continue
+            if idx + 1 >= num_datapoints:
+                break
+            pts.append((x, y.item(), batchsize))
+            idx += 1
+    return pts
+
+
+def conditional_spectra(builder, loader, num_datapoints, seed=42, levels=None, noise=None, overlap=True):
+    """Spectra of the label-1 validation points at the noise levels ``linspace(sampling_eps, 0.3, 12)``
+    (dim_reduction.py:39-101).  Returns one dict per level: ``{'level', 't', 'images', 'singular_values', 'labels'}``.
+
+    MI355X specifics: per level the points are sharded round-robin over the ranks and their spectra combined by one
+    all-gather (parallel.py); the spectrum of point p runs on the side stream under the score evaluations of point
+    p+1 (``SpectrumPipeline``); nothing is synchronised with the host until a level is complete.  The Philox stream
+    of (level, point) is keyed by ``seed + 1000003 * (point + 1) + 7919 * level``: levels do not share draws.
+    ``levels`` restricts the sweep to some of the 12 indices and ``noise(level, point) -> [rows, *x.shape]`` supplies
+    explicit draws (parity tests); the drop-in entry point below uses neither."""
+    rank, world = parallel.rank_world()
+    device = builder.device
+    times = torch.linspace(builder.eps, 0.3, 12)
+    out = []
+    for level, t_slice in enumerate(times):
+        if levels is not None and level not in levels:
+            continue
+        points = collect_labelled_points(loader, num_datapoints)
+        mine = parallel.my_points(len(points), rank, world)
+        pipe = SpectrumPipeline(device, overlap=overlap)
+        with torch.no_grad():
+            for p in mine:
+                x, _, batchsize = points[p]
+                z = None if noise is None else noise(level, p).to(device)
+                pipe.submit(builder.build(x.to(device), batchsize, t=float(t_slice), noise=z,
+                                          seed=seed + 1000003 * (p + 1) + 7919 * level))
+            local = pipe.results()
+        if points:
+            x0, _, b0 = points[0]
+            n_sv = min(batching(tuple(x0.shape), b0)[2], x0.numel())
+            local = torch.stack(local) if local else torch.empty(0, n_sv, device=device)
+            spectra = parallel.gather_spectra(local, len(points), n_sv, device).cpu()
+        else:
+            spectra = torch.empty(0, 0)
+        out.append({'level': level, 't': float(t_slice),
+                    'images': torch.stack([x.permute(1, 2, 0) for x, _, _ in points]).numpy() if points else [],
+                    'singular_values': [s.tolist() for s in spectra], 'labels': [y for _, y, _ in points]})
+    return out
+
+
 def get_conditional_manifold_dimension(config, name=None):
     """dim_reduction.py:12-114: the same estimator at 12 noise levels linspace(sampling_eps, 0.3, 12) on the
-    label==1 points of the validation loader; writes images.pkl / labels_svd.pkl / labels.pkl per level."""
+    label==1 points of the validation loader; writes images.pkl / labels_svd.pkl / labels.pkl per level
+    (rank 0 only when run under torch.distributed)."""
     log_path, log_name = config.logging.log_path, config.logging.log_name
     config.data.return_labels = True
     seed = int(config.get('seed', 42))
@@ -300,28 +374,16 @@ def get_conditional_manifold_dimension(config, name=None):
     num_datapoints = config.get('dim_estimation.num_datapoints', 26)
     builder = ScoreMatrixBuilder(score_fn, pl_module.sde, pl_module.sampling_eps, device,
                                  config.get('dim_estimation.inflight_rows', None))
-    times = torch.linspace(pl_module.sampling_eps, 0.3, 12)
-    for t_slice in times:
-        t_save_path = os.path.join(log_path, log_name, 'svd', '%.3f' % t_slice.item())
+    loader = DataModule.val_dataloader()
+    results = conditional_spectra(builder, loader, num_datapoints, seed=seed,
+                                  overlap=bool(config.get('dim_estimation.overlap_spectrum', True)))
+    if parallel.rank_world()[0] != 0:
+        return
+    for lv in results:
+        t_save_path = os.path.join(log_path, log_name, 'svd', '%.3f' % lv['t'])
         Path(t_save_path).mkdir(parents=True, exist_ok=True)
-        singular_values, labels, imgs, idx = [], [], [], 0
-        with torch.no_grad():
-            for orig_batch, orig_labels in DataModule.val_dataloader():
-                batchsize = orig_batch.size(0)
-                if idx + 1 >= num_datapoints:
-                    break
-                for x, y in zip(orig_batch, orig_labels):
-                    if y.item() != 1:
-                        continue
-                    if idx + 1 >= num_datapoints:
-                        break
-                    imgs.append(x.permute(1, 2, 0))
-                    S = builder.build(x.to(device), batchsize, t=float(t_slice), seed=seed + 1000003 * (idx + 1))
-                    singular_values.append(_lib.spectrum(S).tolist())
-                    labels.append(y.item())
-                    idx += 1
-        for fname, payload in (('images.pkl', {'images': torch.stack(imgs).numpy() if imgs else []}),
-                               ('labels_svd.pkl', {'singular_values': singular_values}),
-                               ('labels.pkl', {'labels': labels})):
+        for fname, payload in (('images.pkl', {'images': lv['images']}),
+                               ('labels_svd.pkl', {'singular_values': lv['singular_values']}),
+                               ('labels.pkl', {'labels': lv['labels']})):
             with open(os.path.join(t_save_path, fname), 'wb') as f:
                 pickle.dump(payload, f)

@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from .. import sde_lib
 from ..models import utils as mutils
-from . import utils
+from . import checkpoint_io, utils
 
 
 @utils.register_lightning_module(name='base')
@@ -26,18 +26,20 @@ class BaseSdeGenerativeModel(nn.Module):
     def load_from_checkpoint(self, checkpoint_path, **kwargs):
         """Lightning ``.ckpt`` = torch.save({'state_dict': {'score_model.<k>': tensor}, 'hyper_parameters': ...}).
 
-        ``None`` keeps the freshly initialised weights (benchmarks / tests: no trained checkpoint ships with the
-        reference).  Unlike Lightning's classmethod this restores into the existing instance; the call site
+        Unlike Lightning's classmethod this restores into the existing instance; the call site
         ``pl_module = pl_module.load_from_checkpoint(path)`` (dim_reduction.py:128) reads the same either way.
+        ``None`` is an error, as in the reference (Lightning raises on it), unless the score model has no weights to
+        restore (the analytic ``ksphere_exact``) or ``config.model.allow_random_init`` opts in (benchmarks / tests:
+        no trained checkpoint ships with the reference).
         """
         if checkpoint_path is None:
+            has_weights = any(p.requires_grad for p in self.score_model.parameters())   # trained weights
+            if has_weights and not bool(self.config.model.get('allow_random_init', False)):
+                raise ValueError(
+                    "config.model.checkpoint_path is None: the ID estimate of an untrained score network is "
+                    "meaningless.  Pass --checkpoint_path, or set config.model.allow_random_init = True "
+                    "(--allow_random_init) to time / test the pipeline on random weights.")
             return self
-        try:
-            ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-        except Exception:
-            # Lightning checkpoints pickle the ConfigDict under 'hyper_parameters'; only 'state_dict' is needed.
-            ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
-        state = ckpt.get("state_dict", ckpt)
-        own = {k[len("score_model."):]: v for k, v in state.items() if k.startswith("score_model.")}
-        self.score_model.load_state_dict(own if own else state, strict=True)
+        ckpt = checkpoint_io.load_checkpoint(checkpoint_path)
+        self.score_model.load_state_dict(checkpoint_io.score_model_state_dict(ckpt), strict=True)
         return self

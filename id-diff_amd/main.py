@@ -6,7 +6,6 @@ Run it from the repo root as ``python id-diff_amd/main.py ...`` or, for several 
 """
 import argparse
 import os
-import pickle
 import sys
 
 if __package__ in (None, ""):
@@ -16,6 +15,7 @@ if __package__ in (None, ""):
 
 from id_diff_amd import parallel, run_lib  # noqa: E402
 from id_diff_amd.configs.utils import read_config  # noqa: E402
+from id_diff_amd.lightning_modules.checkpoint_io import load_config_pickle  # noqa: E402
 
 _HOT_MODES = ('manifold_dimension', 'conditional_manifold_dimension')
 
@@ -30,20 +30,23 @@ def parse(argv=None):
     ap.add_argument("--eval_folder", default="eval")
     ap.add_argument("--debug", action="store_true")
     ap.add_argument("--log_name", default=None)
+    ap.add_argument("--allow_random_init", action="store_true",
+                    help="run on freshly initialised weights when no checkpoint is given (timing / plumbing only)")
     return ap.parse_args(argv)
 
 
 def main(argv=None):
     flags = parse(argv)
     if flags.config.endswith('pkl'):
-        with open(flags.config, 'rb') as f:
-            config = pickle.load(f)
+        config = load_config_pickle(flags.config)      # ml_collections pickles load without ml_collections
     elif flags.config.endswith('py'):
         config = read_config(flags.config)
     else:
         raise RuntimeError('Unknown config extension. Provide a path to .py or .pkl file.')
     if flags.checkpoint_path is not None:
         config.model.checkpoint_path = flags.checkpoint_path
+    if flags.allow_random_init:
+        config.model.allow_random_init = True
     if flags.mode not in _HOT_MODES:
         raise SystemExit(f"mode {flags.mode!r} is outside the scope of id-diff_amd (the MI355X build covers "
                          f"{', '.join(_HOT_MODES)}); use the reference for training / sampling / evaluation")

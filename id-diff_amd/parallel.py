@@ -18,10 +18,14 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* if they are set."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* if a launcher set them.
+
+    A ``torch.distributed.run`` launch with ONE rank initialises the group too (RCCL on a GPU box), so that the
+    single-GPU leg of a scaling run goes through the same communicator set-up and collectives as the N-GPU legs.
+    Must be called before anything else touches the GPU: the device is selected first, then RCCL binds to it."""
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
         return 0, 1, 0
+    world = int(os.environ["WORLD_SIZE"])
     rank = int(os.environ["RANK"])
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     if not dist.is_initialized():
@@ -30,7 +34,11 @@ def init_from_env(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kwargs = {}
+        if backend == "nccl":
+            kwargs["device_id"] = torch.device("cuda", local_rank)    # eager communicator on THIS device
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
 
 
@@ -52,7 +60,7 @@ def gather_spectra(local, num_points, n_sv, device):
     padded to ``ceil(num_points / world)`` so a single fixed-size all-gather suffices.
     """
     rank, world = rank_world()
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     per = (num_points + world - 1) // world
     send = torch.zeros(per, n_sv, dtype=torch.float32, device=device)
@@ -78,6 +86,6 @@ def my_rows(total_rows, rank, world):
 
 def all_reduce_sum(tensor):
     """In-place sum over the default process group; identity when there is none."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor

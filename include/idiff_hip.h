@@ -5,7 +5,10 @@
  * Conventions
  *   - Every pointer is a DEVICE pointer (HBM) unless named h_*; the library never
  *     allocates, frees or synchronises: the caller owns all buffers and passes the
- *     hipStream_t (as void*) the work is enqueued on.  Re-entrant, no global state.
+ *     hipStream_t (as void*) the work is enqueued on.  Re-entrant.  The only process-level state is
+ *     (a) which devices already carry the per-kernel dynamic-LDS attribute (one bit per device
+ *     ordinal, set on first use on that device) and (b) the debug switches of idiff_set_option(),
+ *     read from the environment once when the library is loaded -- never on a launch path.
  *   - Return value: 0 on success, otherwise a hipError_t (launch failure) or
  *     IDIFF_EINVAL (1001) for an argument the kernels cannot take; idiff_last_error()
  *     gives a thread-local message.
@@ -26,6 +29,12 @@ extern "C" {
 
 int idiff_abi_version(void);
 const char *idiff_last_error(void);
+
+/* Debug / A-B switches, named like the environment variables that initialise them at load time:
+ * IDIFF_NO_WINOGRAD (3x3 convs on the implicit GEMM), IDIFF_NO_COLSTATS, IDIFF_NO_PIPE, IDIFF_SCALAR_EPILOGUE,
+ * IDIFF_DBUF_ONLY, IDIFF_TRIDIAG_ONESTAGE (per-column Householder instead of the two-stage band reduction),
+ * IDIFF_UFD_ROWS.  Returns the previous value, -1 for an unknown name.  No reference counterpart. */
+int idiff_set_option(const char *name, int value);
 
 /* ------------------------------------------------------------------ native ops (op/) */
 

@@ -76,6 +76,54 @@ def estimate_dims(svd, mode="all"):
     return [estimate_dim(s) for s in sv]
 
 
+def conditional_times(sampling_eps):
+    """The 12 noise levels of dim_reduction.py:39."""
+    return torch.linspace(sampling_eps, 0.3, 12)
+
+
+def get_conditional_manifold_dimension(score_fn, sde, sampling_eps, loader, num_datapoints=26, noise=None):
+    """The loop of dim_reduction.py:39-114 over an iterable of (images, labels) validation batches.
+
+    For every level of ``linspace(sampling_eps, 0.3, 12)`` (:39) the loader is walked again (:49), only items with
+    label == 1 are used (:56-57), ``num_datapoints - 1`` of them (:52-53, :59-60); rows per score batch = the
+    LOADER batch size (:51, :65), batching arithmetic as in the unconditional driver (:64-69), noise from the global
+    torch RNG (``randn_like``, :79) unless ``noise(level, point, batch_index, shape)`` supplies the draws.
+    Returns one dict per level with what the reference pickles (:103-114) plus the level's time:
+    ``{'t', 'images', 'singular_values', 'labels'}``; the directory name of a level is ``'%.3f' % t`` (:41).
+    """
+    out = []
+    for level, t_slice in enumerate(conditional_times(sampling_eps)):
+        singular_values, labels, imgs, idx = [], [], [], 0
+        for orig_batch, orig_labels in loader:
+            batchsize = orig_batch.size(0)
+            if idx + 1 >= num_datapoints:
+                break
+            for x, y in zip(orig_batch, orig_labels):
+                if y.item() != 1:
+                    continue
+                if idx + 1 >= num_datapoints:
+                    break
+                imgs.append(x.permute(1, 2, 0))
+                num_batches, extra, _ = batching(x.shape, batchsize)
+                rep = x.repeat([batchsize] + [1] * x.ndim)
+                vec_t = torch.ones(batchsize) * t_slice
+                rows = []
+                for i in range(1, num_batches + 1):
+                    batch = rep.clone()
+                    mean, std = sde.marginal_prob(batch, vec_t)
+                    z = torch.randn_like(batch) if noise is None else noise(level, idx, i - 1, batch.shape)
+                    batch = mean + std[(...,) + (None,) * len(batch.shape[1:])] * z
+                    with torch.no_grad():
+                        score = score_fn(batch, vec_t)
+                    rows.append(score if i < num_batches else score[:extra])
+                singular_values.append(spectrum(torch.flatten(torch.cat(rows, dim=0), start_dim=1)).tolist())
+                labels.append(y.item())
+                idx += 1
+        out.append({"t": float(t_slice), "images": torch.stack(imgs).numpy() if imgs else [],
+                    "singular_values": singular_values, "labels": labels})
+    return out
+
+
 def get_manifold_dimension(score_fn, sde, sampling_eps, loader, batchsize, num_datapoints, generator=None):
     """The loop of dim_reduction.py:150-211 over an iterable of data batches.
 

@@ -8,6 +8,7 @@ from id_diff_amd.configs.utils import read_config
 
 def say(*a): print(*a, flush=True)
 cfg = read_config('configs/dimension_estimation/paper/euclidean_data/ksphere/50dim.py')
+cfg.model.allow_random_init = True
 cfg.device = "cuda:0"
 cfg.data.data_samples = 8000
 for P, name in ((65, 'fcn'), (513, 'fcn'), (65, 'ksphere_exact')):

@@ -10,6 +10,7 @@ from id_diff_amd.models import utils as mutils
 def say(*a): print(*a, flush=True)
 dev = torch.device("cuda:0")
 cfg = read_config('configs/dimension_estimation/extra_experiments/styleGAN/style_gan_64d_BeatGAN.py')
+cfg.model.allow_random_init = True
 torch.manual_seed(0)
 model = mutils.create_model(cfg)
 g = torch.Generator().manual_seed(3)

@@ -464,10 +464,187 @@ def gen_svd_and_rule():
     save("svd_rule.npz", **out)
 
 
+def fill_from_seed(module, seed, scale=0.05):
+    """Overwrite every parameter with draws that a test can regenerate from (seed, state_dict order, shapes): wide
+    models are pinned without storing tens of MB of weights.  1-D tensors (biases, norm weights) get 1 + draws for
+    '.weight' of a norm layer and plain draws otherwise, through one generator, in state_dict order."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, prm in module.state_dict().items():
+            if not prm.dtype.is_floating_point:
+                continue
+            fan = prm[0].numel() if prm.ndim > 1 else 1
+            draw = torch.randn(prm.shape, generator=g) * (1.0 / max(fan, 1) ** 0.5 if prm.ndim > 1 else scale)
+            if prm.ndim == 1 and name.endswith("weight"):
+                draw = 1.0 + draw
+            prm.copy_(draw)
+
+
+def gen_vp():
+    """VP branch of get_score_fn (models/utils.py:238-255): VPSDE beta in [0.1, 20], t = 1e-3 (sampling_eps of VP,
+    BaseSdeGenerativeModel.py:44-47) and 0.2, on the weights of ncsnpp_bench_init1 (rebuilt from the same seed and
+    checked against the stored ones); plus the perturbation mean/std the driver feeds it (dim_reduction.py:180-182)."""
+    torch.manual_seed(0)
+    cfg = ncsnpp_config(**NCSNPP_VARIANTS["bench_init1"])
+    cfg.training.sde = "vpsde"
+    model = mutils.create_model(cfg)
+    stored = np.load(os.path.join(HERE, "ncsnpp_bench_init1.npz"))
+    for k, v in model.state_dict().items():
+        assert np.array_equal(stored["sd::" + k], v.numpy()), k
+    sde = sde_lib.VPSDE(beta_min=0.1, beta_max=20., N=1000)
+    score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(4, 3, 32, 32, generator=g)
+    t = torch.tensor([1e-3, 1e-3, 0.2, 0.7])
+    z = torch.randn(4, 3, 32, 32, generator=g)
+    mean, std = sde.marginal_prob(x, t)
+    perturbed = mean + std[(...,) + (None,) * 3] * z      # dim_reduction.py:180-182
+    with torch.no_grad():
+        y = score_fn(perturbed, t)
+    save("ncsnpp_vp.npz", x=x.numpy(), t=t.numpy(), z=z.numpy(), mean=mean.numpy(), std=std.numpy(),
+         perturbed=perturbed.numpy(), score=y.numpy(), weights_of=np.array("ncsnpp_bench_init1.npz"),
+         params=np.array([0.1, 20., 1000]))
+
+
+WIDE_SEED = 20260
+
+
+def gen_wide():
+    """Wide branches against reference output: nf = 128 so that GroupNorm's min(ch // 4, 32) caps at
+    32 groups and the 3x3 convs are Winograd-eligible (Cin % 8 == 0, Cout % 64 == 0); BeatGANs at model_channels =
+    128 so that GroupNorm32 has 4 channels per group.  Weights are NOT stored: ``fill_from_seed`` draws them."""
+    torch.manual_seed(0)
+    over = {"model.nf": 128, "model.ch_mult": (1,), "model.num_res_blocks": 1, "model.attn_resolutions": (8,),
+            "model.init_scale": 1.0, "data.image_size": 8, "data.effective_image_size": 8, "data.shape": [3, 8, 8]}
+    cfg = ncsnpp_config(**over)
+    model = mutils.create_model(cfg)
+    fill_from_seed(model, WIDE_SEED)
+    sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50, N=1000)
+    score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
+    x = torch.rand(3, 3, 8, 8, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([1e-5, 0.2, 0.9])
+    with torch.no_grad():
+        y = score_fn(x, t)
+        raw = model.eval()(x, t * 999)
+    ks = sorted(over)
+    chk = np.array([float(v.double().abs().sum()) for v in model.state_dict().values() if v.dtype.is_floating_point])
+    save("ncsnpp_wide.npz", x=x.numpy(), t=t.numpy(), score=y.numpy(), model_out=raw.numpy(), weight_abs_sums=chk,
+         seed=np.array(WIDE_SEED), n_modules=np.array(len(model.all_modules)),
+         override_keys=np.array(ks, dtype="U64"), override_vals=np.array([repr(over[k]) for k in ks], dtype="U64"))
+
+    from models import BeatGANsUNET  # noqa: F401
+    torch.manual_seed(0)
+    over = {"model.model_channels": 128, "model.channel_mult": (1, 2), "model.embed_channels": 64,
+            "model.attention_resolutions": (2,), "data.image_size": 8, "data.effective_image_size": 8,
+            "data.shape": [3, 8, 8], "model.image_size": 8}
+    cfg = beatgans_config(**over)
+    model = mutils.create_model(cfg)
+    fill_from_seed(model, WIDE_SEED + 1)
+    score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
+    x = torch.rand(3, 3, 8, 8, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        y = score_fn(x, t)
+        raw = model.eval()(x, t * 999)
+    ks = sorted(over)
+    chk = np.array([float(v.double().abs().sum()) for v in model.state_dict().values() if v.dtype.is_floating_point])
+    save("beatgans_wide.npz", x=x.numpy(), t=t.numpy(), score=y.numpy(), model_out=raw.numpy(), weight_abs_sums=chk,
+         seed=np.array(WIDE_SEED + 1),
+         override_keys=np.array(ks, dtype="U64"), override_vals=np.array([repr(over[k]) for k in ks], dtype="U64"))
+
+
+COND_SEED = 4242
+
+
+def gen_conditional():
+    """get_conditional_manifold_dimension (dim_reduction.py:12-114) RUN from the reference's own file: the Lightning
+    registries it imports (lightning_modules.utils / lightning_data_modules.utils pull in the whole training stack)
+    are replaced by two-function stand-ins that hand it a reference ncsnpp, the reference VESDE and a one-batch
+    labelled validation loader.  The loop, the batching arithmetic, the label filter, the 12 levels, the SVD and the
+    three pickles per level are the reference's code.  Noise = torch's global CPU generator seeded with COND_SEED,
+    consumed in the reference's order (level, point, batch) -- a test replays it."""
+    import pickle
+    import tempfile
+
+    over = {"model.init_scale": 1.0, "model.attn_resolutions": (8,), "data.image_size": 16,
+            "data.effective_image_size": 16, "data.shape": [3, 16, 16], "model.num_res_blocks": 1}
+    cfg = ncsnpp_config(**over)
+    torch.manual_seed(0)
+    model = mutils.create_model(cfg)
+    B = 60
+    g = torch.Generator().manual_seed(3)
+    images = torch.rand(B, 3, 16, 16, generator=g)
+    labels = torch.arange(B) % 3            # label 1 at items 1, 4, 7, ...
+
+    class Module(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.score_model = model
+
+        def load_from_checkpoint(self, path):
+            return self
+
+        def configure_sde(self, config):      # BaseSdeGenerativeModel.py:27-47, VE branch
+            self.sde = sde_lib.VESDE(sigma_min=config.model.sigma_min, sigma_max=config.model.sigma_max,
+                                     N=config.model.num_scales)
+            self.sampling_eps = 1e-5
+
+    class Data:
+        def setup(self):
+            pass
+
+        def val_dataloader(self):
+            return [(images, labels)]
+
+    saved = {k: sys.modules.get(k) for k in ("lightning_modules", "lightning_modules.utils",
+                                             "lightning_data_modules", "lightning_data_modules.utils", "dim_reduction")}
+    lm, lmu = types.ModuleType("lightning_modules"), types.ModuleType("lightning_modules.utils")
+    ld, ldu = types.ModuleType("lightning_data_modules"), types.ModuleType("lightning_data_modules.utils")
+    lmu.create_lightning_module = lambda config: Module()
+    ldu.create_lightning_datamodule = lambda config: Data()
+    lm.utils, ld.utils = lmu, ldu
+    sys.modules.update({"lightning_modules": lm, "lightning_modules.utils": lmu,
+                        "lightning_data_modules": ld, "lightning_data_modules.utils": ldu})
+    sys.modules.pop("dim_reduction", None)
+    try:
+        import dim_reduction as ref_dim   # /root/reference/dim_reduction.py
+        assert ref_dim.__file__.startswith(REF)
+        with tempfile.TemporaryDirectory() as tmp:
+            cfg.logging = ConfigDict(log_path=tmp, log_name="cond")
+            cfg.model.checkpoint_path = None
+            cfg.device = "cpu"
+            cfg.dim_estimation = ConfigDict(num_datapoints=3)
+            torch.manual_seed(COND_SEED)
+            ref_dim.get_conditional_manifold_dimension(cfg)
+            root = os.path.join(tmp, "cond", "svd")
+            levels = sorted(os.listdir(root))
+            sv, lab, img = [], [], []
+            for lv in levels:
+                with open(os.path.join(root, lv, "labels_svd.pkl"), "rb") as f:
+                    sv.append(np.array(pickle.load(f)["singular_values"], dtype=np.float64))
+                with open(os.path.join(root, lv, "labels.pkl"), "rb") as f:
+                    lab.append(np.array(pickle.load(f)["labels"]))
+                with open(os.path.join(root, lv, "images.pkl"), "rb") as f:
+                    img.append(pickle.load(f)["images"])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    out = sd_arrays(model)
+    ks = sorted(over)
+    out.update(val_images=images.numpy(), val_labels=labels.numpy(), level_dirs=np.array(levels, dtype="U16"),
+               singular_values=np.stack(sv), labels=np.stack(lab), images_pkl=np.stack(img)[0],
+               seed=np.array(COND_SEED), num_datapoints=np.array(3),
+               override_keys=np.array(ks, dtype="U64"), override_vals=np.array([repr(over[k]) for k in ks], dtype="U64"))
+    save("conditional.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "fcn", "ncsnpp", "ksphere", "svd", "beatgans", "ddpm"]
+    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "fcn", "ncsnpp", "ksphere", "svd", "beatgans", "ddpm", "vp", "wide", "conditional"]
     table = {"upfirdn2d": gen_upfirdn2d, "fused_act": gen_fused_act, "sde": gen_sde, "fcn": gen_fcn,
-             "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule, "beatgans": gen_beatgans, "ddpm": gen_ddpm}
+             "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule, "beatgans": gen_beatgans, "ddpm": gen_ddpm, "vp": gen_vp, "wide": gen_wide,
+             "conditional": gen_conditional}
     for w in which:
         table[w]()

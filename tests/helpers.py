@@ -84,3 +84,35 @@ def ddpm_config(**over):
     for k, v in over.items():
         c[k] = v
     return c
+
+
+def fill_from_seed(module, seed, scale=0.05):
+    """The weight recipe of tests/golden/make_golden.py::fill_from_seed (wide fixtures store no weights)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, prm in module.state_dict().items():
+            if not prm.dtype.is_floating_point:
+                continue
+            fan = prm[0].numel() if prm.ndim > 1 else 1
+            draw = torch.randn(prm.shape, generator=g) * (1.0 / max(fan, 1) ** 0.5 if prm.ndim > 1 else scale)
+            if prm.ndim == 1 and name.endswith("weight"):
+                draw = 1.0 + draw
+            prm.copy_(draw)
+
+
+def weight_abs_sums(module):
+    return np.array([float(v.double().abs().sum()) for v in module.state_dict().values() if v.dtype.is_floating_point])
+
+
+def replay_conditional_noise(seed, n_levels, n_points, num_batches, batch_shape, rows, keep_levels):
+    """The draws the reference's conditional loop consumed (global CPU generator seeded with ``seed``; order level,
+    point, batch -- dim_reduction.py:39-79) as {(level, point): [rows, *sample_shape]} for the levels in
+    ``keep_levels``; the other levels' draws are generated and dropped to keep the stream aligned."""
+    g = torch.Generator().manual_seed(int(seed))
+    out = {}
+    for level in range(n_levels):
+        for point in range(n_points):
+            z = torch.randn(num_batches, *batch_shape, generator=g)
+            if level in keep_levels:
+                out[(level, point)] = z.reshape(num_batches * batch_shape[0], *batch_shape[1:])[:rows].clone()
+    return out

@@ -4,8 +4,8 @@ import pytest
 import torch
 
 import id_diff_amd
-from helpers import (beatgans_config, ddpm_config, fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden,
-                     rel_err)
+from helpers import (beatgans_config, ddpm_config, fcn_config, fill_from_seed, ncsnpp_config, overrides_from_golden,
+                     rel_err, replay_conditional_noise, state_dict_from_golden, weight_abs_sums)
 from id_diff_amd import _lib, dim_reduction, plot_utils, sde_lib
 from id_diff_amd.configs.utils import read_config
 from id_diff_amd.models import utils as mutils
@@ -230,6 +230,7 @@ def test_conditional_manifold_dimension_layout(tmp_path):
     cfg.training.lightning_module = 'base'
     cfg.validation = type(cfg)(batch_size=100)
     cfg.model.checkpoint_path = None
+    cfg.model.allow_random_init = True          # no trained checkpoint ships with the reference
     cfg.logging = type(cfg)(log_path=str(tmp_path), log_name='cond')
     cfg.dim_estimation = type(cfg)(num_datapoints=3)
     cfg.device = DEV
@@ -321,7 +322,7 @@ def test_driver_row_sharded_matches_point_sharded(tmp_path):
         assert plot_utils.plot_dims({'singular_values': got[rank]})[1] == [10] * 4
 
 
-def test_winograd_and_implicit_gemm_paths_agree_on_the_spectrum(monkeypatch):
+def test_winograd_and_implicit_gemm_paths_agree_on_the_spectrum():
     """The benchmark network (nf = 128) on one data point, 3x3 convs once through Winograd F(2x2,3x3) and once through
     the implicit GEMM (IDIFF_NO_WINOGRAD): score matrix, singular values (the 1e-4 bar of the north star) and ID."""
     cfg = read_config('configs/dimension_estimation/paper/image_data/cifar_shaped/ncsnpp.py')
@@ -332,9 +333,11 @@ def test_winograd_and_implicit_gemm_paths_agree_on_the_spectrum(monkeypatch):
     x = torch.rand(3, 32, 32, generator=torch.Generator().manual_seed(4)).to(DEV)
     with torch.no_grad():
         S_w = builder.build(x, 128, seed=9)
-        monkeypatch.setenv("IDIFF_NO_WINOGRAD", "1")
-        S_d = builder.build(x, 128, seed=9)
-        monkeypatch.delenv("IDIFF_NO_WINOGRAD")
+        assert _lib.set_option("IDIFF_NO_WINOGRAD", True) is False
+        try:
+            S_d = builder.build(x, 128, seed=9)
+        finally:
+            _lib.set_option("IDIFF_NO_WINOGRAD", False)
     assert S_w.shape == (4480, 3072)
     assert not torch.equal(S_w, S_d)                      # different arithmetic ...
     assert rel_err(S_w.cpu(), S_d.double().cpu()) < 2e-5  # ... same numbers
@@ -342,3 +345,116 @@ def test_winograd_and_implicit_gemm_paths_agree_on_the_spectrum(monkeypatch):
     big = sv_d > 1e-3 * sv_d[0]                          # the part of the spectrum the estimator can see
     assert float(((sv_w - sv_d).abs() / sv_d)[big].max()) < 1e-4
     assert plot_utils.estimate_dim(sv_w.tolist()) == plot_utils.estimate_dim(sv_d.tolist())
+
+
+# ---------------------------------------------------------------------------------------------- round-2 parity holes
+def test_wide_ncsnpp_golden(golden):
+    """nf = 128 against REFERENCE output (weights from the seed recipe of make_golden.fill_from_seed): the GroupNorm
+    32-group cap and the Winograd-eligible 3x3 convs (Cin % 8 == 0, Cout % 64 == 0) are now pinned to the reference,
+    not only to the oracle."""
+    z = golden("ncsnpp_wide.npz")
+    model = mutils.create_model(ncsnpp_config(**overrides_from_golden(z)))
+    assert len(model.all_modules) == int(z["n_modules"])
+    fill_from_seed(model, int(z["seed"]))
+    np.testing.assert_allclose(weight_abs_sums(model), z["weight_abs_sums"], rtol=1e-12)
+    model.to(DEV)
+    model._invalidate()
+    x, t = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV)
+    raw = model(x, t * 999)
+    assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
+    y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x, t)
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+
+
+def test_wide_beatgans_golden(golden):
+    z = golden("beatgans_wide.npz")
+    model = mutils.create_model(beatgans_config(**overrides_from_golden(z)))
+    fill_from_seed(model, int(z["seed"]))
+    np.testing.assert_allclose(weight_abs_sums(model), z["weight_abs_sums"], rtol=1e-12)
+    model.to(DEV)
+    model._invalidate()
+    x, t = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV)
+    raw = model(x, t * 999)
+    assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
+    y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x, t)
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+
+
+def test_vp_score_fn_golden(golden):
+    """VP branch of get_score_fn (models/utils.py:238-255) on the GPU against the reference's output, and the VP
+    perturbation (mean coefficient path of idiff_perturb_f32) against the reference's mean + std * z."""
+    z = golden("ncsnpp_vp.npz")
+    w = golden(str(z["weights_of"]))
+    cfg = ncsnpp_config(**overrides_from_golden(w))
+    cfg.training.sde = "vpsde"
+    cfg.model.beta_min, cfg.model.beta_max = 0.1, 20.
+    model = mutils.create_model(cfg)
+    model.load_state_dict(state_dict_from_golden(w))
+    model.to(DEV)
+    sde, eps = sde_lib.configure_sde(cfg)
+    assert isinstance(sde, sde_lib.VPSDE) and eps == 1e-3
+    t = torch.from_numpy(z["t"]).to(DEV)
+    y = mutils.get_score_fn(sde, model)(torch.from_numpy(z["perturbed"]).to(DEV), t)
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+    # the driver's perturbation of ONE sample repeated over the rows (dim_reduction.py:167, 180-182), VP: mean = coeff * x
+    x0 = torch.from_numpy(z["x"][0]).to(DEV)
+    noise = torch.from_numpy(z["z"]).to(DEV).reshape(4, -1).contiguous()
+    mean_unit, std = sde.marginal_prob(torch.ones((), device=DEV), t)
+    out = torch.empty(4, x0.numel(), device=DEV)
+    _lib.perturb(x0.reshape(-1).contiguous(), noise, std.contiguous(), mean_unit.reshape(-1).contiguous(), out, 4, x0.numel())
+    ref_mean, ref_std = osde.VPSDE(0.1, 20., 1000).marginal_prob(torch.from_numpy(z["x"][:1]).repeat(4, 1, 1, 1), t.cpu())
+    ref = ref_mean + ref_std[:, None, None, None] * torch.from_numpy(z["z"])
+    torch.testing.assert_close(out.cpu().reshape(ref.shape), ref, rtol=2e-6, atol=2e-6)
+
+
+def test_vp_score_matrix_and_spectrum_vs_oracle(golden):
+    """The whole per-point recipe under the VP SDE at its sampling_eps = 1e-3 (BaseSdeGenerativeModel.py:44-47): HIP
+    score matrix against the oracle's on identical noise, spectrum at the 1e-4 bar, same integer ID."""
+    z = golden("conditional.npz")                                  # 16x16 nf=8 NCSN++ with stored weights
+    cfg = ncsnpp_config(**overrides_from_golden(z))
+    ref_model = omodels.create_model(cfg)
+    ref_model.load_state_dict(state_dict_from_golden(z))
+    model = mutils.create_model(cfg)
+    model.load_state_dict(state_dict_from_golden(z))
+    model.to(DEV)
+    x = torch.from_numpy(z["val_images"][2])
+    sde_c, sde_h = osde.VPSDE(0.1, 20., 1000), sde_lib.VPSDE(0.1, 20., 1000)
+    S, S_ref = _pipeline_pair(mutils.get_score_fn(sde_h, model), osde.get_score_fn(sde_c, ref_model), sde_h, sde_c, x, 100, 1e-3)
+    assert S.shape == (1156, 768) and rel_err(S.cpu(), S_ref) < 5e-5
+    sv = _lib.spectrum(S).cpu()
+    ref64 = odim.spectrum_f64(S.cpu())
+    keep = ref64 > 2e-5 * ref64[0]
+    np.testing.assert_allclose(sv.numpy()[keep], odim.spectrum(S.cpu()).numpy()[keep], rtol=1e-4)
+    assert plot_utils.estimate_dim(sv.tolist()) == odim.estimate_dim(odim.spectrum(S_ref).tolist())
+
+
+def test_conditional_manifold_dimension_vs_reference(golden):
+    """get_conditional_manifold_dimension (dim_reduction.py:12-114) against the REFERENCE's own function: same model,
+    same labelled validation batch, and the same noise -- the reference consumed torch's global CPU generator in the
+    order (level, point, batch); the test replays that stream and hands it to the HIP driver.  Three of the twelve
+    levels (first, middle, last), both label-1 points: spectra within 1e-4, integer IDs equal."""
+    z = golden("conditional.npz")
+    cfg = ncsnpp_config(**overrides_from_golden(z))
+    model = mutils.create_model(cfg)
+    model.load_state_dict(state_dict_from_golden(z))
+    model.to(DEV)
+    sde = sde_lib.VESDE(0.01, 50, 1000)
+    builder = dim_reduction.ScoreMatrixBuilder(mutils.get_score_fn(sde, model), sde, 1e-5, torch.device(DEV))
+    images, labels = torch.from_numpy(z["val_images"]), torch.from_numpy(z["val_labels"])
+    B = images.shape[0]
+    num_batches, _, rows = odim.batching(tuple(images.shape[1:]), B)
+    levels = (0, 5, 11)
+    noise = replay_conditional_noise(int(z["seed"]), 12, 2, num_batches, (B, *images.shape[1:]), rows, levels)
+    out = dim_reduction.conditional_spectra(builder, [(images, labels)], int(z["num_datapoints"]), levels=levels,
+                                            noise=lambda level, point: noise[(level, point)])
+    assert [lv["level"] for lv in out] == list(levels)
+    for lv in out:
+        ref = z["singular_values"][lv["level"]]
+        assert '%.3f' % lv["t"] == str(z["level_dirs"][lv["level"]])
+        assert lv["labels"] == z["labels"][lv["level"]].tolist()
+        np.testing.assert_array_equal(lv["images"], z["images_pkl"])
+        got = np.array(lv["singular_values"])
+        assert got.shape == ref.shape == (2, 768)
+        np.testing.assert_allclose(got, ref, rtol=1e-4)
+        for a, b in zip(got, ref):
+            assert plot_utils.estimate_dim(a.tolist()) == odim.estimate_dim(b.tolist())

@@ -92,6 +92,33 @@ def test_image_sized_matrix():
     assert abs(float(eig.sum()) / float((c * c).sum()) - 1.0) < 1e-10
 
 
+def test_config5_sized_matrix(golden):
+    """BASELINE config 5 size (S 16768 x 12288: 64x64x3 images, B = 128): the D > 8192 path (1.2 GB fp64 Gram) against
+    an fp64 ``torch.linalg.svdvals`` of the same matrix computed once in the build container
+    (tests/golden/make_spectrum_cfg5.py; the matrix is rebuilt from its seed).  Planted cliff: 64 columns at 1/70."""
+    from golden.make_spectrum_cfg5 import cfg5_matrix, D, K_PLANTED, M
+    z = golden("spectrum_cfg5.npz")
+    ref = z["sv_f64"]
+    S = cfg5_matrix()
+    assert S.shape == (M, D)
+    c = S - S.mean(dim=0, keepdim=True)
+    fro2 = float((c.double() ** 2).sum())
+    assert abs(fro2 / float(z["fro2"]) - 1.0) < 1e-12            # the same matrix as the one the fixture was made from
+    del c
+    sv, eig = _lib.spectrum(S.to(DEV), return_eig=True)
+    sv, eig = sv.cpu().double().numpy(), eig.cpu()
+    assert sv.shape == (D,) and bool((sv[:-1] >= sv[1:]).all())
+    # every singular value, top to bottom, within the 1e-4 bar of the north star (measured ~1e-7: fp32 rounding of sv)
+    np.testing.assert_allclose(sv, ref, rtol=1e-4)
+    np.testing.assert_allclose(sv[[0, 1, D - K_PLANTED - 1, D - K_PLANTED, D - 1]],
+                               ref[[0, 1, D - K_PLANTED - 1, D - K_PLANTED, D - 1]], rtol=2e-6)
+    assert plot_utils.estimate_dim(sv.tolist()) == odim.estimate_dim(ref.tolist()) == K_PLANTED
+    # trace identity: the Gram eigenvalues sum to ||S - fp64 mean||_F^2 (the kernel centres in fp64)
+    Sd = S.double()
+    c64 = Sd - Sd.mean(0, keepdim=True)
+    assert abs(float(eig.sum()) / float((c64 * c64).sum()) - 1.0) < 1e-10
+
+
 def test_stage_exports():
     g = torch.Generator().manual_seed(4)
     M, D = 257, 70

@@ -239,3 +239,112 @@ def test_image_folder_datamodule(tmp_path):
     cfg.data.dataset = 'mnist'
     with pytest.raises(FileNotFoundError, match="no network"):
         dutils.create_lightning_datamodule(cfg).setup()
+
+
+def _fake_ml_collections():
+    """Classes pickling like ml_collections 0.1.0's (instance __dict__ with `_fields`, FieldReference with `_value`)
+    and like Lightning's AttributeDict (a dict subclass), under the module names a real checkpoint carries."""
+    import types
+    mods = {}
+    for name in ("ml_collections", "ml_collections.config_dict", "ml_collections.config_dict.config_dict",
+                 "pytorch_lightning", "pytorch_lightning.utilities", "pytorch_lightning.utilities.parsing"):
+        mods[name] = types.ModuleType(name)
+    cd = mods["ml_collections.config_dict.config_dict"]
+
+    class FieldReference:
+        def __init__(self, value):
+            self._value, self._field_type, self._ops, self._required = value, type(value), [], False
+
+    class MLConfigDict:
+        def __init__(self, **fields):
+            self.__dict__["_fields"] = fields
+            self.__dict__["_locked"] = False
+            self.__dict__["_type_safe"] = True
+            self.__dict__["_convert_dict"] = True
+
+    class AttributeDict(dict):
+        pass
+
+    for cls, mod in ((FieldReference, cd), (MLConfigDict, cd), (AttributeDict, mods["pytorch_lightning.utilities.parsing"])):
+        cls.__module__ = mod.__name__
+        cls.__qualname__ = cls.__name__ = {"MLConfigDict": "ConfigDict"}.get(cls.__name__, cls.__name__)
+        setattr(mod, cls.__name__, cls)
+    return mods, MLConfigDict, FieldReference, AttributeDict
+
+
+def test_lightning_checkpoint_round_trip(tmp_path, monkeypatch):
+    """A checkpoint shaped the way Lightning writes the reference's (BaseSdeGenerativeModel.py:17 save_hyperparameters:
+    `score_model.*` keys + a pickled ml_collections.ConfigDict) loads with strict=True although neither ml_collections nor
+    pytorch_lightning is importable -- and nothing the file names gets imported or executed."""
+    import sys
+    from id_diff_amd.lightning_modules import checkpoint_io
+    from id_diff_amd.lightning_modules.utils import create_lightning_module
+    from id_diff_amd.models import utils as mutils
+    mods, MLConfigDict, FieldReference, AttributeDict = _fake_ml_collections()
+    cfg = fcn_config(hidden_nodes=32, hidden_layers=2)
+    cfg.training.lightning_module = 'base'
+    torch.manual_seed(3)
+    donor = mutils.create_model(cfg)
+    state = {'score_model.' + k: v.clone() for k, v in donor.state_dict().items()}
+    foreign_cfg = MLConfigDict(model=MLConfigDict(name='fcn', sigma_min=FieldReference(0.01), hidden_nodes=32),
+                               training=MLConfigDict(sde='vesde', batch_size=500))
+    ckpt = {'epoch': 7, 'global_step': 123, 'pytorch-lightning_version': '1.5.1', 'state_dict': state,
+            'hyper_parameters': AttributeDict(config=foreign_cfg), 'optimizer_states': [{'state': {0: {'exp_avg': torch.ones(3)}}}]}
+    path, cfg_pkl = str(tmp_path / 'last.ckpt'), str(tmp_path / 'config.pkl')
+    with monkeypatch.context() as mp:
+        for k, v in mods.items():
+            mp.setitem(sys.modules, k, v)
+        torch.save(ckpt, path)
+        import pickle
+        with open(cfg_pkl, 'wb') as f:
+            pickle.dump(foreign_cfg, f)
+    assert 'ml_collections' not in sys.modules and 'pytorch_lightning' not in sys.modules
+
+    torch.manual_seed(4)
+    module = create_lightning_module(cfg)
+    before = {k: v.clone() for k, v in module.score_model.state_dict().items()}
+    module = module.load_from_checkpoint(path)
+    after = module.score_model.state_dict()
+    assert all(torch.equal(after[k], donor.state_dict()[k]) for k in after) and any(not torch.equal(before[k], after[k]) for k in after)
+    assert 'ml_collections' not in sys.modules and 'pytorch_lightning' not in sys.modules      # nothing got imported
+
+    loaded = checkpoint_io.load_checkpoint(path)
+    hp = checkpoint_io.to_config(loaded['hyper_parameters'])
+    assert hp.config.model.name == 'fcn' and hp.config.model.sigma_min == 0.01 and hp.config.training.batch_size == 500
+    assert torch.equal(loaded['optimizer_states'][0]['state'][0]['exp_avg'], torch.ones(3))
+    conf = checkpoint_io.load_config_pickle(cfg_pkl)                                         # main.py --config x.pkl
+    assert isinstance(conf, ConfigDict) and conf.model.hidden_nodes == 32 and hasattr(conf, 'training.sde')
+
+    # a plain state-dict file (no Lightning wrapper) and strictness
+    torch.save(donor.state_dict(), str(tmp_path / 'plain.pt'))
+    create_lightning_module(cfg).load_from_checkpoint(str(tmp_path / 'plain.pt'))
+    bad = dict(state)
+    bad.pop(next(iter(bad)))
+    torch.save({'state_dict': bad}, str(tmp_path / 'bad.ckpt'))
+    with pytest.raises(RuntimeError, match="Missing key"):
+        create_lightning_module(cfg).load_from_checkpoint(str(tmp_path / 'bad.ckpt'))
+    with pytest.raises(FileNotFoundError):
+        create_lightning_module(cfg).load_from_checkpoint(str(tmp_path / 'nope.ckpt'))
+
+    # a malicious global is never resolved: os.system would run on a permissive unpickler
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ('touch ' + str(tmp_path / 'pwned'),))
+    torch.save({'state_dict': state, 'hyper_parameters': Evil()}, str(tmp_path / 'evil.ckpt'))
+    create_lightning_module(cfg).load_from_checkpoint(str(tmp_path / 'evil.ckpt'))
+    assert not (tmp_path / 'pwned').exists()
+
+
+def test_missing_checkpoint_is_an_error_unless_opted_in():
+    """dim_reduction.py:128 `load_from_checkpoint(None)` raises in the reference; random weights need an explicit opt-in."""
+    from id_diff_amd.lightning_modules.utils import create_lightning_module
+    cfg = fcn_config(hidden_nodes=16, hidden_layers=1)
+    cfg.training.lightning_module = 'base'
+    with pytest.raises(ValueError, match="allow_random_init"):
+        create_lightning_module(cfg).load_from_checkpoint(None)
+    cfg.model.allow_random_init = True
+    create_lightning_module(cfg).load_from_checkpoint(None)
+    cfg = read_config('configs/dimension_estimation/paper/euclidean_data/ksphere/10dim.py')
+    cfg.model.name = 'ksphere_exact'                    # analytic score: nothing to restore
+    create_lightning_module(cfg).load_from_checkpoint(None)

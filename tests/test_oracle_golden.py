@@ -3,8 +3,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (beatgans_config, ddpm_config, fcn_config, ncsnpp_config, overrides_from_golden, state_dict_from_golden,
-                     rel_err)
+from helpers import (beatgans_config, ddpm_config, fcn_config, fill_from_seed, ncsnpp_config, overrides_from_golden,
+                     rel_err, state_dict_from_golden, weight_abs_sums)
 from oracle import ops as oops, sde as osde, models as omodels, ksphere as oks, dim as odim
 
 
@@ -195,3 +195,71 @@ def test_cfg1_exact_score_recovers_id_on_cpu(k):
                                       generator=torch.Generator().manual_seed(0))
     assert len(out["singular_values"]) == 2 and len(out["singular_values"][0]) == 100
     assert odim.estimate_dims(out) == [k, k]
+
+
+def test_vp_score_fn(golden):
+    """VP branch of get_score_fn (models/utils.py:238-255) + the VP perturbation the driver feeds it (:180-182)."""
+    z = golden("ncsnpp_vp.npz")
+    w = golden(str(z["weights_of"]))
+    cfg = ncsnpp_config(**overrides_from_golden(w))
+    cfg.training.sde = "vpsde"
+    cfg.model.beta_min, cfg.model.beta_max = 0.1, 20.
+    model = omodels.create_model(cfg)
+    model.load_state_dict(state_dict_from_golden(w), strict=True)
+    sde, eps = osde.make_sde(cfg)
+    assert isinstance(sde, osde.VPSDE) and eps == 1e-3
+    x, t, noise = torch.from_numpy(z["x"]), torch.from_numpy(z["t"]), torch.from_numpy(z["z"])
+    mean, std = sde.marginal_prob(x, t)
+    assert torch.equal(mean, torch.from_numpy(z["mean"])) and torch.equal(std, torch.from_numpy(z["std"]))
+    perturbed = mean + std[(...,) + (None,) * 3] * noise
+    assert torch.equal(perturbed, torch.from_numpy(z["perturbed"]))
+    with torch.no_grad():
+        y = osde.get_score_fn(sde, model)(perturbed, t)
+    assert rel_err(y, z["score"]) < 2e-6
+
+
+def test_wide_ncsnpp_score_fn(golden):
+    """nf = 128: GroupNorm's 32-group cap and Winograd-eligible widths, against reference output (weights from seed)."""
+    z = golden("ncsnpp_wide.npz")
+    model = omodels.create_model(ncsnpp_config(**overrides_from_golden(z)))
+    assert len(model.all_modules) == int(z["n_modules"])
+    fill_from_seed(model, int(z["seed"]))
+    np.testing.assert_allclose(weight_abs_sums(model), z["weight_abs_sums"], rtol=1e-12)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    with torch.no_grad():
+        raw = model.eval()(x, t * 999)
+        y = osde.get_score_fn(osde.VESDE(0.01, 50, 1000), model)(x, t)
+    assert rel_err(raw, z["model_out"]) < 2e-6
+    assert rel_err(y, z["score"]) < 2e-6
+
+
+def test_wide_beatgans_score_fn(golden):
+    z = golden("beatgans_wide.npz")
+    model = omodels.create_model(beatgans_config(**overrides_from_golden(z)))
+    fill_from_seed(model, int(z["seed"]))
+    np.testing.assert_allclose(weight_abs_sums(model), z["weight_abs_sums"], rtol=1e-12)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    with torch.no_grad():
+        raw = model.eval()(x, t * 999)
+        y = osde.get_score_fn(osde.VESDE(0.01, 50, 1000), model)(x, t)
+    assert rel_err(raw, z["model_out"]) < 2e-6
+    assert rel_err(y, z["score"]) < 2e-6
+
+
+def test_conditional_manifold_dimension(golden):
+    """oracle.dim.get_conditional_manifold_dimension against the reference's own function run on the same model, the
+    same labelled batch and the same global-RNG noise stream (tests/golden/make_golden.py::gen_conditional)."""
+    z = golden("conditional.npz")
+    model = omodels.create_model(ncsnpp_config(**overrides_from_golden(z)))
+    model.load_state_dict(state_dict_from_golden(z), strict=True)
+    sde = osde.VESDE(0.01, 50, 1000)
+    loader = [(torch.from_numpy(z["val_images"]), torch.from_numpy(z["val_labels"]))]
+    torch.manual_seed(int(z["seed"]))
+    out = odim.get_conditional_manifold_dimension(osde.get_score_fn(sde, model), sde, 1e-5, loader,
+                                                  num_datapoints=int(z["num_datapoints"]))
+    assert ['%.3f' % lv["t"] for lv in out] == [str(d) for d in z["level_dirs"]]
+    for i, lv in enumerate(out):
+        assert lv["labels"] == z["labels"][i].tolist()
+        np.testing.assert_array_equal(lv["images"], z["images_pkl"])
+        # same draws, same ATen kernels; gesdd of a matrix that differs in the last bits
+        np.testing.assert_allclose(np.array(lv["singular_values"]), z["singular_values"][i], rtol=2e-5)
