@@ -455,6 +455,26 @@ def test_conditional_manifold_dimension_vs_reference(golden):
         np.testing.assert_array_equal(lv["images"], z["images_pkl"])
         got = np.array(lv["singular_values"])
         assert got.shape == ref.shape == (2, 768)
-        np.testing.assert_allclose(got, ref, rtol=1e-4)
+        # 1e-4 relative (north star) above the floor of the reference's own arithmetic: its fp32 gesdd is only good to
+        # ~3e-7 * sigma_max absolute (measured on this fixture against an fp64 SVD of the same S: 2.7e-7), and the
+        # two fp32 networks differ by summation order (a 5e-6 elementwise change of S moves the smallest singular
+        # values by up to 8e-4 relative) -- the same-input 1e-4 bar is held by tests/test_hip_spectrum.py
         for a, b in zip(got, ref):
+            np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6 * b[0])
             assert plot_utils.estimate_dim(a.tolist()) == odim.estimate_dim(b.tolist())
+    # one (level, point) with the perturbation made explicit: the oracle's S on the same draws, then Weyl's bound
+    ref_model = omodels.create_model(cfg)
+    ref_model.load_state_dict(state_dict_from_golden(z))
+    sde_c = osde.VESDE(0.01, 50, 1000)
+    lvl, t_lvl = levels[1], float(odim.conditional_times(1e-5)[levels[1]])
+    pts = dim_reduction.collect_labelled_points([(images, labels)], int(z["num_datapoints"]))
+    x0 = pts[0][0]
+    nz = noise[(lvl, 0)]
+    pad = torch.zeros(num_batches * B - rows, *x0.shape)
+    S_ref = odim.score_matrix(osde.get_score_fn(sde_c, ref_model), sde_c, x0, B, t_lvl,
+                              noise=torch.cat([nz, pad]).reshape(num_batches, B, *x0.shape))
+    S = builder.build(x0.to(DEV), B, t=t_lvl, noise=nz.to(DEV))
+    assert rel_err(S.cpu(), S_ref) < 5e-5
+    bound = float(torch.linalg.matrix_norm(S.cpu().double() - S_ref.double(), ord=2))
+    sv = _lib.spectrum(S).cpu().double()
+    assert float((sv - odim.spectrum_f64(S_ref)).abs().max()) <= 1.5 * bound + 1e-7 * float(sv[0])
