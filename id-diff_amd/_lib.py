@@ -63,6 +63,9 @@ _SIGNATURES = {
     "idiff_spectrum_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p]),
     "idiff_colmean_f64": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "idiff_centered_gram_f64": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "idiff_symtridiag_scratch_doubles": (c_i64, [c_i]),
+    "idiff_symband_ld": (c_i, []),
+    "idiff_symband_f64": (c_i, [c_p, c_i, c_p, c_p]),
     "idiff_symtridiag_f64": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "idiff_tridiag_eigvals_f64": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
 }
@@ -395,13 +398,33 @@ def centered_gram(S, mean):
     return G
 
 
+def sym_band(G):
+    """Stage 1 of the two-stage eigensolver alone: dense symmetric band matrix [D, D] (half-width 32) similar to G (G is
+    overwritten).  For the parity tests and the profiler."""
+    _dev(G, "G", dtype=torch.float64)
+    D = G.shape[0]
+    scratch = torch.zeros(lib().idiff_symtridiag_scratch_doubles(D), dtype=torch.float64, device=G.device)
+    _check(lib().idiff_symband_f64(G.data_ptr(), D, scratch.data_ptr(), _stream()), "idiff_symband_f64")
+    ld = lib().idiff_symband_ld()
+    band = scratch[:D * ld].view(D, ld)                       # band[j, k] = B[j + k, j]
+    B = torch.zeros(D, D, dtype=torch.float64, device=G.device)
+    j = torch.arange(D, device=G.device)
+    for k in range(ld):
+        n = D - k
+        if n <= 0:
+            break
+        B[j[:n] + k, j[:n]] = band[:n, k]
+        B[j[:n], j[:n] + k] = band[:n, k]
+    return B
+
+
 def sym_eigvals(G):
     """Eigenvalues (ascending, fp64) of a symmetric fp64 matrix [D, D]; G is overwritten (Householder + Sturm bisection)."""
     _dev(G, "G", dtype=torch.float64)
     D = G.shape[0]
     diag = torch.empty(D, dtype=torch.float64, device=G.device)
     offd = torch.empty(D, dtype=torch.float64, device=G.device)
-    scratch = torch.empty(4 * D + 16 + ((D + 511) // 512 + 1) * D, dtype=torch.float64, device=G.device)
+    scratch = torch.empty(max(1, lib().idiff_symtridiag_scratch_doubles(D)), dtype=torch.float64, device=G.device)
     eig = torch.empty(D, dtype=torch.float64, device=G.device)
     _check(lib().idiff_symtridiag_f64(G.data_ptr(), 1, D, diag.data_ptr(), offd.data_ptr(), scratch.data_ptr(), _stream()),
            "idiff_symtridiag_f64")

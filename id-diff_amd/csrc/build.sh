@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRC="runtime upfirdn2d fused_bias_act igemm norm_act rng spectrum winograd"
+SRC="runtime upfirdn2d fused_bias_act igemm norm_act rng spectrum sbr winograd"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function"
 OBJ=$(mktemp -d)
 trap 'rm -rf "$OBJ"' EXIT

@@ -147,9 +147,10 @@ __global__ void __launch_bounds__(64) panel_chol1_kernel(const double *__restric
 
 // x <- x R^-1 for one row x (forward substitution over the columns of the upper-triangular R held in LDS).
 __device__ __forceinline__ void row_solve_upper(double *x, const double (*R)[BW + 1]) {
-#pragma unroll 4
-  for (int j = 0; j < BW; ++j) {
+#pragma unroll
+  for (int j = 0; j < BW; ++j) {      // fully unrolled: x[] stays in registers
     double s = x[j];
+#pragma unroll
     for (int i = 0; i < j; ++i) s -= x[i] * R[i][j];
     x[j] = s / R[j][j];
   }
@@ -428,17 +429,19 @@ __global__ void __launch_bounds__(256) trailing_z_kernel(PanelGeom g, const doub
 #pragma unroll
     for (int j = 0; j < BW; ++j) { x[j] = Y[(int64_t)row * BW + j]; v[j] = V[(int64_t)row * BW + j]; }
     row_solve_upper(x, Ti);
-#pragma unroll 4
+#pragma unroll
     for (int j = 0; j < BW; ++j) {
       double s = x[j];
+#pragma unroll
       for (int k = 0; k < BW; ++k) s += v[k] * Wm[k][j];
       Z[(int64_t)row * BW + j] = s;
     }
     if (row >= BW) {
       double *p = g.A + (int64_t)(g.lo + row) * g.D + g.j0;
-#pragma unroll 4
+#pragma unroll
       for (int j = 0; j < BW; ++j) {
         double s = p[j];
+#pragma unroll
         for (int k = 0; k < BW; ++k) s -= v[k] * Cm[k][j];
         res += s * s;
         p[j] = 0.0;
@@ -728,8 +731,9 @@ int64_t sbr_scratch_doubles(int D) {
          + 8 * BW * BW + BW + 16;             // R1, R2, U, Vtop, Tinv, C, W2, spare | sgn | scalars
 }
 
-// G (D x D, both triangles, overwritten) -> diag/offd of a similar tridiagonal matrix.  Everything is enqueued on `st`.
-int sbr_tridiagonalize(double *G, int D, double *diag, double *offd, double *scratch, hipStream_t st) {
+// Stage 1: G (D x D, both triangles, overwritten) -> compact lower band AB = scratch[0 .. D * LDB) (column-major band:
+// AB[j * LDB + k] = B[j + k][j]).  Everything is enqueued on `st`.
+int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
   double *AB = scratch;
   double *vs = AB + (int64_t)D * LDB;
   double *Q = vs + (int64_t)D * (BW + 1);
@@ -777,7 +781,15 @@ int sbr_tridiagonalize(double *G, int D, double *diag, double *offd, double *scr
     if (n > BW + 1) hipLaunchKernelGGL(corner_kernel, dim3(1), dim3(256), lds, st, G, D, j0);
   }
   hipLaunchKernelGGL(extract_band_kernel, dim3((unsigned)ceil_div64((int64_t)D * LDB, 256)), dim3(256), 0, st, G, D, AB);
-  // stage 2: launch k = tasks with 2 s + t = k; task (s, t) exists iff D - (s + 1 + t BW) >= 2
+  return launch_status("sbr_to_band");
+}
+
+// Stage 2: the band left in scratch by sbr_to_band -> diag / offd.
+int sbr_chase(int D, double *diag, double *offd, double *scratch, hipStream_t st) {
+  double *AB = scratch;
+  double *vs = AB + (int64_t)D * LDB;
+  double *scal = scratch + sbr_scratch_doubles(D) - 16;
+  // launch k = tasks with 2 s + t = k; task (s, t) exists iff D - (s + 1 + t BW) >= 2
   ChaseArgs c;
   c.AB = AB; c.vs = vs; c.D = D;
   for (int k = 0; k <= 2 * (D - 3); ++k) {
@@ -788,9 +800,16 @@ int sbr_tridiagonalize(double *G, int D, double *diag, double *offd, double *scr
     c.k = k; c.s_hi = s_hi;
     hipLaunchKernelGGL(chase_kernel, dim3(s_hi - s_lo + 1), dim3(64), 0, st, c);
   }
-  // tolerance^2 on residual^2 / ||G||_F^2: an exact annihilation leaves ~1e-32
+  // tolerance^2 on residual^2 / ||G||_F^2: an exact annihilation leaves ~1e-30
   hipLaunchKernelGGL(band_to_de_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, st, AB, D, diag, offd, scal, scal + 1, 1e-22);
-  return launch_status("sbr_tridiagonalize");
+  return launch_status("sbr_chase");
 }
+
+int sbr_tridiagonalize(double *G, int D, double *diag, double *offd, double *scratch, hipStream_t st) {
+  if (int rc = sbr_to_band(G, D, scratch, st)) return rc;
+  return sbr_chase(D, diag, offd, scratch, st);
+}
+
+int sbr_band_ld() { return LDB; }
 
 }  // namespace idiff

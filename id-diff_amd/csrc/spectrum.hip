@@ -672,7 +672,30 @@ int bisect_launch(const double *diag, const double *offd, int P, int D, double *
 
 }  // namespace
 
+namespace idiff {
+int64_t sbr_scratch_doubles(int D);                                                                     // sbr.hip
+int sbr_tridiagonalize(double *G, int D, double *diag, double *offd, double *scratch, hipStream_t st);  // sbr.hip
+int sbr_to_band(double *G, int D, double *scratch, hipStream_t st);
+int sbr_band_ld();
+}
+
 using namespace idiff;
+
+// doubles of scratch idiff_symtridiag_f64 needs for a D x D matrix (0 for the LDS-resident path)
+IDIFF_API int64_t idiff_symtridiag_scratch_doubles(int D) {
+  if (D <= SMALL_D_MAX) return 0;
+  const int64_t onestage = 4 * (int64_t)D + 16 + (int64_t)((D + 511) / 512 + 1) * D;
+  const int64_t twostage = sbr_scratch_doubles(D);
+  return onestage > twostage ? onestage : twostage;
+}
+
+// Stage 1 of the two-stage path alone (parity tests, profiler): G -> lower band of half-width 32, column-major with
+// leading dimension idiff_symband_ld(): band[j * ld + k] = B[j + k][j]; the band is the first D * ld doubles of scratch.
+IDIFF_API int idiff_symband_ld(void) { return sbr_band_ld(); }
+IDIFF_API int idiff_symband_f64(double *G, int D, double *scratch, void *stream) {
+  if (!G || !scratch || D <= SMALL_D_MAX) return fail("symband: needs D > %d, G and scratch", SMALL_D_MAX);
+  return sbr_to_band(G, D, scratch, (hipStream_t)stream);
+}
 
 IDIFF_API int idiff_colmean_f64(const float *S, int P, int M, int D, double *mean, double *scratch, void *stream) {
   if (!S || !mean || !scratch || P <= 0 || M <= 0 || D <= 0) return fail("colmean: bad arguments");
@@ -707,7 +730,15 @@ IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double
     hipLaunchKernelGGL(tridiag_small_kernel, dim3(P), dim3(256), lds, st, G, D, diag, offdiag);
     return launch_status("tridiag_small");
   }
-  if (!scratch) return fail("symtridiag: scratch (4*D+16 + (ceil(D/512)+1)*D doubles) required for D > %d", SMALL_D_MAX);
+  if (!scratch) return fail("symtridiag: scratch (idiff_symtridiag_scratch_doubles(D) doubles) required for D > %d", SMALL_D_MAX);
+  if (!option(OPT_TRIDIAG_ONESTAGE)) {
+    // two-stage: blocked band reduction on the fp64 matrix cores, then bulge chasing on the compact band (sbr.hip)
+    for (int p = 0; p < P; ++p) {
+      const int rc = sbr_tridiagonalize(G + (int64_t)p * D * D, D, diag + (int64_t)p * D, offdiag + (int64_t)p * D, scratch, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if ((size_t)D * sizeof(double) > 60 * 1024) {
     static AttrGuard guard2;
     const void *fn = reinterpret_cast<const void *>(tridiag_symv_kernel);
@@ -806,12 +837,11 @@ IDIFF_API int idiff_tridiag_eigvals_f64(const double *diag, const double *offdia
 }
 
 // workspace layout (doubles): mean[P*D] | colsum partials[P*32*D] | G[P*D*D] | diag[P*D] | offd[P*D] |
-//                             scratch[4*D+16 + (ceil(D/512)+1)*D]
+//                             scratch[idiff_symtridiag_scratch_doubles(D)]
 IDIFF_API int64_t idiff_spectrum_workspace_bytes(int P, int M, int D) {
   (void)M;
   if (P <= 0 || D <= 0) return 0;
-  const int64_t n = (int64_t)P * D * (1 + MEAN_SPLITS) + (int64_t)P * D * D + 2 * (int64_t)P * D + 4 * (int64_t)D + 16 +
-                    (int64_t)((D + 511) / 512 + 1) * D;
+  const int64_t n = (int64_t)P * D * (1 + MEAN_SPLITS) + (int64_t)P * D * D + 2 * (int64_t)P * D + idiff_symtridiag_scratch_doubles(D);
   return n * (int64_t)sizeof(double);
 }
 

@@ -201,7 +201,7 @@ int idiff_resample2x_nhwc_f32(const float *x, float *y, int B, int H, int W, int
 /* Replaces `scores - scores.mean(0)` + `torch.linalg.svd(...)` of dim_reduction.py:193-198 for a batch of P
  * score matrices S[p] (M x D fp32, row-major, contiguous): singular values, descending, min(M, D) of them
  * (M >= D required).  Method: fp64 column means -> fp64 Gram of the centred columns on v_mfma_f64_16x16x4 ->
- * Householder tridiagonalisation (fp64) -> Sturm bisection -> sqrt.  Products of fp32 inputs are exact in
+ * tridiagonalisation (fp64, idiff_symtridiag_f64) -> Sturm bisection -> sqrt.  Products of fp32 inputs are exact in
  * fp64, so the squared condition number costs nothing at the 1e-4 tolerance.
  * workspace: idiff_spectrum_workspace_bytes(P, M, D) bytes; sv: [P, D] fp32.
  * `eig_out` (optional, [P, D] fp64) receives the Gram eigenvalues (ascending) for diagnosis. */
@@ -212,6 +212,17 @@ int idiff_spectrum_f32(const float *S, int P, int M, int D, void *workspace, int
 /* scratch: P * 32 * D doubles (deterministic two-stage column sums). */
 int idiff_colmean_f64(const float *S, int P, int M, int D, double *mean, double *scratch, void *stream);
 int idiff_centered_gram_f64(const float *S, const double *mean, int P, int M, int D, double *G, void *stream);
+/* G [P][D][D] symmetric (both triangles), overwritten -> diag/offdiag [P][D] of a similar tridiagonal matrix.
+ * D <= 128: one workgroup per matrix in LDS.  Larger D: two-stage -- blocked reduction to a band of half-width 32
+ * (CholeskyQR2 + Householder-reconstruction panels, compact-WY rank-64 trailing updates on v_mfma_f64_16x16x4) and
+ * bulge chasing on the compact band; if the panels' annihilation residual exceeds 1e-11 ||G||_F the outputs are NaN
+ * (never a silently wrong spectrum; IDIFF_TRIDIAG_ONESTAGE selects the unblocked Householder sweep instead).
+ * scratch: idiff_symtridiag_scratch_doubles(D) doubles (shared by the P matrices, which are processed in turn). */
+int64_t idiff_symtridiag_scratch_doubles(int D);
+/* stage 1 alone (D > 128): on return the first D * idiff_symband_ld() doubles of scratch hold the lower band,
+ * band[j * ld + k] = B[j + k][j], k <= 32 (the rest of a column is bulge room, zero). */
+int idiff_symband_ld(void);
+int idiff_symband_f64(double *G, int D, double *scratch, void *stream);
 int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double *offdiag, double *scratch, void *stream);
 int idiff_tridiag_eigvals_f64(const double *diag, const double *offdiag, int P, int D, double *eig, void *stream);
 

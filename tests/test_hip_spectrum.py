@@ -136,7 +136,7 @@ def test_stage_exports():
     np.testing.assert_allclose(G.cpu().numpy()[0], (c.T @ c).numpy(), rtol=1e-11, atol=1e-11)
     assert torch.equal(G[0], G[0].T)
     diag, off = torch.empty(1, D, device=DEV, dtype=torch.float64), torch.zeros(1, D, device=DEV, dtype=torch.float64)
-    scr = torch.empty(4 * D + 16 + ((D + 511) // 512 + 1) * D, device=DEV, dtype=torch.float64)
+    scr = torch.empty(max(1, lib.idiff_symtridiag_scratch_doubles(D)), device=DEV, dtype=torch.float64)
     Gc = G.clone()
     assert lib.idiff_symtridiag_f64(Gc.data_ptr(), 1, D, diag.data_ptr(), off.data_ptr(), scr.data_ptr(), st) == 0
     eig = torch.empty(1, D, device=DEV, dtype=torch.float64)
