@@ -26,6 +26,7 @@ constexpr int BW = 32;             // half-bandwidth after stage 1 = panel width
 constexpr int CORNER = 128;        // trailing block reduced in LDS by one workgroup (CORNER >= 4 BW keeps panels tall)
 constexpr int CHUNK = 256;         // rows of a panel per workgroup in the tall-skinny kernels
 constexpr int LDB = 2 * BW;        // leading dimension of the compact lower band: diagonals 0 .. 2BW-1 (bulge room)
+constexpr int PAD = 2;             // zero columns appended to the band (indices beyond it read as zero too): node 0 runs one sweep per column
 constexpr int KSPLIT_COLS = 512;   // columns of A' per workgroup of the Y = A' V kernel
 
 // ---------------------------------------------------------------------------------------------- MFMA helpers
@@ -42,16 +43,28 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// acc[16 x 16] += X[r0 .. r1)^T[:, i0 .. i0+16) * Y[r0 .. r1)[:, j0 .. j0+16)   (row-major X, Y; rows beyond `rows` are zero)
+// acc[16 x 16] += X[r0 .. r1)^T[:, i0 .. i0+16) * Y[r0 .. r1)[:, j0 .. j0+16)   (row-major X, Y).  Thirty-two rows (eight MFMA
+// k-steps) are fetched before the first MFMA is issued: the loop is a chain of L2 round trips otherwise.
 __device__ __forceinline__ void gram_tile(const double *__restrict__ X, int ldx, int i0, const double *__restrict__ Y, int ldy,
                                           int j0, int r0, int r1, doublex4 &acc) {
   const int lane = threadIdx.x & 63, fl = lane & 15, fk = lane >> 4;
-  for (int r = r0; r < r1; r += 4) {
-    const int rr = r + fk;
-    const double a = rr < r1 ? X[(int64_t)rr * ldx + i0 + fl] : 0.0;
-    const double b = rr < r1 ? Y[(int64_t)rr * ldy + j0 + fl] : 0.0;
-    acc = mfma(a, b, acc);
+  doublex4 acc2 = {0.0, 0.0, 0.0, 0.0};
+  for (int r = r0; r < r1; r += 32) {
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int rr = r + 4 * u + fk;
+      a[u] = rr < r1 ? X[(int64_t)rr * ldx + i0 + fl] : 0.0;
+      b[u] = rr < r1 ? Y[(int64_t)rr * ldy + j0 + fl] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      acc = mfma(a[u], b[u], acc);
+      acc2 = mfma(a[u + 1], b[u + 1], acc2);
+    }
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] += acc2[q];
 }
 
 __device__ __forceinline__ void store_tile_partial(double *__restrict__ dst /* [BW][BW] */, int i0, int j0, const doublex4 &acc) {
@@ -86,12 +99,26 @@ __global__ void __launch_bounds__(256) panel_gram_kernel(PanelGeom g, double *__
   store_tile_partial(Gpart + (int64_t)chunk * BW * BW, i0, j0, acc);
 }
 
-// Sum of `n` BW x BW partials into LDS (pitch BW + 1), symmetrised from the upper triangle; 64 threads.
+// Sum of `n` BW x BW partials into LDS (pitch BW + 1), symmetrised from the upper triangle.  Every thread of the
+// workgroup takes BW*BW / blockDim elements; the loop over the partials is unrolled so that a thread keeps 16 loads in
+// flight (one wave walking the partials one at a time spent 50 us of L2 round trips here).
 __device__ __forceinline__ void reduce_partials(const double *__restrict__ part, int n, double (*M)[BW + 1], bool symmetric) {
-  for (int e = threadIdx.x; e < BW * BW; e += blockDim.x) {
-    double s = 0.0;
-    for (int c = 0; c < n; ++c) s += part[(int64_t)c * BW * BW + e];
-    M[e / BW][e % BW] = s;
+  constexpr int PER = 4;
+  for (int e0 = threadIdx.x; e0 < BW * BW; e0 += blockDim.x * PER) {
+    double s[PER] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int c = 0; c < n; ++c) {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int e = e0 + q * blockDim.x;
+        if (e < BW * BW) s[q] += part[(int64_t)c * BW * BW + e];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = e0 + q * blockDim.x;
+      if (e < BW * BW) M[e / BW][e % BW] = s[q];
+    }
   }
   __syncthreads();
   if (symmetric) {
@@ -103,46 +130,78 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
   }
 }
 
-// Upper Cholesky factor R (G = R^T R) of the Jacobi-scaled matrix in LDS, pivots clamped: a column whose pivot is not
-// positive keeps R[j][j] = 1 and a zero row (its Q column comes out ~0 and is dealt with by the orthogonal T below).
-// On exit M holds R in its upper triangle (scaling folded back in), zeros below.  One wave (threads 0..63).
-__device__ void cholesky_upper(double (*M)[BW + 1], double *dsc /* [BW] */) {
-  const int tid = threadIdx.x;
-  if (tid < BW) { const double d = M[tid][tid]; dsc[tid] = d > 0.0 ? sqrt(d) : 1.0; }
+// Upper Cholesky factor R (G = R^T R) of the Jacobi-scaled symmetric matrix M (LDS, pitch BW + 1), pivots clamped: a
+// column whose pivot is not positive keeps R[j][j] = 1 and a zero row (its Q column comes out ~0; the T factor built from
+// the stored V keeps the block reflector orthogonal whatever happens here).  One wave: lane i < BW keeps ROW i of the
+// working matrix in registers (the matrix is symmetric, so a[j] is also the lane's element of column j); per step one
+// LDS word per lane broadcasts column j, everything else is register arithmetic.  On exit M holds R (upper, scaling
+// folded back in), zeros below.
+__device__ __forceinline__ void cholesky_upper(double (*M)[BW + 1], double *dsc /* [BW] */, double (*bc)[BW] /* [2][BW] */) {
+  const int tid = threadIdx.x, i = tid < BW ? tid : 0;
+  const double di = M[i][i] > 0.0 ? sqrt(M[i][i]) : 1.0;
+  if (tid < BW) dsc[tid] = di;
   __syncthreads();
-  for (int e = tid; e < BW * BW; e += blockDim.x) { const int i = e / BW, j = e % BW; M[i][j] /= dsc[i] * dsc[j]; }
-  __syncthreads();
+  double a[BW];                   // row i of the working matrix; a[j] turns into R[j][i] once step j is done
+#pragma unroll
+  for (int k = 0; k < BW; ++k) a[k] = M[i][k] / (di * dsc[k]);
+#pragma unroll
   for (int j = 0; j < BW; ++j) {
-    const double piv = M[j][j];
+    double (*buf) = bc[j & 1];
+    if (tid < BW) buf[tid] = a[j];
+    __syncthreads();
+    const double piv = buf[j];
     const bool ok = piv > 1e-30;
     const double rinv = ok ? 1.0 / sqrt(piv) : 0.0;
-    __syncthreads();
-    if (tid < BW) {
-      if (tid == j) M[j][j] = ok ? sqrt(piv) : 1.0;
-      else if (tid > j) M[j][tid] *= rinv;                     // row j of R (zero when the pivot was clamped)
-    }
-    __syncthreads();
-    // trailing update of the upper triangle: thread i owns row i (i > j), columns k >= i
-    if (tid > j && tid < BW) {
-      const double rji = M[j][tid];
-      for (int k = tid; k < BW; ++k) M[tid][k] -= rji * M[j][k];
-    }
-    __syncthreads();
+    const double rji = a[j] * rinv;                    // R[j][i], this lane's multiplier
+    a[j] = i == j ? (ok ? piv * rinv : 1.0) : (i > j ? rji : 0.0);
+#pragma unroll
+    for (int k = j + 1; k < BW; ++k) a[k] -= rji * (buf[k] * rinv);
   }
-  for (int e = tid; e < BW * BW; e += blockDim.x) {
-    const int i = e / BW, j = e % BW;
-    M[i][j] = i <= j ? M[i][j] * dsc[j] : 0.0;
+  __syncthreads();
+  if (tid < BW) {
+#pragma unroll
+    for (int j = 0; j < BW; ++j) M[j][i] = a[j] * di;    // R[j][i] (zero for j > i), column scaling folded back
+  }
+  __syncthreads();
+}
+
+// LU without pivoting of the matrix in LDS (in place: unit-lower multipliers below the diagonal, U on and above it).
+// Lane i keeps row i in registers; the pivot row is passed through LDS by its owner.
+__device__ __forceinline__ void lu_nopivot(double (*Bm)[BW + 1], double (*bc)[BW] /* [2][BW] */) {
+  const int tid = threadIdx.x, i = tid < BW ? tid : 0;
+  double a[BW];
+#pragma unroll
+  for (int k = 0; k < BW; ++k) a[k] = Bm[i][k];
+#pragma unroll
+  for (int j = 0; j < BW - 1; ++j) {
+    double (*buf) = bc[j & 1];
+    if (tid == j) {
+#pragma unroll
+      for (int k = j; k < BW; ++k) buf[k] = a[k];
+    }
+    __syncthreads();
+    if (i > j) {
+      const double l = a[j] / buf[j];
+      a[j] = l;
+#pragma unroll
+      for (int k = j + 1; k < BW; ++k) a[k] -= l * buf[k];
+    }
+  }
+  if (tid < BW) {
+#pragma unroll
+    for (int k = 0; k < BW; ++k) Bm[i][k] = a[k];
   }
   __syncthreads();
 }
 
 // k2: R1 = chol(sum Gpart)
-__global__ void __launch_bounds__(64) panel_chol1_kernel(const double *__restrict__ Gpart, int nchunk, double *__restrict__ R1) {
+__global__ void __launch_bounds__(256) panel_chol1_kernel(const double *__restrict__ Gpart, int nchunk, double *__restrict__ R1) {
   __shared__ double M[BW][BW + 1];
   __shared__ double dsc[BW];
+  __shared__ double bc[2][BW];
   reduce_partials(Gpart, nchunk, M, true);
-  cholesky_upper(M, dsc);
-  for (int e = threadIdx.x; e < BW * BW; e += 64) R1[e] = M[e / BW][e % BW];
+  cholesky_upper(M, dsc, bc);
+  for (int e = threadIdx.x; e < BW * BW; e += blockDim.x) R1[e] = M[e / BW][e % BW];
 }
 
 // x <- x R^-1 for one row x (forward substitution over the columns of the upper-triangular R held in LDS).
@@ -186,16 +245,17 @@ __global__ void __launch_bounds__(256) panel_q_kernel(PanelGeom g, const double 
 
 // k4: R2 = chol(sum Gpart2); Q1_top = Q_top R2^-1; S' = -sign(diag Q1_top); LU (no pivoting) of I - Q1_top S' = V_top U'.
 // Outputs (all BW x BW): R2, U' (upper), Vtop (unit lower), sgn[BW] = S'.
-__global__ void __launch_bounds__(64) panel_hr_kernel(const double *__restrict__ Gpart2, int nchunk, const double *__restrict__ Q,
+__global__ void __launch_bounds__(256) panel_hr_kernel(const double *__restrict__ Gpart2, int nchunk, const double *__restrict__ Q,
                                                       double *__restrict__ R2out, double *__restrict__ Uout,
                                                       double *__restrict__ Vtop, double *__restrict__ sgn) {
   __shared__ double M[BW][BW + 1];
   __shared__ double Bm[BW][BW + 1];
   __shared__ double dsc[BW];
+  __shared__ double bc[2][BW];
   const int tid = threadIdx.x;
   reduce_partials(Gpart2, nchunk, M, true);
-  cholesky_upper(M, dsc);
-  for (int e = tid; e < BW * BW; e += 64) R2out[e] = M[e / BW][e % BW];
+  cholesky_upper(M, dsc, bc);
+  for (int e = tid; e < BW * BW; e += blockDim.x) R2out[e] = M[e / BW][e % BW];
   // Q1_top rows
   if (tid < BW) {
     double x[BW];
@@ -208,24 +268,15 @@ __global__ void __launch_bounds__(64) panel_hr_kernel(const double *__restrict__
   __syncthreads();
   if (tid < BW) dsc[tid] = Bm[tid][tid] >= 0.0 ? -1.0 : 1.0;      // S'
   __syncthreads();
-  for (int e = tid; e < BW * BW; e += 64) {
+  for (int e = tid; e < BW * BW; e += blockDim.x) {
     const int i = e / BW, j = e % BW;
     Bm[i][j] = (i == j ? 1.0 : 0.0) - Bm[i][j] * dsc[j];
   }
   __syncthreads();
   // LU without pivoting (diagonal entries start at 1 + |q_ii| >= 1; Ballard et al., "Reconstructing Householder vectors
   // from TSQR": the multipliers stay bounded by 1 for an orthonormal Q1)
-  for (int j = 0; j < BW; ++j) {
-    const double piv = Bm[j][j];
-    __syncthreads();
-    if (tid > j && tid < BW) {
-      const double l = Bm[tid][j] / piv;
-      Bm[tid][j] = l;
-      for (int k = j + 1; k < BW; ++k) Bm[tid][k] -= l * Bm[j][k];
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < BW * BW; e += 64) {
+  lu_nopivot(Bm, bc);
+  for (int e = tid; e < BW * BW; e += blockDim.x) {
     const int i = e / BW, j = e % BW;
     Uout[e] = i <= j ? Bm[i][j] : 0.0;
     Vtop[e] = i > j ? Bm[i][j] : (i == j ? 1.0 : 0.0);
@@ -279,32 +330,33 @@ __global__ void __launch_bounds__(256) panel_v_kernel(PanelGeom g, const double 
 // k6: Tinv = striu(V^T V) + diag(V^T V) / 2 (upper triangular; T itself is never formed: every use is a triangular solve);
 //     C = T^T (V^T P) = Tinv^-T (V^T P);  the panel's surviving block R = P_top - V_top C goes back into A (upper triangle,
 //     mirrored), C is kept for the residual check of k10.
-__global__ void __launch_bounds__(64) panel_t_kernel(PanelGeom g, const double *__restrict__ VtVpart, const double *__restrict__ VtPpart,
+__global__ void __launch_bounds__(256) panel_t_kernel(PanelGeom g, const double *__restrict__ VtVpart, const double *__restrict__ VtPpart,
                                                      const double *__restrict__ Vtop, double *__restrict__ Tinv, double *__restrict__ C) {
   __shared__ double M[BW][BW + 1];
   __shared__ double W[BW][BW + 1];
   const int tid = threadIdx.x;
   reduce_partials(VtVpart, g.nchunk, M, true);
-  for (int e = tid; e < BW * BW; e += 64) {
+  for (int e = tid; e < BW * BW; e += blockDim.x) {
     const int i = e / BW, j = e % BW;
     const double t = i < j ? M[i][j] : (i == j ? 0.5 * M[i][i] : 0.0);
     Tinv[e] = t;
   }
   __syncthreads();
-  for (int e = tid; e < BW * BW; e += 64) { const int i = e / BW, j = e % BW; M[i][j] = i < j ? M[i][j] : (i == j ? 0.5 * M[i][i] : 0.0); }
+  for (int e = tid; e < BW * BW; e += blockDim.x) { const int i = e / BW, j = e % BW; M[i][j] = i < j ? M[i][j] : (i == j ? 0.5 * M[i][i] : 0.0); }
   reduce_partials(VtPpart, g.nchunk, W, false);
   // C = Tinv^-T W: column c of C solves Tinv^T x = W[:, c] (forward substitution, Tinv^T lower); thread c owns column c
-  if (tid < BW) {
-    for (int i = 0; i < BW; ++i) {
-      double s = W[i][tid];
-      for (int k = 0; k < i; ++k) s -= M[k][i] * W[k][tid];
-      W[i][tid] = s / M[i][i];
-    }
+  if (tid < BW) {          // Tinv^T x = w has the recurrence of x Tinv = w^T: the row solver on a register copy
+    double x[BW];
+#pragma unroll
+    for (int i = 0; i < BW; ++i) x[i] = W[i][tid];
+    row_solve_upper(x, M);
+#pragma unroll
+    for (int i = 0; i < BW; ++i) W[i][tid] = x[i];
   }
   __syncthreads();
-  for (int e = tid; e < BW * BW; e += 64) C[e] = W[e / BW][e % BW];
+  for (int e = tid; e < BW * BW; e += blockDim.x) C[e] = W[e / BW][e % BW];
   // R = P_top - V_top C, upper triangle kept (what is below is rounding noise of an exact annihilation)
-  for (int e = tid; e < BW * BW; e += 64) {
+  for (int e = tid; e < BW * BW; e += blockDim.x) {
     const int i = e / BW, j = e % BW;
     double r = 0.0;
     if (i <= j) {
@@ -314,7 +366,7 @@ __global__ void __launch_bounds__(64) panel_t_kernel(PanelGeom g, const double *
     M[i][j] = r;
   }
   __syncthreads();
-  for (int e = tid; e < BW * BW; e += 64) {
+  for (int e = tid; e < BW * BW; e += blockDim.x) {
     const int i = e / BW, j = e % BW;
     g.A[(int64_t)(g.lo + i) * g.D + g.j0 + j] = M[i][j];
     g.A[(int64_t)(g.j0 + j) * g.D + g.lo + i] = M[i][j];
@@ -331,19 +383,27 @@ __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const doub
   const int c0 = ks * KSPLIT_COLS, c1 = min(g.m, c0 + KSPLIT_COLS);
   const double *arow = g.A + (int64_t)(g.lo + min(row, g.m - 1)) * g.D + g.lo;
   doublex4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-  for (int c = c0; c < c1; c += 16) {
-    double a[4];
-    const int kb = c + 4 * fk;
+  for (int c = c0; c < c1; c += 32) {
+    double a[2][4], b0[2][4], b1[2][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = (kb + u < c1 && row < g.m) ? arow[kb + u] : 0.0;
+    for (int h = 0; h < 2; ++h) {
+      const int kb = c + 16 * h + 4 * fk;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = kb + u;
-      const double b0 = k < c1 ? V[(int64_t)k * BW + fl] : 0.0;
-      const double b1 = k < c1 ? V[(int64_t)k * BW + 16 + fl] : 0.0;
-      acc0 = mfma(a[u], b0, acc0);
-      acc1 = mfma(a[u], b1, acc1);
+      for (int u = 0; u < 4; ++u) {
+        const int k = kb + u;
+        const bool in = k < c1;
+        a[h][u] = (in && row < g.m) ? arow[k] : 0.0;
+        b0[h][u] = in ? V[(int64_t)k * BW + fl] : 0.0;
+        b1[h][u] = in ? V[(int64_t)k * BW + 16 + fl] : 0.0;
+      }
     }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc0 = mfma(a[h][u], b0[h][u], acc0);
+        acc1 = mfma(a[h][u], b1[h][u], acc1);
+      }
   }
   double *yp = Ypart + ((int64_t)ks * g.m) * BW;
 #pragma unroll
@@ -364,6 +424,7 @@ __global__ void __launch_bounds__(256) trailing_yk_kernel(PanelGeom g, const dou
   for (int e = tid; e < (r1 - r0) * BW; e += 256) {
     const int64_t idx = (int64_t)r0 * BW + e;
     double s = 0.0;
+#pragma unroll 8
     for (int k = 0; k < nks; ++k) s += Ypart[(int64_t)k * g.m * BW + idx];
     Y[idx] = s;
   }
@@ -377,16 +438,16 @@ __global__ void __launch_bounds__(256) trailing_yk_kernel(PanelGeom g, const dou
 }
 
 // k9: W2 = -(1/2) T^T K T = -(1/2) Tinv^-T K Tinv^-1 with K = sum Kpart (symmetric)
-__global__ void __launch_bounds__(64) trailing_w2_kernel(const double *__restrict__ Kpart, int nchunk, const double *__restrict__ Tinv,
+__global__ void __launch_bounds__(256) trailing_w2_kernel(const double *__restrict__ Kpart, int nchunk, const double *__restrict__ Tinv,
                                                          double *__restrict__ W2) {
   __shared__ double K[BW][BW + 1];
   __shared__ double Ti[BW][BW + 1];
   const int tid = threadIdx.x;
   reduce_partials(Kpart, nchunk, K, false);
-  for (int e = tid; e < BW * BW; e += 64) Ti[e / BW][e % BW] = Tinv[e];
+  for (int e = tid; e < BW * BW; e += blockDim.x) Ti[e / BW][e % BW] = Tinv[e];
   __syncthreads();
   // symmetrise K (V^T A' V of a symmetric A' up to rounding)
-  for (int e = tid; e < BW * BW; e += 64) { const int i = e / BW, j = e % BW; if (i < j) { const double s = 0.5 * (K[i][j] + K[j][i]); K[i][j] = s; K[j][i] = s; } }
+  for (int e = tid; e < BW * BW; e += blockDim.x) { const int i = e / BW, j = e % BW; if (i < j) { const double s = 0.5 * (K[i][j] + K[j][i]); K[i][j] = s; K[j][i] = s; } }
   __syncthreads();
   // rows: K <- K Tinv^-1 (thread i owns row i)
   if (tid < BW) {
@@ -400,14 +461,15 @@ __global__ void __launch_bounds__(64) trailing_w2_kernel(const double *__restric
   __syncthreads();
   // columns: K <- Tinv^-T K (thread c owns column c; Tinv^T is lower triangular)
   if (tid < BW) {
-    for (int i = 0; i < BW; ++i) {
-      double s = K[i][tid];
-      for (int k = 0; k < i; ++k) s -= Ti[k][i] * K[k][tid];
-      K[i][tid] = s / Ti[i][i];
-    }
+    double x[BW];
+#pragma unroll
+    for (int i = 0; i < BW; ++i) x[i] = K[i][tid];
+    row_solve_upper(x, Ti);
+#pragma unroll
+    for (int i = 0; i < BW; ++i) K[i][tid] = x[i];
   }
   __syncthreads();
-  for (int e = tid; e < BW * BW; e += 64) W2[e] = -0.5 * K[e / BW][e % BW];
+  for (int e = tid; e < BW * BW; e += blockDim.x) W2[e] = -0.5 * K[e / BW][e % BW];
 }
 
 // k10: Z = Y Tinv^-1 + V W2 (one thread per row); rows >= BW of the panel are checked (|| P_low - V_low C ||^2 is what
@@ -589,7 +651,7 @@ __global__ void __launch_bounds__(256) corner_kernel(double *__restrict__ A, int
 // AB[j][k] = A[j + k][j] for k <= BW (lower band, column-major), zero for BW < k < 2 BW (room for the bulges).
 __global__ void __launch_bounds__(256) extract_band_kernel(const double *__restrict__ A, int D, double *__restrict__ AB) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)D * LDB) return;
+  if (e >= (int64_t)(D + PAD) * LDB) return;
   const int j = (int)(e / LDB), k = (int)(e % LDB);
   AB[e] = (k <= BW && j + k < D) ? A[(int64_t)(j + k) * D + j] : 0.0;
 }
@@ -616,82 +678,351 @@ __device__ __forceinline__ void make_house(double x0, double tail, double &alpha
   tau = 2.0 / (v0 * v0 + tail);
 }
 
-__global__ void __launch_bounds__(64) chase_kernel(ChaseArgs g) {
-  __shared__ double W[2 * BW][BW + 1];
-  __shared__ double v[BW], w[BW], v2[BW], q[BW];
-  const int lane = threadIdx.x;
+// Thread (r = tid >> 2, part = tid & 3) keeps row r of the 2BW x BW window, columns [8 part, 8 part + 8), in registers
+// (rows < BW: the diagonal block, symmetric, both triangles; rows >= BW: the block below).  Matrix-vector products are
+// partial sums over the 8 columns + two shuffles; the rank-two / rank-one updates are local.
+__global__ void __launch_bounds__(256) chase_kernel(ChaseArgs g) {
+  __shared__ double v[BW], pq[2 * BW], x2[BW], v2[BW], dpart[2][BW];
+  __shared__ double sc[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = g.s_hi - blockIdx.x, t = g.k - 2 * s;
   const int D = g.D;
   const int a = s + 1 + t * BW;
   if (s < 0 || t < 0 || D - a < 2) return;
   const int e = min(a + BW, D), e2 = min(e + BW, D);
-  const int len = e - a, len2 = e2 - e;          // diagonal block len x len, lower block len2 x len
+  const int len = e - a, len2 = e2 - e;          // diagonal block len x len, block below len2 x len
   double *AB = g.AB;
-  // load: column c of the window = rows [a + c, e2) of band column a + c, contiguous
-  for (int c = 0; c < len; ++c) {
-    const int rows = e2 - (a + c);
-    const double *col = AB + (int64_t)(a + c) * LDB;
-    if (lane < rows) W[c + lane][c] = col[lane];
+  const int r = tid >> 2, c0 = (tid & 3) * 8;
+  const bool diag_row = r < BW;
+  const int gr = diag_row ? a + r : e + (r - BW);                 // global row of this thread
+  const bool row_ok = diag_row ? r < len : (r - BW) < len2;
+  double x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j, gc = a + c;
+    double val = 0.0;
+    if (row_ok && c < len) {
+      // lower band storage: (i, j) with i >= j sits at AB[j * LDB + i - j]
+      val = gr >= gc ? AB[(int64_t)gc * LDB + (gr - gc)] : AB[(int64_t)gr * LDB + (gc - gr)];
+    }
+    x[j] = val;
   }
-  __syncthreads();
-  for (int i = lane; i < len * len; i += 64) { const int r = i / len, c = i % len; if (r < c) W[r][c] = W[c][r]; }
   double tau;
   if (t == 0) {
-    const double *col = AB + (int64_t)s * LDB;               // column s: rows [a, e) are diagonals 1 .. len
-    const double x = lane < len ? col[1 + lane] : 0.0;
-    const double tail = wave_sum(lane >= 1 && lane < len ? x * x : 0.0);
-    double alpha, v0;
-    make_house(__shfl(x, 0, 64), tail, alpha, v0, tau);
-    if (lane < len) v[lane] = lane == 0 ? v0 : x;
-    if (lane < len) AB[(int64_t)s * LDB + 1 + lane] = lane == 0 ? alpha : 0.0;
+    if (wave == 0) {
+      const double *col = AB + (int64_t)s * LDB;             // column s: rows [a, e) are diagonals 1 .. len
+      const double xv = lane < len ? col[1 + lane] : 0.0;
+      const double tail = wave_sum(lane >= 1 && lane < len ? xv * xv : 0.0);
+      double alpha, v0, tl;
+      make_house(__shfl(xv, 0, 64), tail, alpha, v0, tl);
+      if (lane < BW) v[lane] = lane < len ? (lane == 0 ? v0 : xv) : 0.0;
+      if (lane < len) AB[(int64_t)s * LDB + 1 + lane] = lane == 0 ? alpha : 0.0;
+      if (lane == 0) sc[0] = tl;
+    }
   } else {
     const double *src = g.vs + (int64_t)s * (BW + 1);
-    if (lane < len) v[lane] = src[lane];
-    tau = src[BW];
+    if (tid < BW) v[tid] = tid < len ? src[tid] : 0.0;
+    if (tid == 0) sc[0] = src[BW];
   }
   __syncthreads();
+  tau = sc[0];
   if (tau != 0.0) {
-    // (1) p = tau * Dg v ; w = p - (tau/2)(p.v) v ; Dg -= v w^T + w v^T        lanes [0, len)
-    double p = 0.0;
-    if (lane < len) { for (int c = 0; c < len; ++c) p += W[lane][c] * v[c]; p *= tau; }
-    const double pv = wave_sum(lane < len ? p * v[lane] : 0.0);
-    if (lane < len) w[lane] = p - 0.5 * tau * pv * v[lane];
-    // (2) q = tau * Ob v                                                     lanes [32, 32 + len2)
-    const int r2 = lane - 32;
-    if (r2 >= 0 && r2 < len2) { double s2 = 0.0; for (int c = 0; c < len; ++c) s2 += W[len + r2][c] * v[c]; q[r2] = tau * s2; }
+    // rows < BW: p_r = tau (Dg v)_r ; rows >= BW: q_r = tau (Ob v)_r
+    double part = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part += x[j] * v[c0 + j];
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    if ((tid & 3) == 0) pq[r] = tau * part;
     __syncthreads();
-    if (lane < len) { const double vr = v[lane], wr = w[lane]; for (int c = 0; c < len; ++c) W[lane][c] -= vr * w[c] + wr * v[c]; }
-    if (r2 >= 0 && r2 < len2) { const double qr = q[r2]; for (int c = 0; c < len; ++c) W[len + r2][c] -= qr * v[c]; }
-    __syncthreads();
+    // K = (tau / 2) p.v, every wave for itself
+    const double pv = wave_sum(lane < BW ? pq[lane] * v[lane] : 0.0);
+    const double kk = 0.5 * tau * pv;
+    if (diag_row) {
+      const double vr = v[r], wr = pq[r] - kk * vr;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const double vc = v[c0 + j], wc = pq[c0 + j] - kk * vc; x[j] -= vr * wc + wr * vc; }
+    } else {
+      const double qr = pq[r];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] -= qr * v[c0 + j];
+    }
   }
-  // (3) next reflector from the lower block's first column
-  if (len2 >= 2) {
-    const double x = lane < len2 ? W[len + lane][0] : 0.0;
-    const double tail = wave_sum(lane >= 1 && lane < len2 ? x * x : 0.0);
-    double alpha, v0, tau2;
-    make_house(__shfl(x, 0, 64), tail, alpha, v0, tau2);
-    if (lane < len2) v2[lane] = lane == 0 ? v0 : x;
+  // next reflector from the first column of the block below
+  const bool chase_on = len2 >= 2;
+  if (chase_on) {
+    if (!diag_row && (tid & 3) == 0) x2[r - BW] = x[0];
     __syncthreads();
-    if (lane < len2) W[len + lane][0] = lane == 0 ? alpha : 0.0;
-    if (tau2 != 0.0) {
-      // columns 1 .. len-1: d_c = tau2 * v2 . Ob[:, c] (lane c), Ob[:, c] -= d_c v2
-      if (lane >= 1 && lane < len) {
-        double d = 0.0;
-        for (int r = 0; r < len2; ++r) d += v2[r] * W[len + r][lane];
-        d *= tau2;
-        for (int r = 0; r < len2; ++r) W[len + r][lane] -= d * v2[r];
+    double alpha2, v20, tau2;
+    {
+      const double xv = lane < len2 ? x2[lane] : 0.0;
+      const double tail = wave_sum(lane >= 1 && lane < len2 ? xv * xv : 0.0);
+      make_house(x2[0], tail, alpha2, v20, tau2);          // every wave computes the same numbers
+      if (wave == 0 && lane < BW) v2[lane] = lane < len2 ? (lane == 0 ? v20 : xv) : 0.0;
+    }
+    __syncthreads();
+    if (!diag_row) {
+      // d_c = tau2 * sum_r v2_r Ob[r][c] over the 32 rows of the block below = waves 2 and 3, 16 rows each
+      const double vr = v2[r - BW];
+      double dloc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        double dv = vr * x[j];
+        dv += __shfl_xor(dv, 4, 64); dv += __shfl_xor(dv, 8, 64); dv += __shfl_xor(dv, 16, 64); dv += __shfl_xor(dv, 32, 64);
+        dloc[j] = dv;
+      }
+      if (lane < 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dpart[wave - 2][lane * 8 + j] = dloc[j];
+      }
+    }
+    __syncthreads();
+    if (!diag_row) {
+      const double vr = v2[r - BW];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        const double dc = tau2 * (dpart[0][c] + dpart[1][c]);
+        if (c == 0) x[j] = (r == BW) ? alpha2 : 0.0;
+        else x[j] -= dc * vr;
       }
     }
     double *dst = g.vs + (int64_t)s * (BW + 1);
-    if (lane < len2) dst[lane] = v2[lane];
-    if (lane == 0) dst[BW] = tau2;
+    if (tid < BW) dst[tid] = v2[tid];
+    if (tid == 0) dst[BW] = tau2;
+  }
+  // store the lower triangle of the diagonal block and the block below
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j, gc = a + c;
+    if (row_ok && c < len && gr >= gc) AB[(int64_t)gc * LDB + (gr - gc)] = x[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- stage 2, systolic form
+// ONE launch: workgroup t ("node") owns chase step t of EVERY sweep.  Its window -- rows [a, a + 2BW) x columns
+// [a, a + BW), a = s + 1 + t BW -- lives in registers for the whole kernel (layout of chase_kernel) and slides by one
+// row and column per sweep.  What crosses workgroups are two 33-double messages per sweep:
+//   refl : node t -> t + 1, the reflector it made from the first column of its lower block (task (s, t + 1) needs it);
+//   col  : node t -> t - 1, the first column of its window after task (s, t): the column that enters node t - 1's window
+//          at sweep s + 1 (this IS the dependency (s + 1, t - 1) after (s, t)).
+// Messages are data-tagged 8-byte granules {32 data bits, sweep tag}: one agent-scope (sc1) store per granule, polled by
+// the consumer with agent-scope loads -- no flag, no fence, nothing cached on either side (MI355X_MICROARCH.md,
+// hand-off by granules).  Two slots per mailbox suffice: a producer can be at most one sweep ahead of its consumer.
+// The band is zero-padded by PAD columns, so every window is a full block (zero rows and columns are inert under the
+// reflections) and a message that no longer comes (the neighbour has run out of sweeps) is a message of zeros.
+// Node 0 emits the tridiagonal: e[s] when it makes the reflector of sweep s, d[s + 1] from its leaving column.
+// Every spin is bounded; on overflow the abort word is set, everybody leaves and the caller reports NaN.
+struct SysArgs {
+  const double *AB;           // [Dp][LDB]
+  unsigned long long *mbox;   // [T][2 kinds][2 slots][128] granules, zeroed before the launch
+  double *diag, *offd;        // [D]
+  int *abort_flag;
+  int D, Dp;
+};
+constexpr int MSG = BW + 1;           // doubles per message
+constexpr int GRAN = 2 * MSG;         // granules per message
+constexpr long SPIN_LIMIT = 1L << 24;
+
+__device__ __forceinline__ unsigned long long *mailbox(const SysArgs &g, int node, int kind, int slot) {
+  return g.mbox + (((int64_t)node * 2 + kind) * 2 + slot) * 128;
+}
+
+// threads [0, GRAN) publish `src` (LDS, MSG doubles) with tag `tag`
+__device__ __forceinline__ void msg_send(unsigned long long *box, const double *src, unsigned tag) {
+  const int tid = threadIdx.x;
+  if (tid < GRAN) {
+    const unsigned half = reinterpret_cast<const unsigned *>(src)[tid];
+    __hip_atomic_store(box + tid, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// threads [0, GRAN) wait for their granule of tag `tag` and put it into `dst` (LDS); returns false (to those threads) on abort
+__device__ __forceinline__ void msg_recv(const unsigned long long *box, double *dst, unsigned tag, int *abort_flag) {
+  const int tid = threadIdx.x;
+  if (tid < GRAN) {
+    long spins = 0;
+    for (;;) {
+      const unsigned long long u = __hip_atomic_load(box + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(u >> 32) == tag) { reinterpret_cast<unsigned *>(dst)[tid] = (unsigned)u; break; }
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255) == 0) {
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (spins > SPIN_LIMIT) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
+  __shared__ double v[BW], pq[2 * BW], x2[BW], v2[BW], dpart[2][BW];
+  __shared__ double msg_in[MSG], msg_out[MSG], colbuf[MSG], rowbuf[BW], edge[4][BW], xcol[BW];
+  __shared__ double sc[2];
+  __shared__ int ab;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.x, Dp = g.Dp;
+  const int S = Dp - 2 - t * BW;                 // sweeps this node takes part in: task (s, t) exists iff Dp - (s + 1 + t BW) >= 2
+  if (S <= 0) return;
+  const double *AB = g.AB;
+  const int r = tid >> 2, part = tid & 3, c0 = part * 8;
+  const bool diag_row = r < BW;
+  double x[8];
+  {
+    const int a = 1 + t * BW, gr = a + r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int gc = a + c0 + j;
+      double val = 0.0;
+      if (gr < Dp && gc < Dp) val = gr >= gc ? AB[(int64_t)gc * LDB + (gr - gc)] : AB[(int64_t)gr * LDB + (gc - gr)];
+      x[j] = val;
+    }
+    if (t == 0) {
+      if (tid < BW) xcol[tid] = AB[1 + tid];       // column 0, rows 1 .. BW
+      if (tid == 0) g.diag[0] = AB[0];
+    }
+    if (tid == 0) ab = 0;
   }
   __syncthreads();
-  for (int c = 0; c < len; ++c) {
-    const int rows = e2 - (a + c);
-    double *col = AB + (int64_t)(a + c) * LDB;
-    if (lane < rows) col[lane] = W[c + lane][c];
+  for (int s = 0; s < S; ++s) {
+    if (s > 0) {
+      // ---- slide the window by one: W'[r][c] = W[r + 1][c + 1]; the new last column comes from the mirror of the
+      //      old lower block's first row, node t + 1's column message of sweep s - 1, and its alpha
+      const bool has = Dp - (s + (t + 1) * BW) >= 2;          // task (s - 1, t + 1) exists
+      if (has) msg_recv(mailbox(g, t, 1, (s - 1) & 1), msg_in, (unsigned)s, g.abort_flag);
+      else if (tid < MSG) msg_in[tid] = 0.0;
+      if (r == BW) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rowbuf[c0 + j] = x[j];
+      }
+      if ((r & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) edge[wave][c0 + j] = x[j];
+      }
+      __syncthreads();
+      double y[9];                                             // row r + 1, columns c0 .. c0 + 8
+      const bool last_in_wave = (r & 15) == 15;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = __shfl_down(x[j], 4, 64);
+      y[8] = __shfl_down(x[0], 5, 64);                         // thread (r + 1, part + 1), meaningful for part < 3
+      if (last_in_wave) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = wave < 3 ? edge[wave + 1][c0 + j] : 0.0;
+        y[8] = (wave < 3 && part < 3) ? edge[wave + 1][c0 + 8] : 0.0;
+      }
+      if (part == 3) {
+        // new last column (window column BW - 1 = global column a + BW of the old window)
+        double nv;
+        if (r < BW - 1) nv = rowbuf[r + 1];
+        else if (r == BW - 1) nv = msg_in[0];
+        else if (r < 2 * BW - 1) nv = msg_in[r - BW + 1];
+        else nv = msg_in[BW];
+        y[8] = nv;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = y[j + 1];
+      __syncthreads();
+    }
+    // ---- reflector of task (s, t)
+    if (t == 0) {
+      if (wave == 0) {
+        const double xv = lane < BW ? xcol[lane] : 0.0;
+        const double tail = wave_sum(lane >= 1 && lane < BW ? xv * xv : 0.0);
+        double alpha, v0, tl;
+        make_house(__shfl(xv, 0, 64), tail, alpha, v0, tl);
+        if (lane < BW) v[lane] = lane == 0 ? v0 : xv;
+        if (lane == 0) { sc[0] = tl; if (s < g.D) g.offd[s] = alpha; }
+      }
+    } else {
+      msg_recv(mailbox(g, t, 0, s & 1), msg_in, (unsigned)(s + 1), g.abort_flag);
+      __syncthreads();
+      if (tid < BW) v[tid] = msg_in[tid];
+      if (tid == 0) sc[0] = msg_in[BW];
+    }
+    __syncthreads();
+    if (__hip_atomic_load(g.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ab = 1;   // benign race: all write 1
+    const double tau = sc[0];
+    if (tau != 0.0) {
+      double ps = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ps += x[j] * v[c0 + j];
+      ps += __shfl_xor(ps, 1, 64);
+      ps += __shfl_xor(ps, 2, 64);
+      if (part == 0) pq[r] = tau * ps;
+      __syncthreads();
+      const double pv = wave_sum(lane < BW ? pq[lane] * v[lane] : 0.0);
+      const double kk = 0.5 * tau * pv;
+      if (diag_row) {
+        const double vr = v[r], wr = pq[r] - kk * vr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double vc = v[c0 + j], wc = pq[c0 + j] - kk * vc; x[j] -= vr * wc + wr * vc; }
+      } else {
+        const double qr = pq[r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] -= qr * v[c0 + j];
+      }
+    }
+    // ---- next reflector from the first column of the lower block, applied from the left to its other columns
+    if (!diag_row && part == 0) x2[r - BW] = x[0];
+    __syncthreads();
+    if (ab) break;                                            // uniform: `ab` was written before the barrier above
+    double alpha2, v20, tau2;
+    {
+      const double xv = lane < BW ? x2[lane] : 0.0;
+      const double tail = wave_sum(lane >= 1 && lane < BW ? xv * xv : 0.0);
+      make_house(x2[0], tail, alpha2, v20, tau2);
+      if (wave == 0 && lane < BW) { const double vv = lane == 0 ? v20 : xv; v2[lane] = vv; msg_out[lane] = vv; }
+      if (tid == 0) msg_out[BW] = tau2;
+    }
+    __syncthreads();
+    if (Dp - (s + 1 + (t + 1) * BW) >= 2) msg_send(mailbox(g, t + 1, 0, s & 1), msg_out, (unsigned)(s + 1));   // task (s, t + 1) exists
+    if (!diag_row) {
+      const double vr = v2[r - BW];
+      double dloc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        double dv = vr * x[j];
+        dv += __shfl_xor(dv, 4, 64); dv += __shfl_xor(dv, 8, 64); dv += __shfl_xor(dv, 16, 64); dv += __shfl_xor(dv, 32, 64);
+        dloc[j] = dv;
+      }
+      if (lane < 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dpart[wave - 2][lane * 8 + j] = dloc[j];
+      }
+    }
+    __syncthreads();
+    if (!diag_row) {
+      const double vr = v2[r - BW];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        const double dc = tau2 * (dpart[0][c] + dpart[1][c]);
+        if (c == 0) x[j] = (r == BW) ? alpha2 : 0.0;
+        else x[j] -= dc * vr;
+      }
+    }
+    // ---- the window's first column (rows 0 .. BW) leaves: to node t - 1, or, on node 0, it is the next sweep's column
+    if (r <= BW && part == 0) colbuf[r] = x[0];
+    __syncthreads();
+    if (t > 0) {
+      msg_send(mailbox(g, t - 1, 1, s & 1), colbuf, (unsigned)(s + 1));
+    } else {
+      if (tid < BW) xcol[tid] = colbuf[tid + 1];
+      if (tid == 0 && s + 1 < g.D) g.diag[s + 1] = colbuf[0];
+    }
+    __syncthreads();
   }
+}
+
+// diag/offd come from the systolic kernel; poison them if the band reduction or the chase reported trouble
+__global__ void __launch_bounds__(256) finish_de_kernel(int D, double *__restrict__ diag, double *__restrict__ offd,
+                                                        const double *__restrict__ resid2, const double *__restrict__ fro2,
+                                                        double tol2, const int *__restrict__ abort_flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= D) return;
+  const bool bad = (*resid2 > tol2 * *fro2) || *abort_flag != 0;
+  const double nanv = __longlong_as_double(0x7ff8000000000000ll);
+  if (bad) { diag[i] = nanv; offd[i] = nanv; }
+  else if (i == D - 1) offd[i] = 0.0;
 }
 
 __global__ void __launch_bounds__(256) band_to_de_kernel(const double *__restrict__ AB, int D, double *__restrict__ diag,
@@ -723,7 +1054,7 @@ namespace idiff {
 int64_t sbr_scratch_doubles(int D) {
   const int64_t m = D;
   const int64_t nchunk = (m + CHUNK - 1) / CHUNK, nks = (m + KSPLIT_COLS - 1) / KSPLIT_COLS;
-  return (int64_t)D * LDB                     // band
+  return (int64_t)(D + PAD) * LDB             // band, zero-padded
          + (int64_t)D * (BW + 1)              // carried reflectors of stage 2
          + 4 * m * BW                         // Q, V, Y, Z
          + nks * m * BW                       // Ypart
@@ -735,7 +1066,7 @@ int64_t sbr_scratch_doubles(int D) {
 // AB[j * LDB + k] = B[j + k][j]).  Everything is enqueued on `st`.
 int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
   double *AB = scratch;
-  double *vs = AB + (int64_t)D * LDB;
+  double *vs = AB + (int64_t)(D + PAD) * LDB;
   double *Q = vs + (int64_t)D * (BW + 1);
   double *V = Q + (int64_t)D * BW, *Y = V + (int64_t)D * BW, *Z = Y + (int64_t)D * BW;
   const int64_t nchunk_max = (D + CHUNK - 1) / CHUNK, nks_max = (D + KSPLIT_COLS - 1) / KSPLIT_COLS;
@@ -758,14 +1089,14 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     g.A = G; g.D = D; g.j0 = j0; g.lo = j0 + BW; g.m = D - g.lo; g.nchunk = ceil_div(g.m, CHUNK);
     const int nks = ceil_div(g.m, KSPLIT_COLS);
     hipLaunchKernelGGL(panel_gram_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp);
-    hipLaunchKernelGGL(panel_chol1_kernel, dim3(1), dim3(64), 0, st, Gp, g.nchunk, R1);
+    hipLaunchKernelGGL(panel_chol1_kernel, dim3(1), dim3(256), 0, st, Gp, g.nchunk, R1);
     hipLaunchKernelGGL(panel_q_kernel, dim3(g.nchunk), dim3(256), 0, st, g, R1, Q, Gp);
-    hipLaunchKernelGGL(panel_hr_kernel, dim3(1), dim3(64), 0, st, Gp, g.nchunk, Q, R2, U, Vtop, sgn);
+    hipLaunchKernelGGL(panel_hr_kernel, dim3(1), dim3(256), 0, st, Gp, g.nchunk, Q, R2, U, Vtop, sgn);
     hipLaunchKernelGGL(panel_v_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Q, R2, U, Vtop, sgn, V, VtVp, VtPp);
-    hipLaunchKernelGGL(panel_t_kernel, dim3(1), dim3(64), 0, st, g, VtVp, VtPp, Vtop, Tinv, C);
+    hipLaunchKernelGGL(panel_t_kernel, dim3(1), dim3(256), 0, st, g, VtVp, VtPp, Vtop, Tinv, C);
     hipLaunchKernelGGL(trailing_y_kernel, dim3(ceil_div(g.m, 64), nks), dim3(256), 0, st, g, V, Ypart);
     hipLaunchKernelGGL(trailing_yk_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Ypart, nks, V, Y, Kp);
-    hipLaunchKernelGGL(trailing_w2_kernel, dim3(1), dim3(64), 0, st, Kp, g.nchunk, Tinv, W2);
+    hipLaunchKernelGGL(trailing_w2_kernel, dim3(1), dim3(256), 0, st, Kp, g.nchunk, Tinv, W2);
     hipLaunchKernelGGL(trailing_z_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Y, V, Tinv, W2, C, Z, scal);
     const int tiles = ceil_div(g.m, 64);
     hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, g, V, Z);
@@ -780,15 +1111,28 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
       return rc;
     if (n > BW + 1) hipLaunchKernelGGL(corner_kernel, dim3(1), dim3(256), lds, st, G, D, j0);
   }
-  hipLaunchKernelGGL(extract_band_kernel, dim3((unsigned)ceil_div64((int64_t)D * LDB, 256)), dim3(256), 0, st, G, D, AB);
+  hipLaunchKernelGGL(extract_band_kernel, dim3((unsigned)ceil_div64((int64_t)(D + PAD) * LDB, 256)), dim3(256), 0, st, G, D, AB);
   return launch_status("sbr_to_band");
 }
 
 // Stage 2: the band left in scratch by sbr_to_band -> diag / offd.
 int sbr_chase(int D, double *diag, double *offd, double *scratch, hipStream_t st) {
   double *AB = scratch;
-  double *vs = AB + (int64_t)D * LDB;
-  double *scal = scratch + sbr_scratch_doubles(D) - 16;
+  double *vs = AB + (int64_t)(D + PAD) * LDB;
+  double *scal = scratch + sbr_scratch_doubles(D) - 16;     // [0] residual^2, [1] ||G||_F^2, [2] abort word
+  if (!option(OPT_CHASE_WAVEFRONT)) {
+    SysArgs a;
+    a.AB = AB; a.mbox = reinterpret_cast<unsigned long long *>(vs); a.diag = diag; a.offd = offd;
+    a.abort_flag = reinterpret_cast<int *>(scal + 2); a.D = D; a.Dp = D + PAD;
+    const int T = ceil_div(a.Dp - 2, BW);                    // nodes with at least one sweep
+    hipError_t e = hipMemsetAsync(vs, 0, (size_t)T * 512 * sizeof(unsigned long long), st);
+    if (e == hipSuccess) e = hipMemsetAsync(scal + 2, 0, sizeof(double), st);
+    if (e != hipSuccess) { set_error("sbr: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(chase_systolic_kernel, dim3(T), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(finish_de_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, st, D, diag, offd, scal, scal + 1, 1e-22,
+                       reinterpret_cast<const int *>(scal + 2));
+    return launch_status("sbr_chase_systolic");
+  }
   // launch k = tasks with 2 s + t = k; task (s, t) exists iff D - (s + 1 + t BW) >= 2
   ChaseArgs c;
   c.AB = AB; c.vs = vs; c.D = D;
@@ -798,7 +1142,7 @@ int sbr_chase(int D, double *diag, double *offd, double *scratch, hipStream_t st
     int s_lo = num > 0 ? (int)((num + 2 * BW - 2) / (2 * BW - 1)) : 0;
     if (s_lo > s_hi) continue;
     c.k = k; c.s_hi = s_hi;
-    hipLaunchKernelGGL(chase_kernel, dim3(s_hi - s_lo + 1), dim3(64), 0, st, c);
+    hipLaunchKernelGGL(chase_kernel, dim3(s_hi - s_lo + 1), dim3(256), 0, st, c);
   }
   // tolerance^2 on residual^2 / ||G||_F^2: an exact annihilation leaves ~1e-30
   hipLaunchKernelGGL(band_to_de_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, st, AB, D, diag, offd, scal, scal + 1, 1e-22);
