@@ -24,10 +24,10 @@ typedef double doublex4 __attribute__((ext_vector_type(4)));
 
 constexpr int BW = 32;             // half-bandwidth after stage 1 = panel width
 constexpr int CORNER = 128;        // trailing block reduced in LDS by one workgroup (CORNER >= 4 BW keeps panels tall)
-constexpr int CHUNK = 256;         // rows of a panel per workgroup in the tall-skinny kernels
+constexpr int CHUNK = 128;         // minimum rows of a panel per workgroup in the tall-skinny kernels
 constexpr int LDB = 2 * BW;        // leading dimension of the compact lower band: diagonals 0 .. 2BW-1 (bulge room)
 constexpr int PAD = 2;             // zero columns appended to the band (indices beyond it read as zero too): node 0 runs one sweep per column
-constexpr int KSPLIT_COLS = 512;   // columns of A' per workgroup of the Y = A' V kernel
+constexpr int KSPLIT_COLS = 256;   // columns of A' per workgroup of the Y = A' V kernel (its V slice, 64 KB, sits in LDS)
 
 // ---------------------------------------------------------------------------------------------- MFMA helpers
 // v_mfma_f64_16x16x4_f64: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; the accumulator
@@ -35,6 +35,29 @@ constexpr int KSPLIT_COLS = 512;   // columns of A' per workgroup of the Y = A' 
 // consecutive k of its row with two 16-byte loads and feed them to four consecutive MFMAs (both operands permuted alike).
 __device__ __forceinline__ doublex4 mfma(double a, double b, doublex4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// v_rsq_f64 / v_rcp_f64 seeds (~2^-26 relative) + two Newton steps: full double accuracy without the ~150-instruction
+// IEEE sqrt / division sequences, which dominated the single-wave factorisations of the panel kernels.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+}
+
+// One wave exchanging data through LDS with itself: DS operations of a wave execute in order, so all that is needed is
+// that the compiler neither reorders nor caches across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -84,13 +107,14 @@ __device__ __forceinline__ void wave_tile(int &i0, int &j0) {
 struct PanelGeom {
   double *A;        // [D][D] row-major, both triangles
   int D, j0, lo, m; // panel columns [j0, j0+BW), rows [lo, D) with lo = j0 + BW, m = D - lo
-  int nchunk;       // ceil(m / CHUNK)
+  int chunk_rows;   // rows of the panel per workgroup of the tall-skinny kernels (= CHUNK <= 256: one row per thread)
+  int nchunk;       // ceil(m / chunk_rows)
 };
 
 // k1: Gpart[chunk] = P_chunk^T P_chunk
 __global__ void __launch_bounds__(256) panel_gram_kernel(PanelGeom g, double *__restrict__ Gpart) {
   const int chunk = blockIdx.x;
-  const int r0 = chunk * CHUNK, r1 = min(g.m, r0 + CHUNK);
+  const int r0 = chunk * g.chunk_rows, r1 = min(g.m, r0 + g.chunk_rows);
   const double *P = g.A + (int64_t)g.lo * g.D + g.j0;
   int i0, j0;
   wave_tile(i0, j0);
@@ -103,22 +127,19 @@ __global__ void __launch_bounds__(256) panel_gram_kernel(PanelGeom g, double *__
 // workgroup takes BW*BW / blockDim elements; the loop over the partials is unrolled so that a thread keeps 16 loads in
 // flight (one wave walking the partials one at a time spent 50 us of L2 round trips here).
 __device__ __forceinline__ void reduce_partials(const double *__restrict__ part, int n, double (*M)[BW + 1], bool symmetric) {
-  constexpr int PER = 4;
-  for (int e0 = threadIdx.x; e0 < BW * BW; e0 += blockDim.x * PER) {
-    double s[PER] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int c = 0; c < n; ++c) {
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int e = e0 + q * blockDim.x;
-        if (e < BW * BW) s[q] += part[(int64_t)c * BW * BW + e];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int e = e0 + q * blockDim.x;
-      if (e < BW * BW) M[e / BW][e % BW] = s[q];
-    }
+  // 256 threads x 4 consecutive elements = one BW x BW partial per pass; 16-byte loads, eight partials in flight
+  static_assert(BW * BW == 1024, "reduce_partials assumes 256 threads x 4 elements");
+  const int e0 = threadIdx.x * 4;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const double2 *src = reinterpret_cast<const double2 *>(part + e0);
+#pragma unroll 8
+  for (int c = 0; c < n; ++c) {
+    const double2 lo = src[(int64_t)c * (BW * BW / 2)], hi = src[(int64_t)c * (BW * BW / 2) + 1];
+    s0 += lo.x; s1 += lo.y; s2 += hi.x; s3 += hi.y;
+  }
+  if (threadIdx.x < 256) {
+    const int i = e0 / BW, j = e0 % BW;
+    M[i][j] = s0; M[i][j + 1] = s1; M[i][j + 2] = s2; M[i][j + 3] = s3;
   }
   __syncthreads();
   if (symmetric) {
@@ -137,36 +158,38 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
 // LDS word per lane broadcasts column j, everything else is register arithmetic.  On exit M holds R (upper, scaling
 // folded back in), zeros below.
 __device__ __forceinline__ void cholesky_upper(double (*M)[BW + 1], double *dsc /* [BW] */, double (*bc)[BW] /* [2][BW] */) {
+  // executed by wave 0 only (the other waves of the workgroup wait at the caller's barrier)
   const int tid = threadIdx.x, i = tid < BW ? tid : 0;
-  const double di = M[i][i] > 0.0 ? sqrt(M[i][i]) : 1.0;
-  if (tid < BW) dsc[tid] = di;
-  __syncthreads();
+  const double dii = M[i][i];
+  const double rdi = dii > 0.0 ? fast_rsqrt(dii) : 1.0;          // 1 / d_i
+  if (tid < BW) dsc[tid] = rdi;
+  wave_lds_sync();
   double a[BW];                   // row i of the working matrix; a[j] turns into R[j][i] once step j is done
 #pragma unroll
-  for (int k = 0; k < BW; ++k) a[k] = M[i][k] / (di * dsc[k]);
+  for (int k = 0; k < BW; ++k) a[k] = M[i][k] * (rdi * dsc[k]);
 #pragma unroll
   for (int j = 0; j < BW; ++j) {
     double (*buf) = bc[j & 1];
     if (tid < BW) buf[tid] = a[j];
-    __syncthreads();
+    wave_lds_sync();
     const double piv = buf[j];
     const bool ok = piv > 1e-30;
-    const double rinv = ok ? 1.0 / sqrt(piv) : 0.0;
+    const double rinv = ok ? fast_rsqrt(piv) : 0.0;
     const double rji = a[j] * rinv;                    // R[j][i], this lane's multiplier
     a[j] = i == j ? (ok ? piv * rinv : 1.0) : (i > j ? rji : 0.0);
 #pragma unroll
     for (int k = j + 1; k < BW; ++k) a[k] -= rji * (buf[k] * rinv);
   }
-  __syncthreads();
+  const double di = dii > 0.0 ? dii * rdi : 1.0;                  // d_i = sqrt(G_ii)
   if (tid < BW) {
 #pragma unroll
     for (int j = 0; j < BW; ++j) M[j][i] = a[j] * di;    // R[j][i] (zero for j > i), column scaling folded back
   }
-  __syncthreads();
+  wave_lds_sync();
 }
 
 // LU without pivoting of the matrix in LDS (in place: unit-lower multipliers below the diagonal, U on and above it).
-// Lane i keeps row i in registers; the pivot row is passed through LDS by its owner.
+// Lane i keeps row i in registers; the pivot row is passed through LDS by its owner.  Wave 0 only.
 __device__ __forceinline__ void lu_nopivot(double (*Bm)[BW + 1], double (*bc)[BW] /* [2][BW] */) {
   const int tid = threadIdx.x, i = tid < BW ? tid : 0;
   double a[BW];
@@ -179,9 +202,9 @@ __device__ __forceinline__ void lu_nopivot(double (*Bm)[BW + 1], double (*bc)[BW
 #pragma unroll
       for (int k = j; k < BW; ++k) buf[k] = a[k];
     }
-    __syncthreads();
+    wave_lds_sync();
     if (i > j) {
-      const double l = a[j] / buf[j];
+      const double l = a[j] * fast_rcp(buf[j]);
       a[j] = l;
 #pragma unroll
       for (int k = j + 1; k < BW; ++k) a[k] -= l * buf[k];
@@ -191,7 +214,7 @@ __device__ __forceinline__ void lu_nopivot(double (*Bm)[BW + 1], double (*bc)[BW
 #pragma unroll
     for (int k = 0; k < BW; ++k) Bm[i][k] = a[k];
   }
-  __syncthreads();
+  wave_lds_sync();
 }
 
 // k2: R1 = chol(sum Gpart)
@@ -200,7 +223,8 @@ __global__ void __launch_bounds__(256) panel_chol1_kernel(const double *__restri
   __shared__ double dsc[BW];
   __shared__ double bc[2][BW];
   reduce_partials(Gpart, nchunk, M, true);
-  cholesky_upper(M, dsc, bc);
+  if (threadIdx.x < 64) cholesky_upper(M, dsc, bc);
+  __syncthreads();
   for (int e = threadIdx.x; e < BW * BW; e += blockDim.x) R1[e] = M[e / BW][e % BW];
 }
 
@@ -211,7 +235,7 @@ __device__ __forceinline__ void row_solve_upper(double *x, const double (*R)[BW 
     double s = x[j];
 #pragma unroll
     for (int i = 0; i < j; ++i) s -= x[i] * R[i][j];
-    x[j] = s / R[j][j];
+    x[j] = s * fast_rcp(R[j][j]);
   }
 }
 
@@ -222,9 +246,9 @@ __global__ void __launch_bounds__(256) panel_q_kernel(PanelGeom g, const double 
   const int chunk = blockIdx.x, tid = threadIdx.x;
   for (int e = tid; e < BW * BW; e += 256) R[e / BW][e % BW] = R1[e];
   __syncthreads();
-  const int r0 = chunk * CHUNK, r1 = min(g.m, r0 + CHUNK);
+  const int r0 = chunk * g.chunk_rows, r1 = min(g.m, r0 + g.chunk_rows);
   const int row = r0 + tid;
-  if (row < r1) {
+  if (row < r1) {                                   // chunk_rows <= 256: one row per thread
     double x[BW];
     const double *p = g.A + (int64_t)(g.lo + row) * g.D + g.j0;
 #pragma unroll
@@ -254,7 +278,8 @@ __global__ void __launch_bounds__(256) panel_hr_kernel(const double *__restrict_
   __shared__ double bc[2][BW];
   const int tid = threadIdx.x;
   reduce_partials(Gpart2, nchunk, M, true);
-  cholesky_upper(M, dsc, bc);
+  if (tid < 64) cholesky_upper(M, dsc, bc);
+  __syncthreads();
   for (int e = tid; e < BW * BW; e += blockDim.x) R2out[e] = M[e / BW][e % BW];
   // Q1_top rows
   if (tid < BW) {
@@ -275,7 +300,8 @@ __global__ void __launch_bounds__(256) panel_hr_kernel(const double *__restrict_
   __syncthreads();
   // LU without pivoting (diagonal entries start at 1 + |q_ii| >= 1; Ballard et al., "Reconstructing Householder vectors
   // from TSQR": the multipliers stay bounded by 1 for an orthonormal Q1)
-  lu_nopivot(Bm, bc);
+  if (tid < 64) lu_nopivot(Bm, bc);
+  __syncthreads();
   for (int e = tid; e < BW * BW; e += blockDim.x) {
     const int i = e / BW, j = e % BW;
     Uout[e] = i <= j ? Bm[i][j] : 0.0;
@@ -296,7 +322,7 @@ __global__ void __launch_bounds__(256) panel_v_kernel(PanelGeom g, const double 
   for (int e = tid; e < BW * BW; e += 256) { Ra[e / BW][e % BW] = R2[e]; Ub[e / BW][e % BW] = U[e]; }
   if (tid < BW) sg[tid] = sgn[tid];
   __syncthreads();
-  const int r0 = chunk * CHUNK, r1 = min(g.m, r0 + CHUNK);
+  const int r0 = chunk * g.chunk_rows, r1 = min(g.m, r0 + g.chunk_rows);
   const int row = r0 + tid;
   if (row < r1) {
     double x[BW];
@@ -373,54 +399,77 @@ __global__ void __launch_bounds__(256) panel_t_kernel(PanelGeom g, const double 
   }
 }
 
-// k7: Ypart[ks][m][BW] = A'[:, ks-th column slice] V[slice]; workgroup = 64 rows x BW columns x one slice of KSPLIT_COLS.
-// Wave w owns rows [16 w, 16 w + 16) and both 16-column tiles.  A lane fetches four consecutive k of its row (32 bytes)
-// and spends them on four MFMAs per tile; V rows come straight from L2 (16 lanes = one 128-byte run).
-__global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const double *__restrict__ V, double *__restrict__ Ypart) {
+// k7: Ypart[ks][m][BW] = A'[:, ks-th column slice] V[slice]; workgroup = 128 rows x BW columns x one slice of KSPLIT_COLS
+// columns.  The V slice (KSPLIT_COLS x BW doubles) is staged in LDS once per workgroup; wave w owns rows [32 w, 32 w + 32)
+// as two 16-row MFMA tiles x two 16-column tiles.  A lane fetches four consecutive k of each of its two rows (32 bytes
+// each) and spends them on four MFMAs per tile.
+constexpr int YROWS = 128;
+__global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const double *__restrict__ V, double *__restrict__ Ypart, int krange) {
+  __shared__ double Vs[KSPLIT_COLS][BW];
   const int rb = blockIdx.x, ks = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fl = lane & 15, fk = lane >> 4;
-  const int row = rb * 64 + wave * 16 + fl;                 // local row of A'
-  const int c0 = ks * KSPLIT_COLS, c1 = min(g.m, c0 + KSPLIT_COLS);
-  const double *arow = g.A + (int64_t)(g.lo + min(row, g.m - 1)) * g.D + g.lo;
-  doublex4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-  for (int c = c0; c < c1; c += 32) {
-    double a[2][4], b0[2][4], b1[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fl = lane & 15, fk = lane >> 4;
+  const int k_lo = ks * krange, k_hi = min(g.m, k_lo + krange);
+  const int row0 = rb * YROWS + wave * 32 + fl, row1 = row0 + 16;           // local rows of A'
+  const double *ar0 = g.A + (int64_t)(g.lo + min(row0, g.m - 1)) * g.D + g.lo;
+  const double *ar1 = g.A + (int64_t)(g.lo + min(row1, g.m - 1)) * g.D + g.lo;
+  doublex4 acc[2][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int kb = c + 16 * h + 4 * fk;
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = kb + u;
-        const bool in = k < c1;
-        a[h][u] = (in && row < g.m) ? arow[k] : 0.0;
-        b0[h][u] = in ? V[(int64_t)k * BW + fl] : 0.0;
-        b1[h][u] = in ? V[(int64_t)k * BW + 16 + fl] : 0.0;
-      }
+    for (int b = 0; b < 2; ++b) acc[a][b] = (doublex4){0.0, 0.0, 0.0, 0.0};
+  for (int c0 = k_lo; c0 < k_hi; c0 += KSPLIT_COLS) {
+    const int c1 = min(k_hi, c0 + KSPLIT_COLS);
+    __syncthreads();
+    for (int e = tid; e < KSPLIT_COLS * BW; e += 256) {
+      const int kl = e / BW, k = c0 + kl;
+      // rows 4 apart would sit on the same banks (1 KB stride): rotate every other group of four rows by 16 columns
+      Vs[kl][(e % BW + 16 * ((kl >> 2) & 1)) & 31] = k < c1 ? V[(int64_t)k * BW + e % BW] : 0.0;
     }
+    __syncthreads();
+    for (int c = c0; c < c1; c += 32) {
+      double a0[2][4], a1[2][4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h) {
+        const int kb = c + 16 * h + 4 * fk;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc0 = mfma(a[h][u], b0[h][u], acc0);
-        acc1 = mfma(a[h][u], b1[h][u], acc1);
+        for (int u = 0; u < 4; ++u) {
+          const int k = min(kb + u, g.m - 1);        // columns beyond the slice meet zero rows of Vs
+          a0[h][u] = ar0[k];
+          a1[h][u] = ar1[k];
+        }
       }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kl = c - c0 + 16 * h + 4 * fk + u;
+          const int rot = 16 * ((kl >> 2) & 1);
+          const double b0 = Vs[kl][(fl + rot) & 31], b1 = Vs[kl][(16 + fl + rot) & 31];
+          acc[0][0] = mfma(a0[h][u], b0, acc[0][0]);
+          acc[0][1] = mfma(a0[h][u], b1, acc[0][1]);
+          acc[1][0] = mfma(a1[h][u], b0, acc[1][0]);
+          acc[1][1] = mfma(a1[h][u], b1, acc[1][1]);
+        }
+    }
   }
   double *yp = Ypart + ((int64_t)ks * g.m) * BW;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int orow = rb * 64 + wave * 16 + fk + 4 * r;
-    if (orow < g.m) {
-      yp[(int64_t)orow * BW + fl] = acc0[r];
-      yp[(int64_t)orow * BW + 16 + fl] = acc1[r];
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = rb * YROWS + wave * 32 + a * 16 + fk + 4 * r;
+      if (orow < g.m) {
+        yp[(int64_t)orow * BW + fl] = acc[a][0][r];
+        yp[(int64_t)orow * BW + 16 + fl] = acc[a][1][r];
+      }
     }
-  }
 }
 
 // k8: Y = sum_ks Ypart (row chunk), Kpart[chunk] = V_chunk^T Y_chunk
 __global__ void __launch_bounds__(256) trailing_yk_kernel(PanelGeom g, const double *__restrict__ Ypart, int nks, const double *__restrict__ V,
                                                           double *__restrict__ Y, double *__restrict__ Kpart) {
   const int chunk = blockIdx.x, tid = threadIdx.x;
-  const int r0 = chunk * CHUNK, r1 = min(g.m, r0 + CHUNK);
+  const int r0 = chunk * g.chunk_rows, r1 = min(g.m, r0 + g.chunk_rows);
   for (int e = tid; e < (r1 - r0) * BW; e += 256) {
     const int64_t idx = (int64_t)r0 * BW + e;
     double s = 0.0;
@@ -484,9 +533,9 @@ __global__ void __launch_bounds__(256) trailing_z_kernel(PanelGeom g, const doub
   const int chunk = blockIdx.x, tid = threadIdx.x;
   for (int e = tid; e < BW * BW; e += 256) { Ti[e / BW][e % BW] = Tinv[e]; Wm[e / BW][e % BW] = W2[e]; Cm[e / BW][e % BW] = C[e]; }
   __syncthreads();
-  const int row = chunk * CHUNK + tid;
   double res = 0.0;
-  if (row < g.m) {
+  const int row = chunk * g.chunk_rows + tid;
+  if (tid < g.chunk_rows && row < g.m) {
     double x[BW], v[BW];
 #pragma unroll
     for (int j = 0; j < BW; ++j) { x[j] = Y[(int64_t)row * BW + j]; v[j] = V[(int64_t)row * BW + j]; }
@@ -534,6 +583,18 @@ __global__ void __launch_bounds__(256) trailing_update_kernel(PanelGeom g, const
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (doublex4){0.0, 0.0, 0.0, 0.0};
+  // the tile of A' is requested first: its HBM / L2 latency runs under the operand loads and the 64 MFMAs
+  double *Ap = g.A + (int64_t)g.lo * g.D + g.lo;
+  double cold[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = wi + a * 16 + fk + 4 * r, gj = wj + b * 16 + fl;
+        cold[a][b][r] = (gi < g.m && gj < g.m) ? Ap[(int64_t)gi * g.D + gj] : 0.0;
+      }
   const double *first = below ? Z : V, *second = below ? V : Z;      // acc += first_i second_j^T + second_i first_j^T
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -558,7 +619,6 @@ __global__ void __launch_bounds__(256) trailing_update_kernel(PanelGeom g, const
           for (int b = 0; b < 2; ++b) acc[a][b] = mfma(av[a][u], bv[b][u], acc[a][b]);
     }
   }
-  double *Ap = g.A + (int64_t)g.lo * g.D + g.lo;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -568,9 +628,9 @@ __global__ void __launch_bounds__(256) trailing_update_kernel(PanelGeom g, const
         const int gi = wi + a * 16 + fk + 4 * r, gj = wj + b * 16 + fl;
         if (gi < g.m && gj < g.m) {
           if (ti != tj) {
-            Ap[(int64_t)gi * g.D + gj] -= acc[a][b][r];
+            Ap[(int64_t)gi * g.D + gj] = cold[a][b][r] - acc[a][b][r];
           } else if (gi >= gj) {
-            const double val = Ap[(int64_t)gi * g.D + gj] - acc[a][b][r];
+            const double val = cold[a][b][r] - acc[a][b][r];
             Ap[(int64_t)gi * g.D + gj] = val;
             Ap[(int64_t)gj * g.D + gi] = val;
           }
@@ -845,7 +905,7 @@ __device__ __forceinline__ void msg_recv(const unsigned long long *box, double *
     for (;;) {
       const unsigned long long u = __hip_atomic_load(box + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((unsigned)(u >> 32) == tag) { reinterpret_cast<unsigned *>(dst)[tid] = (unsigned)u; break; }
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if ((++spins & 255) == 0) {
         if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
         if (spins > SPIN_LIMIT) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
@@ -855,7 +915,7 @@ __device__ __forceinline__ void msg_recv(const unsigned long long *box, double *
 }
 
 __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
-  __shared__ double v[BW], pq[2 * BW], x2[BW], v2[BW], dpart[2][BW];
+  __shared__ double v[BW], pq[2 * BW], x2[BW], dpart[2][BW];
   __shared__ double msg_in[MSG], msg_out[MSG], colbuf[MSG], rowbuf[BW], edge[4][BW], xcol[BW];
   __shared__ double sc[2];
   __shared__ int ab;
@@ -961,22 +1021,30 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
         for (int j = 0; j < 8; ++j) x[j] -= qr * v[c0 + j];
       }
     }
-    // ---- next reflector from the first column of the lower block, applied from the left to its other columns
-    if (!diag_row && part == 0) x2[r - BW] = x[0];
+    // ---- next reflector from the first column of the lower block.  The window's first column (rows 0 .. BW) is final
+    //      as soon as alpha2 is known (the left application below only touches columns >= 1): both messages leave here,
+    //      the rest of the task runs off the critical path of the two neighbours.
+    if (part == 0) { if (diag_row) colbuf[r] = x[0]; else x2[r - BW] = x[0]; }
     __syncthreads();
     if (ab) break;                                            // uniform: `ab` was written before the barrier above
     double alpha2, v20, tau2;
     {
       const double xv = lane < BW ? x2[lane] : 0.0;
       const double tail = wave_sum(lane >= 1 && lane < BW ? xv * xv : 0.0);
-      make_house(x2[0], tail, alpha2, v20, tau2);
-      if (wave == 0 && lane < BW) { const double vv = lane == 0 ? v20 : xv; v2[lane] = vv; msg_out[lane] = vv; }
-      if (tid == 0) msg_out[BW] = tau2;
+      make_house(x2[0], tail, alpha2, v20, tau2);             // every wave computes the same numbers
+      if (wave == 0 && lane < BW) msg_out[lane] = lane == 0 ? v20 : xv;
+      if (tid == 0) { msg_out[BW] = tau2; colbuf[BW] = alpha2; }
     }
     __syncthreads();
     if (Dp - (s + 1 + (t + 1) * BW) >= 2) msg_send(mailbox(g, t + 1, 0, s & 1), msg_out, (unsigned)(s + 1));   // task (s, t + 1) exists
+    if (t > 0) {
+      msg_send(mailbox(g, t - 1, 1, s & 1), colbuf, (unsigned)(s + 1));
+    } else {
+      if (tid < BW) xcol[tid] = colbuf[tid + 1];
+      if (tid == 0 && s + 1 < g.D) g.diag[s + 1] = colbuf[0];
+    }
     if (!diag_row) {
-      const double vr = v2[r - BW];
+      const double vr = msg_out[r - BW];
       double dloc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -991,7 +1059,7 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
     }
     __syncthreads();
     if (!diag_row) {
-      const double vr = v2[r - BW];
+      const double vr = msg_out[r - BW];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = c0 + j;
@@ -1000,16 +1068,7 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
         else x[j] -= dc * vr;
       }
     }
-    // ---- the window's first column (rows 0 .. BW) leaves: to node t - 1, or, on node 0, it is the next sweep's column
-    if (r <= BW && part == 0) colbuf[r] = x[0];
-    __syncthreads();
-    if (t > 0) {
-      msg_send(mailbox(g, t - 1, 1, s & 1), colbuf, (unsigned)(s + 1));
-    } else {
-      if (tid < BW) xcol[tid] = colbuf[tid + 1];
-      if (tid == 0 && s + 1 < g.D) g.diag[s + 1] = colbuf[0];
-    }
-    __syncthreads();
+    __syncthreads();       // msg_out / colbuf / dpart are rewritten by the next sweep
   }
 }
 
@@ -1086,15 +1145,21 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
   int j0 = 0;
   while (D - j0 > CORNER) {
     PanelGeom g;
-    g.A = G; g.D = D; g.j0 = j0; g.lo = j0 + BW; g.m = D - g.lo; g.nchunk = ceil_div(g.m, CHUNK);
-    const int nks = ceil_div(g.m, KSPLIT_COLS);
+    g.A = G; g.D = D; g.j0 = j0; g.lo = j0 + BW; g.m = D - g.lo;
+    g.chunk_rows = CHUNK;
+    g.nchunk = ceil_div(g.m, g.chunk_rows);
+    // column range per workgroup of the Y kernel: >= 512 workgroups when the block is large enough, few partials otherwise
+    const int rbs = ceil_div(g.m, YROWS);
+    int nks = min(ceil_div(g.m, KSPLIT_COLS), max(1, ceil_div(512, rbs)));
+    const int krange = ceil_div(ceil_div(g.m, nks), KSPLIT_COLS) * KSPLIT_COLS;
+    nks = ceil_div(g.m, krange);
     hipLaunchKernelGGL(panel_gram_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp);
     hipLaunchKernelGGL(panel_chol1_kernel, dim3(1), dim3(256), 0, st, Gp, g.nchunk, R1);
     hipLaunchKernelGGL(panel_q_kernel, dim3(g.nchunk), dim3(256), 0, st, g, R1, Q, Gp);
     hipLaunchKernelGGL(panel_hr_kernel, dim3(1), dim3(256), 0, st, Gp, g.nchunk, Q, R2, U, Vtop, sgn);
     hipLaunchKernelGGL(panel_v_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Q, R2, U, Vtop, sgn, V, VtVp, VtPp);
     hipLaunchKernelGGL(panel_t_kernel, dim3(1), dim3(256), 0, st, g, VtVp, VtPp, Vtop, Tinv, C);
-    hipLaunchKernelGGL(trailing_y_kernel, dim3(ceil_div(g.m, 64), nks), dim3(256), 0, st, g, V, Ypart);
+    hipLaunchKernelGGL(trailing_y_kernel, dim3(rbs, nks), dim3(256), 0, st, g, V, Ypart, krange);
     hipLaunchKernelGGL(trailing_yk_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Ypart, nks, V, Y, Kp);
     hipLaunchKernelGGL(trailing_w2_kernel, dim3(1), dim3(256), 0, st, Kp, g.nchunk, Tinv, W2);
     hipLaunchKernelGGL(trailing_z_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Y, V, Tinv, W2, C, Z, scal);

@@ -646,6 +646,68 @@ bisect_kernel(const double *__restrict__ diag, const double *__restrict__ offd, 
   if (sv) sv[(int64_t)p * D + (D - 1 - j)] = (float)sqrt(fmax(lam, 0.0));
 }
 
+// D > 8192: the (d_i, e_{i-1}^2) pairs no longer fit the LDS of one workgroup.  All threads of a workgroup walk the same
+// index range in every Sturm sweep, so the pairs are staged tile by tile (BT pairs = 32 KB) and each thread advances its
+// own recurrence through the tile: the one-thread-streams-from-L2 form it replaces took 80 ms at D = 12288.
+constexpr int BT = 2048;
+__global__ void __launch_bounds__(256)
+bisect_tiled_kernel(const double *__restrict__ diag, const double *__restrict__ offd, int D, double *__restrict__ eig,
+                    float *__restrict__ sv) {
+  __shared__ double2 tile[BT];
+  __shared__ double red[8];
+  const int p = blockIdx.y;
+  const double *d = diag + (int64_t)p * D, *e = offd + (int64_t)p * D;
+  const int tid = threadIdx.x;
+  double lo = INFINITY, hi = -INFINITY;
+  for (int i = tid; i < D; i += 256) {
+    const double el = i > 0 ? e[i - 1] : 0.0, er = i + 1 < D ? e[i] : 0.0;
+    const double r = fabs(el) + fabs(er);
+    lo = fmin(lo, d[i] - r);
+    hi = fmax(hi, d[i] + r);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+  if ((tid & 63) == 0) { red[tid >> 6] = lo; red[4 + (tid >> 6)] = hi; }
+  __syncthreads();
+  lo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+  hi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  const double span = fmax(fmax(fabs(lo), fabs(hi)), 1e-300);
+  const double inv = 1.0 / span;
+  const int j = min(blockIdx.x * 256 + tid, D - 1);           // surplus threads shadow the last eigenvalue
+  double a = lo * inv - 2.3e-16 * (double)D, b = hi * inv + 2.3e-16 * (double)D;
+  for (int it = 0; it < 120; ++it) {
+    const double mid = 0.5 * (a + b);
+    const bool live = mid > a && mid < b && (b - a > 1e-13 * fmax(fabs(a), fabs(b)) + 1e-22);
+    if (!__syncthreads_or(live)) break;
+    SturmState st;
+    st.pm = 1.0; st.pc = d[0] * inv - mid; st.count = (unsigned)__double2hiint(st.pc) >> 31;
+    for (int base = 0; base < D; base += BT) {
+      __syncthreads();
+      for (int i = tid; i < BT; i += 256) {
+        const int gi = base + i;
+        double2 v = make_double2(0.0, 0.0);
+        if (gi < D) { const double el = gi > 0 ? e[gi - 1] * inv : 0.0; v = make_double2(d[gi] * inv, el * el); }
+        tile[i] = v;
+      }
+      __syncthreads();
+      const int i0 = base == 0 ? 1 : 0, n = min(BT, D - base);
+      int i = i0;
+      for (; i + 8 <= n; i += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sturm_step(st, tile[i + u].x, tile[i + u].y, mid);
+        sturm_renorm(st);
+      }
+      for (; i < n; ++i) sturm_step(st, tile[i].x, tile[i].y, mid);
+      sturm_renorm(st);
+    }
+    if (live) { if (st.count > j) b = mid; else a = mid; }
+  }
+  if (blockIdx.x * 256 + tid >= D) return;
+  const double lam = 0.5 * (a + b) * span;
+  if (eig) eig[(int64_t)p * D + j] = lam;
+  if (sv) sv[(int64_t)p * D + (D - 1 - j)] = (float)sqrt(fmax(lam, 0.0));
+}
+
 constexpr int SMALL_D_MAX = 128;
 
 size_t small_lds_bytes(int D) { return ((size_t)D * (D + 1) + 2 * D + 8) * sizeof(double); }
@@ -665,8 +727,8 @@ int bisect_launch(const double *diag, const double *offd, int P, int D, double *
     hipLaunchKernelGGL((bisect_kernel<true, 8>), dim3(idiff::ceil_div(D * 8, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv);
   else if (use_lds)
     hipLaunchKernelGGL((bisect_kernel<true, 1>), dim3(idiff::ceil_div(D, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv);
-  else   // D > 8192 streams (d, e) from L2 per thread: eight times the threads made it slower (2.48 -> 2.58 s at D = 12288)
-    hipLaunchKernelGGL((bisect_kernel<false, 1>), dim3(idiff::ceil_div(D, 256), P), dim3(256), 0, st, diag, offd, D, eig, sv);
+  else   // D > 8192: pairs staged through LDS tile by tile
+    hipLaunchKernelGGL(bisect_tiled_kernel, dim3(idiff::ceil_div(D, 256), P), dim3(256), 0, st, diag, offd, D, eig, sv);
   return idiff::launch_status("bisect");
 }
 
