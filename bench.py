@@ -8,12 +8,20 @@ One step = one data point of BASELINE config 3: 4480 score rows (B=128 -> (1024/
 empty; dim_reduction.py:166-171) of the nf=128 NCSN++ on a synthetic 32x32x3 image, written into the
 device-resident S [4480, 3072], then its centred singular spectrum and the integer ID.  Inputs (image, weights)
 are resident in HBM before the timed region.  With N ranks every rank processes K points of its own (weak
-scaling) and the region ends with the one all-gather of spectra the path has.
+scaling) and the region ends with the one exchange step the path has (parallel.gather_spectra).
+
+Passes, in order:
+  1. warm-up (W points), then the TIMED region (K points, no instrumentation)            -> value, ms_per_step
+  2. the same K points again with HIP events around the instrumented launches (rank 0)   -> roofline, roofline.kernels
+  3. the spectrum stages of one point, alone on the device                                -> svd_wall_clock_ms_per_point
+  4. cpu_baseline: the oracle on this box's host cores, bounded sample (rank 0, N = 1)
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,99 +37,305 @@ from id_diff_amd.configs.utils import read_config
 from id_diff_amd.models import utils as mutils
 from id_diff_amd.lightning_data_modules.SyntheticImages import smooth_decoder_images
 
-FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters; fp64 matrix peak: public MI355X figure (= fp64 vector peak)
+FP32_MFMA_PEAK_TFLOPS = 157.3
+FP64_MFMA_PEAK_TFLOPS = 78.6
+HBM_PEAK_GBS = 8000.0
 WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=1e-5, B=128 -> S 4480x3072 + centred spectrum + ID"
+TRAFFIC_TABLE = os.path.join("profiles", "r02_wino_traffic.json")
+WINOGRAD_SOURCE = os.path.join("id-diff_amd", "csrc", "winograd.hip")
 
 
-class ConvProbe:
-    """HIP events around a sample of the dominant kernel's launches (the F(2x2,3x3) Winograd convs of csrc/winograd.hip:
-    71 % of the kernel time of a forward pass) on the launch stream."""
+def _sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
 
-    TRAFFIC = os.path.join("profiles", "r01_wino_traffic.json")
+
+def source_sha256(rel):
+    with open(os.path.join(ROOT, rel), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+class KernelProbe:
+    """HIP events (on the launch stream) around every launch of the instrumented ``_lib`` entry points.
+
+    Each entry is classified by the roofline that bounds it and carries its ALGORITHMIC work: executed flops for the
+    contractions, compulsory HBM bytes (each operand once) for the streaming kernels -- SURVEY.md 8(d) per-unit figures
+    times the units of the launch."""
 
     def __init__(self):
         self.active = False
-        self.records = []
-        self._orig = _lib.conv2d_winograd
+        self.records = {}          # group -> list of (start, end, work, key)
+        self._orig = {}
 
-    def install(self):
+    def _wrap(self, name, account):
+        orig = getattr(_lib, name)
+        self._orig[name] = orig
         probe = self
 
-        def timed(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+        def timed(*a, **k):
             if not probe.active:
-                return probe._orig(x, u, out, B, H, W, Cin, Cout, epilogue)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            r = probe._orig(x, u, out, B, H, W, Cin, Cout, epilogue)
-            b.record()
-            # executed (algorithmic) flops of the Winograd form: 16 positions x [tiles x Cin] x [Cin x Cout] multiply-adds,
-            # tiles = output pixels / 4; the implicit GEMM it replaces would be 2.25x that (9 taps per pixel)
-            flops = 2.0 * 16 * (out.numel() // Cout // 4) * Cin * Cout
-            probe.records.append((a, b, flops, f"{B}x{H}x{W}x{Cin}->{Cout}"))
+                return orig(*a, **k)
+            acc = account(*a, **k)
+            if acc is None:
+                return orig(*a, **k)
+            group, work, key = acc
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            probe.records.setdefault(group, []).append((e0, e1, work, key))
             return r
 
-        _lib.conv2d_winograd = timed
+        setattr(_lib, name, timed)
 
-    def summary(self):
-        if not self.records:
+    def install(self):
+        def wino(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+            # executed flops of F(2x2,3x3): 16 positions x [tiles x Cin] x [Cin x Cout]; the implicit GEMM would be 2.25x that
+            return "winograd_kernel", 2.0 * 16 * (B * H * W // 4) * Cin * Cout, f"{B}x{H}x{W}x{Cin}->{Cout}"
+
+        def gn_apply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None):
+            return "gn_apply_rows", 8.0 * B * HW * (C + (C2 or 0)), f"{B}x{HW}x{C + (C2 or 0)}"
+
+        def gemm(a, bt, out=None, epilogue=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, batch=1,
+                 stride_a=0, stride_b=0, stride_c=0):
+            if M is None:
+                M, K = a.shape
+                N = bt.shape[0]
+            if K > 128 or M * batch < 65536:                    # only the HBM-bound 1x1 / NIN contractions
+                return None
+            res = 4.0 * M * N * batch if (epilogue is not None and epilogue.residual) else 0.0
+            return "igemm_pipe_kernel K<=128 (1x1 / NIN)", 4.0 * batch * (M * K + N * K + M * N) + res, f"{M}x{N}x{K}"
+
+        def gemm_2src(a1, a2, bt, out, epilogue=None):
+            M, K1 = a1.shape
+            K, N = K1 + a2.shape[1], bt.shape[0]
+            if K > 256:
+                return None
+            res = 4.0 * M * N if (epilogue is not None and epilogue.residual) else 0.0
+            return "igemm_pipe_kernel two-source shortcut", 4.0 * (M * K + N * K + M * N) + res, f"{M}x{N}x{K}"
+
+        def ufd(x, k, out, major, in_h, in_w, minor, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
+            return "upfirdn2d_nhwc", 4.0 * (x.numel() + out.numel()) + 4.0 * k.numel(), f"{major}x{in_h}x{in_w}x{minor} up{up_x} down{down_x}"
+
+        def softmax(x, y, rows, cols, scale):
+            return "softmax_rows", 8.0 * rows * cols, f"{rows}x{cols}"
+
+        for name, fn in (("conv2d_winograd", wino), ("groupnorm_apply", gn_apply), ("gemm", gemm), ("gemm_2src", gemm_2src),
+                         ("upfirdn2d_raw", ufd), ("softmax_rows", softmax)):
+            self._wrap(name, fn)
+
+    def uninstall(self):
+        for name, orig in self._orig.items():
+            setattr(_lib, name, orig)
+
+    def group(self, name):
+        recs = self.records.get(name, [])
+        if not recs:
             return None
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        fl = sum(r[2] for r in self.records)
-        return {"launches": len(self.records), "avg_us": ms * 1e3 / len(self.records), "tflops": fl / (ms * 1e-3) / 1e12,
-                "traffic": self.traffic()}
-
-    def traffic(self):
-        """HBM bytes per launch of the sampled shapes, from the committed PMC table (FETCH_SIZE / WRITE_SIZE passes,
-        gfx950 corrections applied; profiles/r01_wino_traffic.json); None if a sampled shape is not in the table."""
-        path = os.path.join(ROOT, self.TRAFFIC)
-        if not os.path.exists(path):
-            return None
-        table = json.load(open(path))["shapes"]
-        keys = [r[3] for r in self.records]
-        if any(k not in table for k in keys):
-            return None
-        return {"bytes_per_launch": sum(table[k]["total_bytes"] for k in keys) / len(keys),
-                "algorithmic_bytes_per_launch": sum(table[k]["algorithmic_bytes"] for k in keys) / len(keys),
-                "source": self.TRAFFIC}
+        ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        work = sum(r[2] for r in recs)
+        return {"launches": len(recs), "avg_us": ms * 1e3 / len(recs), "rate": work / (ms * 1e-3), "keys": [r[3] for r in recs]}
 
 
-def cpu_baseline(cfg, rows_per_point, D):
-    """The oracle (CPU restatement of the reference path) on this box's host cores, bounded sample."""
+def winograd_traffic(keys):
+    """HBM bytes per launch of the sampled shapes from the committed PMC table (separate FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 corrections applied) -- ONLY if the table was measured on the kernel source that is in the tree now."""
+    path = os.path.join(ROOT, TRAFFIC_TABLE)
+    if not os.path.exists(path):
+        return None
+    doc = json.load(open(path))
+    if doc.get("kernel_source_sha256") != source_sha256(WINOGRAD_SOURCE):
+        return None
+    table = doc["shapes"]
+    if any(k not in table for k in keys):
+        return None
+    return {"bytes_per_launch": sum(table[k]["total_bytes"] for k in keys) / len(keys),
+            "algorithmic_bytes_per_launch": sum(table[k]["algorithmic_bytes"] for k in keys) / len(keys),
+            "source": TRAFFIC_TABLE, "kernel_source_sha256": doc["kernel_source_sha256"]}
+
+
+def roofline_report(probe):
+    dom = probe.group("winograd_kernel")
+    if dom is None:
+        return None
+    tfl = dom["rate"] / 1e12
+    traffic = winograd_traffic(dom["keys"])
+    kernels = []
+    for name in ("gn_apply_rows", "igemm_pipe_kernel K<=128 (1x1 / NIN)", "igemm_pipe_kernel two-source shortcut", "upfirdn2d_nhwc",
+                 "softmax_rows"):
+        g = probe.group(name)
+        if g:
+            kernels.append({"kernel": name, "bound": "hbm", "achieved": g["rate"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": g["rate"] / 1e9 / HBM_PEAK_GBS, "launches_sampled": g["launches"], "avg_launch_us": g["avg_us"]})
+    return {"bound": "mfma", "kernel": "winograd_kernel (3x3 conv as F(2x2,3x3): 16 [tiles x Cin] x [Cin x Cout] contractions per launch, "
+                                       "v_mfma_f32_32x32x2_f32)",
+            "achieved": tfl, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP32_MFMA_PEAK_TFLOPS,
+            "flops_counted": "executed Winograd-domain multiply-adds (the implicit GEMM of the same conv is 2.25x more)",
+            "direct_conv_equivalent_tflops": tfl * 2.25,
+            "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
+            "launches_sampled": dom["launches"], "avg_launch_us": dom["avg_us"],
+            "sampled_in": "a second, untimed pass over the same points (spectrum overlap on, as in the timed region)",
+            "kernels": kernels}
+
+
+def spectrum_stage_report(rows, D, dev):
+    """The spectrum of one point alone on the device, stage by stage (events on the launch stream)."""
+    S = torch.randn(rows, D, device=dev)
+
+    def timed(fn, reps=3):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    whole = timed(lambda: _lib.spectrum(S))
+    mean = _lib.column_sums(S) / rows
+    gram_ms = timed(lambda: _lib.centered_gram(S, mean))
+    G = _lib.centered_gram(S, mean)
+    band_ms = timed(lambda: _lib.sym_band(G.clone(), dense=False)) - timed(lambda: G.clone())
+    eig_ms = timed(lambda: _lib.sym_eigvals(G.clone())) - timed(lambda: G.clone())
+    # algorithmic work: Gram = 2 M D^2 / 2 flops (upper-triangular tiles); band reduction streams the trailing block three
+    # times per 32-column panel (read for Y = A'V, read + write for the rank-64 update): 24 bytes x sum_k m_k^2
+    m2 = sum((D - 32 * (k + 1)) ** 2 for k in range(max(0, (D - 128 + 31) // 32)))
+    stages = [
+        {"kernel": "gram_kernel (fp64 centred Gram, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": rows * D * D / (gram_ms * 1e-3) / 1e12,
+         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rows * D * D / (gram_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms": gram_ms},
+        {"kernel": "band reduction, stage 1 of the eigensolver (11 launches per 32-column panel; latency-bound at D = 3072)", "bound": "hbm",
+         "achieved": 24.0 * m2 / (band_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": 24.0 * m2 / (band_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": band_ms},
+        {"kernel": "systolic bulge chasing + Sturm bisection (one persistent launch; a chain of 2D dependent steps)", "bound": "latency",
+         "ms": eig_ms - band_ms, "us_per_sweep": (eig_ms - band_ms) * 1e3 / D},
+    ]
+    return whole, stages
+
+
+def cpu_baseline(cfg, rows_per_point, D, S_gpu):
+    """the oracle (CPU restatement of the reference path) on this box's host cores, bounded sample.
+
+    score_fn both under no_grad and with autograd enabled (the reference never disables it, dim_reduction.py:183);
+    ``torch.linalg.svd`` with full matrices exactly as dim_reduction.py:197 and ``svdvals`` as the fair floor, both on
+    the S the GPU path consumed for its last timed point; median of 5 after one warm-up each."""
     from oracle import models as omodels, sde as osde
     # the GPU box exposes every host core (os.cpu_count() = 256) but grants a 16-core share per GPU:
     # oversubscribing the share makes the CPU run arbitrarily slow, so use the share
     cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
+    model_name = "unknown"
+    try:
+        model_name = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
     torch.manual_seed(0)
     model = omodels.create_model(cfg)
     score_fn = osde.get_score_fn(osde.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales), model)
-    n = 32
-    x = torch.rand(n, 3, 32, 32)
-    t = torch.full((n,), 1e-5)
-    print(f"[bench] cpu_baseline: oracle score_fn on {cores} threads ...", file=sys.stderr, flush=True)
-    with torch.no_grad():
-        score_fn(x[:4], t[:4])
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < 12.0:
-            score_fn(x, t)
-            reps += 1
-            print(f"[bench] cpu_baseline: batch {reps} done at {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
-    evals_per_s = reps * n / (time.perf_counter() - t0)
-    print("[bench] cpu_baseline: full SVD ...", file=sys.stderr, flush=True)
-    S = torch.randn(rows_per_point, D)
-    t0 = time.perf_counter()
+
+    def median_rate(n, grad):
+        x, t = torch.rand(n, 3, 32, 32), torch.full((n,), 1e-5)
+        times = []
+        for rep in range(6):
+            t0 = time.perf_counter()
+            if grad:
+                score_fn(x, t).detach()
+            else:
+                with torch.no_grad():
+                    score_fn(x, t)
+            times.append(time.perf_counter() - t0)
+            print(f"[bench] cpu_baseline: score_fn {'autograd' if grad else 'no_grad'} batch {rep} of {n} rows: {times[-1]:.2f}s",
+                  file=sys.stderr, flush=True)
+        return n / statistics.median(times[1:])
+
+    nograd = median_rate(16, False)
+    withgrad = median_rate(8, True)
+    S = S_gpu.cpu()
     c = S - S.mean(0, keepdim=True)
-    torch.linalg.svd(c)                      # full_matrices=True, as dim_reduction.py:197
-    svd_s = time.perf_counter() - t0
-    per_point = rows_per_point / evals_per_s + svd_s
-    return {"value": rows_per_point / per_point, "unit": "score-vector evals/s", "cores": cores, "kind": "port",
-            "sample": f"oracle NCSN++ score_fn under no_grad, {reps} batches of {n} rows ({evals_per_s:.2f} evals/s) + one "
-                      f"full torch.linalg.svd of {rows_per_point}x{D} ({svd_s:.2f} s); per-point rate extrapolated",
-            "score_evals_per_s": evals_per_s, "svd_s_per_point": svd_s}
+
+    def median_time(fn, reps):
+        times = []
+        for rep in range(reps + 1):
+            t0 = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t0)
+            print(f"[bench] cpu_baseline: svd rep {rep}: {times[-1]:.2f}s", file=sys.stderr, flush=True)
+        return statistics.median(times[1:])
+
+    svd_full = median_time(lambda: torch.linalg.svd(c), 3)           # full_matrices=True, as dim_reduction.py:197
+    svd_vals = median_time(lambda: torch.linalg.svdvals(c), 3)
+    as_reference = rows_per_point / (rows_per_point / withgrad + svd_full)
+    floor = rows_per_point / (rows_per_point / nograd + svd_vals)
+    return {"value": as_reference, "unit": "score-vector evals/s", "cores": cores, "cpu_model": model_name, "kind": "port",
+            "sample": f"oracle NCSN++ score_fn, median of 5 after 1 warm-up: autograd on (as the reference runs, dim_reduction.py:183) "
+                      f"{withgrad:.2f} evals/s on batches of 8, no_grad {nograd:.2f} evals/s on batches of 16; torch.linalg.svd "
+                      f"(full matrices, dim_reduction.py:197) {svd_full:.2f} s and svdvals {svd_vals:.2f} s, median of 3, on the "
+                      f"{rows_per_point}x{D} S of the last timed GPU point; per-point rates extrapolated",
+            "score_evals_per_s_autograd": withgrad, "score_evals_per_s_no_grad": nograd, "svd_full_s": svd_full,
+            "svdvals_s": svd_vals, "value_no_grad_svdvals": floor}
 
 
-def main():
+class Workload:
+    """BASELINE config 3 on one rank."""
+
+    def __init__(self, args, rank, dev):
+        cfg = read_config('configs/dimension_estimation/paper/image_data/cifar_shaped/ncsnpp.py')
+        cfg.model.init_scale = 1.0      # random weights with every branch numerically active (SURVEY 8-d cfg 3)
+        torch.manual_seed(0)
+        self.cfg = cfg
+        self.model = mutils.create_model(cfg).to(dev).eval()
+        sde, eps = sde_lib.configure_sde(cfg)
+        score_fn = mutils.get_score_fn(sde, self.model, conditional=False, train=False, continuous=True)
+        self.B = cfg.training.batch_size
+        self.images = smooth_decoder_images(args.steps + args.warmup, [3, 32, 32], 64, seed=100 + rank).to(dev)
+        _, _, self.rows = dim_reduction.batching((3, 32, 32), self.B)
+        self.D = 3 * 32 * 32
+        self.builder = dim_reduction.ScoreMatrixBuilder(score_fn, sde, eps, dev, inflight_rows=args.inflight)
+        self.rank = rank
+        self.pipe = dim_reduction.SpectrumPipeline(dev, overlap=not args.no_overlap)
+        self.last_S = None
+
+    def point(self, i):
+        self.last_S = self.builder.build(self.images[i], self.B, seed=1234 + 1000003 * (i + 1) + self.rank)
+        self.pipe.submit(self.last_S)   # spectrum of this point overlaps the score evaluations of the next one
+
+    def collect(self):
+        return torch.stack(self.pipe.results())
+
+
+def timed_region(work, warmup, steps, dev):
+    """W untimed points, then EXACTLY `steps` points between barrier + synchronize on both sides; the region includes the
+    path's one exchange step.  Returns (max-over-ranks seconds, spectra of ALL ranks' points in rank-major order)."""
+    rank, world = parallel.rank_world()
+    grouped = dist.is_available() and dist.is_initialized()
+    for i in range(warmup):
+        work.point(i)
+    if warmup:
+        work.collect()
+    _sync(dev)
+    if grouped:
+        dist.barrier()
+    _sync(dev)
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        work.point(i)
+    local = work.collect()
+    # point p of the weak-scaling job = (rank p % world, its step p // world): parallel.gather_spectra's round-robin layout
+    allsv = parallel.gather_spectra(local, world * steps, local.shape[1], dev)
+    _sync(dev)
+    if grouped:
+        dist.barrier()
+    _sync(dev)
+    elapsed = time.perf_counter() - t0
+    if grouped:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed, allsv
+
+
+def main(argv=None, workload_factory=Workload):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -129,124 +343,66 @@ def main():
     ap.add_argument("--inflight", type=int, default=2240, help="score rows per launch set (measured best of 512..4480)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run each point's spectrum on the main stream")
-    args = ap.parse_args()
+    ap.add_argument("--no-probe", action="store_true", help="skip the instrumented second pass (roofline = null)")
+    ap.add_argument("--device", default=None, help="(tests) 'cpu' with a stand-in workload")
+    args = ap.parse_args(argv)
 
-    rank, world, local_rank = parallel.init_from_env()
+    # under a launcher this initialises RCCL (also at world size 1) BEFORE anything else touches the GPU
+    rank, world, local_rank = parallel.init_from_env(backend="gloo" if args.device == "cpu" else None)
     if world != args.gpus and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
+    dev = torch.device(args.device) if args.device else torch.device(f"cuda:{local_rank}")
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
 
-    cfg = read_config('configs/dimension_estimation/paper/image_data/cifar_shaped/ncsnpp.py')
-    cfg.model.init_scale = 1.0      # random weights with every branch numerically active (SURVEY 8-d cfg 3)
-    torch.manual_seed(0)
-    model = mutils.create_model(cfg).to(dev).eval()
-    sde, eps = sde_lib.configure_sde(cfg)
-    score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
-    B = cfg.training.batch_size
-    images = smooth_decoder_images(args.steps + args.warmup, [3, 32, 32], 64, seed=100 + rank).to(dev)
-    _, _, rows = dim_reduction.batching((3, 32, 32), B)
-    D = 3 * 32 * 32
-    builder = dim_reduction.ScoreMatrixBuilder(score_fn, sde, eps, dev, inflight_rows=args.inflight)
-    probe = ConvProbe()
-    probe.install()
-
-    pipe = dim_reduction.SpectrumPipeline(dev, overlap=not args.no_overlap)
-
-    def one_point(i, timed):
-        # sample the dominant kernel's launches of every timed step
-        if timed:
+    work = workload_factory(args, rank, dev)
+    with torch.no_grad():
+        elapsed, allsv = timed_region(work, args.warmup, args.steps, dev)
+    rows, D = work.rows, work.D
+    line = None
+    if dev.type == "cuda":
+        roofline, svd_ms, stages = None, None, None
+        if rank == 0 and not args.no_probe:
+            probe = KernelProbe()
+            probe.install()
             probe.active = True
-        S = builder.build(images[i], B, seed=1234 + 1000003 * (i + 1) + rank)
-        probe.active = False
-        pipe.submit(S)   # spectrum of this point overlaps the score evaluations of the next one
-
-    # probe only one inflight chunk per step: wrap builder.score_fn
-    orig_score_fn = builder.score_fn
-    state = {"calls": 0}
-
-    def sampled_score_fn(x, t):
-        # every launch set of a timed step is sampled (the first runs beside the previous point's spectrum, the last
-        # mostly alone), so that the average is over the same launches rocprofv3 --stats averages
-        state["calls"] += 1
-        return orig_score_fn(x, t)
-
-    builder.score_fn = sampled_score_fn
-    n_chunks = (rows + builder.rows_per_launch(rows, D) - 1) // builder.rows_per_launch(rows, D)
-
-    with torch.no_grad():
-        for i in range(args.warmup):
-            state["calls"] = 0
-            one_point(i, False)
-        pipe.results()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + args.steps):
-            state["calls"] = 0
-            one_point(i, True)
-        local = torch.stack(pipe.results())
-        if world > 1:
-            # the path's one exchange step: all ranks own `steps` points
-            allsv = torch.empty(world * args.steps, D, device=dev)
-            dist.all_gather_into_tensor(allsv, local)
-        else:
-            allsv = local
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # SVD wall-clock of one point, measured alone (outside the timed region) so that it is not a concurrency artefact
-    with torch.no_grad():
-        S_probe = torch.randn(rows, D, device=dev)
-        _lib.spectrum(S_probe)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            _lib.spectrum(S_probe)
-        e1.record()
-        torch.cuda.synchronize()
-        svd_ms = e0.elapsed_time(e1) / 3
+            with torch.no_grad():
+                for i in range(args.warmup, args.warmup + args.steps):
+                    work.point(i)
+                work.collect()
+            torch.cuda.synchronize()
+            probe.active = False
+            probe.uninstall()
+            roofline = roofline_report(probe)
+        if rank == 0:
+            with torch.no_grad():
+                svd_ms, stages = spectrum_stage_report(rows, D, dev)
+            if roofline is not None:
+                roofline["kernels"] += stages
     if rank == 0:
-        ids = [plot_utils.estimate_dim(s.tolist()) for s in allsv[: args.steps].cpu()]
-        conv = probe.summary()
-        roofline = None
-        if conv:
-            roofline = {"bound": "mfma", "kernel": "winograd_kernel (3x3 conv as F(2x2,3x3): 16 [tiles x Cin] x [Cin x Cout] contractions "
-                                                   "per launch, v_mfma_f32_32x32x2_f32)",
-                        "achieved": conv["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": conv["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                        "flops_counted": "executed Winograd-domain multiply-adds (the implicit GEMM of the same conv is 2.25x more)",
-                        "direct_conv_equivalent_tflops": conv["tflops"] * 2.25,
-                        "traffic": conv["traffic"]["bytes_per_launch"] if conv["traffic"] else None,
-                        "traffic_detail": conv["traffic"],
-                        "launches_sampled": conv["launches"], "avg_launch_us": conv["avg_us"]}
+        sv_mine = allsv[0::world][: args.steps].cpu()         # rank 0's own points
+        ids = [plot_utils.estimate_dim(s.tolist()) for s in sv_mine]
         line = {
             "metric": "score-vector evals/sec (rows of S per second incl. the per-point spectrum), 32x32 ncsnpp",
             "value": world * args.steps * rows / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "rows_per_point": rows, "cols": D, "batch_size": B,
+            "config": {"workload": WORKLOAD, "rows_per_point": rows, "cols": D, "batch_size": getattr(work, "B", None),
                        "inflight_rows": args.inflight, "points_per_gpu": args.steps,
-                       "parallelism": f"points sharded over {world} rank(s), one all-gather of spectra"},
-            "svd_wall_clock_ms_per_point": svd_ms, "id_estimates": ids,
-            "model_tflops_per_gpu": rows * args.steps * 21.79e9 / elapsed / 1e12,
-            "roofline": roofline,
+                       "parallelism": f"points sharded over {world} rank(s), one all-gather of spectra",
+                       "process_group": dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None},
+            "id_estimates": ids, "model_tflops_per_gpu": rows * args.steps * 21.79e9 / elapsed / 1e12,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, rows, D)
+        if dev.type == "cuda":
+            line["svd_wall_clock_ms_per_point"] = svd_ms
+            line["roofline"] = roofline
+            if world == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(work.cfg, rows, D, work.last_S)
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

@@ -398,15 +398,18 @@ def centered_gram(S, mean):
     return G
 
 
-def sym_band(G):
-    """Stage 1 of the two-stage eigensolver alone: dense symmetric band matrix [D, D] (half-width 32) similar to G (G is
-    overwritten).  For the parity tests and the profiler."""
+def sym_band(G, dense=True):
+    """Stage 1 of the two-stage eigensolver alone (G is overwritten).  ``dense=True``: the dense symmetric band matrix
+    [D, D] (half-width 32) similar to G, for the parity tests; ``dense=False``: the compact band [D, ld] with
+    band[j, k] = B[j + k, j], for timing."""
     _dev(G, "G", dtype=torch.float64)
     D = G.shape[0]
     scratch = torch.zeros(lib().idiff_symtridiag_scratch_doubles(D), dtype=torch.float64, device=G.device)
     _check(lib().idiff_symband_f64(G.data_ptr(), D, scratch.data_ptr(), _stream()), "idiff_symband_f64")
     ld = lib().idiff_symband_ld()
     band = scratch[:D * ld].view(D, ld)                       # band[j, k] = B[j + k, j]
+    if not dense:
+        return band
     B = torch.zeros(D, D, dtype=torch.float64, device=G.device)
     j = torch.arange(D, device=G.device)
     for k in range(ld):

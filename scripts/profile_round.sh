@@ -5,7 +5,7 @@
 #   3. rocprofv3 --kernel-trace --stats of the default bench (no cpu baseline) -> <tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json
 #   4. the plain default bench with cpu_baseline                             -> <tag>_bench.json
 set -uo pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O

@@ -119,6 +119,52 @@ def test_config5_sized_matrix(golden):
     assert abs(float(eig.sum()) / float((c64 * c64).sum()) - 1.0) < 1e-10
 
 
+def _gram(kind, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "gauss":
+        S = torch.randn(D + 40, D, generator=g, dtype=torch.float64)
+    elif kind == "cliff":
+        S = torch.randn(D + 90, D, generator=g, dtype=torch.float64)
+        S[:, D - 37:] /= 70
+        S = S @ torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
+    elif kind == "lowrank":                      # rank 20 < panel width 32: CholeskyQR meets exactly dependent columns
+        S = torch.randn(D + 10, 20, generator=g, dtype=torch.float64) @ torch.randn(20, D, generator=g, dtype=torch.float64)
+    elif kind == "zero":                         # e.g. the zero-initialised output conv of a fresh BeatGANs U-Net
+        S = torch.zeros(D + 10, D, dtype=torch.float64)
+    elif kind == "diagonal":                     # every panel below the band is exactly zero
+        return torch.diag(torch.linspace(1.0, 50.0, D, dtype=torch.float64))
+    return S.T @ S
+
+
+@pytest.mark.parametrize("kind,D", [("gauss", 129), ("gauss", 257), ("cliff", 517), ("lowrank", 300), ("zero", 260), ("diagonal", 333),
+                                    ("gauss", 1024), ("cliff", 1501)])
+def test_two_stage_eigensolver(kind, D):
+    """idiff_symtridiag_f64 for D > 128 = blocked band reduction (CholeskyQR2 + Householder-reconstruction panels, rank-64
+    trailing updates on the fp64 matrix cores) + systolic bulge chasing: stage 1 alone preserves the spectrum to rounding,
+    and the three routes to the tridiagonal matrix (two-stage with the systolic chase, with one launch per wavefront, the
+    unblocked one-stage sweep) give the same eigenvalues as LAPACK."""
+    G = _gram(kind, D, seed=D)
+    ref = torch.linalg.eigvalsh(G)
+    scale = max(float(ref.abs().max()), 1e-300)
+    Gd = G.to(DEV)
+    B = _lib.sym_band(Gd.clone()).cpu()
+    i, j = torch.meshgrid(torch.arange(D), torch.arange(D), indexing="ij")
+    assert float(B[(i - j).abs() > 32].abs().max()) == 0.0 and torch.equal(B, B.T)
+    assert float((torch.linalg.eigvalsh(B) - ref).abs().max()) <= 2e-14 * scale
+    tol = 5e-14 * scale                                        # the bisection stops at 1e-13 relative
+    ev = _lib.sym_eigvals(Gd.clone()).cpu()
+    assert float((ev - ref).abs().max()) <= tol
+    for opt in ("IDIFF_CHASE_WAVEFRONT", "IDIFF_TRIDIAG_ONESTAGE"):
+        if opt == "IDIFF_TRIDIAG_ONESTAGE" and D % 2:
+            continue                                           # its streaming form needs an even D
+        _lib.set_option(opt, True)
+        try:
+            other = _lib.sym_eigvals(Gd.clone()).cpu()
+        finally:
+            _lib.set_option(opt, False)
+        assert float((other - ref).abs().max()) <= tol, opt
+
+
 def test_stage_exports():
     g = torch.Generator().manual_seed(4)
     M, D = 257, 70

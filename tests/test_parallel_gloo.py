@@ -2,6 +2,7 @@
 import os
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -93,3 +94,53 @@ def test_row_sharded_spectrum_two_and_three_ranks():
         assert ranges[0][0] == 0 and ranges[-1][1] == M and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
         for _, _, sv in got:
             torch.testing.assert_close(sv, ref, rtol=1e-5, atol=1e-6)
+
+
+# ---- bench.py's own control flow (barrier / timed region / exchange / JSON line) at world size 2, stand-in workload
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import bench
+
+    class FakeWork:
+        """12 'rows' per point, spectra of 5 values that encode (rank, point) so the exchange can be checked."""
+        rows, D, B = 12, 5, 4
+
+        def __init__(self, args, rank, dev):
+            self.rank, self.out, self.cfg, self.last_S = rank, [], None, None
+
+        def point(self, i):
+            self.out.append(torch.tensor([50., 40., 30., 2., 1.]) + 0.01 * i + 0.001 * self.rank)
+
+        def collect(self):
+            out, self.out = torch.stack(self.out), []
+            return out
+
+    line = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--device", "cpu"], workload_factory=FakeWork)
+    q.put((rank, line))
+
+
+def test_bench_main_two_ranks_gloo(capfd):
+    """The driver launches bench.py with one rank per GPU; here its main() runs at world size 2 on CPU/gloo with a
+    stand-in workload: rank 0 prints the one JSON line, `value` counts both ranks' points, the spectra went through
+    parallel.gather_spectra (round-robin layout) and the process group is torn down."""
+    import json
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 27500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] is None
+    line = got[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["process_group"] == "gloo" and line["config"]["rows_per_point"] == 12
+    assert line["value"] == pytest.approx(2 * 3 * 12 / (line["ms_per_step"] * 3e-3), rel=1e-6)
+    assert line["id_estimates"] == [2, 2, 2]          # rank 0's three timed points: the cliff 30 -> 2 leaves two small values
+    printed = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(printed) == 1 and json.loads(printed[0])["metric"] == line["metric"]
