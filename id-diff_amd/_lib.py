@@ -30,6 +30,7 @@ class Epilogue(ctypes.Structure):
 _SIGNATURES = {
     "idiff_abi_version": (c_i, []),
     "idiff_last_error": (ctypes.c_char_p, []),
+    "idiff_source_stamp": (ctypes.c_char_p, []),
     "idiff_set_option": (c_i, [ctypes.c_char_p, c_i]),
     "idiff_upfirdn2d_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 14 + [c_p]),
     "idiff_fused_bias_act_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
@@ -87,6 +88,18 @@ def build(verbose=False):
     return _LIB_PATH
 
 
+def source_stamp():
+    """The stamp csrc/build.sh computes: sha256 over csrc/*.hip, csrc/*.h (sorted) and include/idiff_hip.h."""
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    names = sorted(f for f in os.listdir(csrc) if f.endswith(".hip") or f.endswith(".h"))
+    h = hashlib.sha256()
+    for f in [os.path.join(csrc, n) for n in names] + [os.path.join(os.path.dirname(_HERE), "include", "idiff_hip.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     """The loaded library; raises (never falls back) when it is missing or stale."""
     global _lib
@@ -101,6 +114,10 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if handle.idiff_abi_version() != 1:
             raise RuntimeError("libidiff_hip.so ABI version mismatch; rebuild it")
+        built, tree = handle.idiff_source_stamp().decode(), source_stamp()
+        if built != tree:
+            raise RuntimeError(f"{_LIB_PATH} was built from other sources (stamp {built}, tree {tree}): rebuild it with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = handle
     return _lib
 

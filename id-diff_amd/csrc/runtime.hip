@@ -41,7 +41,12 @@ int set_dynamic_lds_once(AttrGuard &g, const void *const *fns, int n_fns, int by
 }
 }  // namespace idiff
 
+#ifndef IDIFF_SOURCE_STAMP
+#define IDIFF_SOURCE_STAMP "unstamped"
+#endif
 IDIFF_API int idiff_abi_version(void) { return IDIFF_ABI_VERSION; }
+// sha256 (first 16 hex digits) of csrc/*.hip, csrc/*.h and include/idiff_hip.h at build time (csrc/build.sh)
+IDIFF_API const char *idiff_source_stamp(void) { return IDIFF_SOURCE_STAMP; }
 IDIFF_API const char *idiff_last_error(void) { return idiff::g_err; }
 
 // Debug switch by its environment-variable name ("IDIFF_NO_WINOGRAD", ...): returns the previous value, -1 if unknown.

@@ -29,6 +29,9 @@ extern "C" {
 
 int idiff_abi_version(void);
 const char *idiff_last_error(void);
+/* First 16 hex digits of the sha256 over the sources the library was built from (csrc/build.sh); the Python binding
+ * compares it with the tree and refuses a stale libidiff_hip.so. */
+const char *idiff_source_stamp(void);
 
 /* Debug / A-B switches, named like the environment variables that initialise them at load time:
  * IDIFF_NO_WINOGRAD (3x3 convs on the implicit GEMM), IDIFF_NO_COLSTATS, IDIFF_NO_PIPE, IDIFF_SCALAR_EPILOGUE,

@@ -44,3 +44,10 @@ cat $O/${TAG}_kernel_stats_top.txt | head -12
 echo "[4] plain bench"
 timeout -k 10 600 python3 bench.py --steps 3 --warmup 1 > $O/${TAG}_bench.json 2> $O/bench.err || echo "bench failed"
 cut -c1-300 $O/${TAG}_bench.json
+echo "[5] eigensolver kernels (two-stage) at D = 3072 and 12288"
+bash $R/scripts/sbr_prof.sh ${TAG}_sbr > $O/${TAG}_eigensolver_kernels.txt 2>&1 || echo "sbr profile failed"
+for D in 3072 12288; do cp $R/gpurun_out/${TAG}_sbr_$D/sbr_kernel_stats.csv $O/${TAG}_eigensolver_kernel_stats_$D.csv 2>/dev/null; done
+head -24 $O/${TAG}_eigensolver_kernels.txt
+echo "[6] memory-bound op kernels at SURVEY 8(d) cfg-3 shapes"
+timeout -k 10 300 python3 $R/scripts/ops_probe.py > $O/${TAG}_membound_kernels.log 2>&1 || echo "ops probe failed"
+tail -25 $O/${TAG}_membound_kernels.log

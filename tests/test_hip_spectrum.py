@@ -74,6 +74,51 @@ def test_batched_ksphere_shape():
         assert plot_utils.estimate_dim(sv[p].tolist()) == odim.estimate_dim(ref.tolist()) == 60
 
 
+@pytest.mark.parametrize("P", [64, 512, 4096])
+def test_batched_ksphere_at_config2_sizes(P):
+    """SURVEY 8(d) cfg 2: P in {64, 512, 4096} matrices of 1501 x 100 in ONE call (2.4 GB of fp32 at P = 4096, generated on
+    the device).  Every matrix: descending, sum sv^2 = ||S - mean||_F^2, ID = planted 60; 32 of them against the
+    reference path (fp32 gesdd on the host) at 1e-4."""
+    M, D, k = 1501, 100, 60
+    g = torch.Generator(device=DEV).manual_seed(P)
+    S = torch.randn(P, M, D, device=DEV, generator=g)
+    S[:, :, 40:] *= 0.02
+    S += 0.5
+    sv = _lib.spectrum(S)
+    assert sv.shape == (P, D) and bool((sv[:, :-1] >= sv[:, 1:]).all())
+    Sd = S[: min(P, 512)].double()                                           # fp64 Frobenius check on up to 512 of them
+    fro2 = ((Sd - Sd.mean(1, keepdim=True)) ** 2).sum((1, 2))
+    torch.testing.assert_close((sv[: Sd.shape[0]].double() ** 2).sum(1), fro2, rtol=1e-5, atol=0)
+    svc = sv.cpu()
+    ids = {plot_utils.estimate_dim(row.tolist()) for row in svc}
+    assert ids == {k}
+    for p in torch.linspace(0, P - 1, 32).long().tolist():
+        np.testing.assert_allclose(svc[p].numpy(), odim.spectrum(S[p].cpu()).numpy(), rtol=SV_RTOL)
+
+
+@pytest.mark.parametrize("cond", [1e5, 1e6])
+def test_geometric_spectra_stress(cond):
+    """SURVEY 8(d) stress set up to cond 1e6, with the floor of the Gram route written down: the Gram eigenvalues carry
+    an absolute error of a few u * lambda_max (u = 2^-53), i.e. a singular value sigma is good to
+    |d sigma| <= c u sigma_max^2 / (2 sigma).  At the 1e-4 relative bar that floor sits at sigma ~ 2e-6 sigma_max; below
+    it the test asks for the absolute bound instead.  (The reference's own fp32 gesdd is only good to ~3e-7 sigma_max
+    absolute, so its values below ~3e-3 sigma_max are no yardstick: the comparison is against an fp64 SVD.)"""
+    g = torch.Generator().manual_seed(int(cond))
+    M, D = 900, 200
+    u, _ = torch.linalg.qr(torch.randn(M, D, generator=g, dtype=torch.float64))
+    v, _ = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))
+    s = torch.logspace(0, -np.log10(cond), D, dtype=torch.float64) * 500
+    S = ((u * s) @ v.T).float()
+    sv = _lib.spectrum(S.to(DEV)).cpu().double()
+    Sd = S.double()
+    exact = torch.linalg.svdvals(Sd - Sd.mean(0, keepdim=True))
+    smax = float(exact[0])
+    bound = 1e-4 * exact + 40 * 2.0 ** -53 * smax * smax / (2 * exact.clamp_min(1e-300)) + 1e-7 * exact   # + fp32 rounding of sv
+    assert bool(((sv - exact).abs() <= bound).all()), float(((sv - exact).abs() / bound).max())
+    above = exact > 2e-6 * smax
+    np.testing.assert_allclose(sv.numpy()[above], exact.numpy()[above], rtol=SV_RTOL)
+
+
 def test_image_sized_matrix():
     """BASELINE config 3 size (4480 x 3072): large-D path; properties + parity with the CPU SVD."""
     g = torch.Generator().manual_seed(3)
