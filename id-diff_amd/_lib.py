@@ -64,6 +64,8 @@ _SIGNATURES = {
     "idiff_spectrum_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p]),
     "idiff_colmean_f64": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "idiff_centered_gram_f64": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "idiff_centered_gram_rows_f64": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "idiff_symmetrize_upper_f64": (c_i, [c_p, c_i, c_p]),
     "idiff_symtridiag_scratch_doubles": (c_i64, [c_i]),
     "idiff_symband_ld": (c_i, []),
     "idiff_symband_f64": (c_i, [c_p, c_i, c_p, c_p]),
@@ -412,6 +414,23 @@ def centered_gram(S, mean):
         return torch.zeros(D, D, dtype=torch.float64, device=S.device)
     G = torch.empty(D, D, dtype=torch.float64, device=S.device)
     _check(lib().idiff_centered_gram_f64(S.data_ptr(), mean.data_ptr(), 1, M, D, G.data_ptr(), _stream()), "idiff_centered_gram_f64")
+    return G
+
+
+def centered_gram_rows(S, mean, G, row0, row1):
+    """Upper-triangle rows [row0, row1) of the centred Gram into the (pre-zeroed) [D, D] fp64 matrix G."""
+    _dev(S, "scores"); _dev(mean, "mean", dtype=torch.float64); _dev(G, "G", dtype=torch.float64)
+    M, D = S.shape
+    if M == 0:
+        return G
+    _check(lib().idiff_centered_gram_rows_f64(S.data_ptr(), mean.data_ptr(), M, D, row0, row1, G.data_ptr(), _stream()),
+           "idiff_centered_gram_rows_f64")
+    return G
+
+
+def symmetrize_upper(G):
+    _dev(G, "G", dtype=torch.float64)
+    _check(lib().idiff_symmetrize_upper_f64(G.data_ptr(), G.shape[0], _stream()), "idiff_symmetrize_upper_f64")
     return G
 
 

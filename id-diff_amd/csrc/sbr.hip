@@ -732,10 +732,11 @@ struct ChaseArgs {
 
 __device__ __forceinline__ void make_house(double x0, double tail, double &alpha, double &v0, double &tau) {
   if (tail == 0.0) { alpha = x0; v0 = 0.0; tau = 0.0; return; }
-  const double norm = sqrt(x0 * x0 + tail);
+  const double n2 = x0 * x0 + tail;
+  const double norm = n2 * fast_rsqrt(n2);          // on the critical path of every chase step: no IEEE sqrt / division
   alpha = x0 > 0.0 ? -norm : norm;
   v0 = x0 - alpha;
-  tau = 2.0 / (v0 * v0 + tail);
+  tau = 2.0 * fast_rcp(v0 * v0 + tail);
 }
 
 // Thread (r = tid >> 2, part = tid & 3) keeps row r of the 2BW x BW window, columns [8 part, 8 part + 8), in registers
@@ -915,7 +916,7 @@ __device__ __forceinline__ void msg_recv(const unsigned long long *box, double *
 }
 
 __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
-  __shared__ double v[BW], pq[2 * BW], x2[BW], dpart[2][BW];
+  __shared__ double v[MSG], pq[2 * BW], x2[BW], dpart[2][BW];
   __shared__ double msg_in[MSG], msg_out[MSG], colbuf[MSG], rowbuf[BW], edge[4][BW], xcol[BW];
   __shared__ double sc[2];
   __shared__ int ab;
@@ -993,14 +994,11 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
         if (lane == 0) { sc[0] = tl; if (s < g.D) g.offd[s] = alpha; }
       }
     } else {
-      msg_recv(mailbox(g, t, 0, s & 1), msg_in, (unsigned)(s + 1), g.abort_flag);
-      __syncthreads();
-      if (tid < BW) v[tid] = msg_in[tid];
-      if (tid == 0) sc[0] = msg_in[BW];
+      msg_recv(mailbox(g, t, 0, s & 1), v, (unsigned)(s + 1), g.abort_flag);     // v[0 .. BW) and tau = v[BW] in one piece
     }
     __syncthreads();
     if (__hip_atomic_load(g.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ab = 1;   // benign race: all write 1
-    const double tau = sc[0];
+    const double tau = t == 0 ? sc[0] : v[BW];
     if (tau != 0.0) {
       double ps = 0.0;
 #pragma unroll

@@ -53,11 +53,11 @@ constexpr int GPITCH = GT + 16;  // row offset = 16 banks: the 4 rows of a k-ste
 
 __global__ void __launch_bounds__(256)
 gram_kernel(const float *__restrict__ S, const double *__restrict__ mean, int M, int D, int tiles,
-            double *__restrict__ G) {
+            double *__restrict__ G, int ti_first, int mirror) {
   __shared__ float Si[GROWS * GPITCH];
   __shared__ float Sj[GROWS * GPITCH];
   // decode upper-triangular tile index
-  int t = blockIdx.x, ti = 0;
+  int t = blockIdx.x, ti = ti_first;       // upper-triangular tiles of the tile rows ti_first, ti_first + 1, ...
   while (t >= tiles - ti) { t -= tiles - ti; ++ti; }
   const int tj = ti + t;
   const int p = blockIdx.y;
@@ -128,7 +128,7 @@ gram_kernel(const float *__restrict__ S, const double *__restrict__ mean, int M,
         if (gi < D && gj < D) {
           const double v = acc[qa][qb][r];
           Gp[(int64_t)gi * D + gj] = v;
-          if (ti != tj) Gp[(int64_t)gj * D + gi] = v;
+          if (ti != tj && mirror) Gp[(int64_t)gj * D + gi] = v;
         }
       }
 }
@@ -774,9 +774,51 @@ IDIFF_API int idiff_centered_gram_f64(const float *S, const double *mean, int P,
   if (P > 65535) return fail("centered_gram: P too large");
   const int tiles = ceil_div(D, GT);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gram_kernel, dim3(tiles * (tiles + 1) / 2, P), dim3(256), 0, st, S, mean, M, D, tiles, G);
+  hipLaunchKernelGGL(gram_kernel, dim3(tiles * (tiles + 1) / 2, P), dim3(256), 0, st, S, mean, M, D, tiles, G, 0, 1);
   hipLaunchKernelGGL(symmetrize_diag_tiles_kernel, dim3(tiles, P), dim3(256), 0, st, G, D);
   return launch_status("centered_gram");
+}
+
+// Rows [row0, row1) of the UPPER triangle of the centred Gram matrix (row0, row1 multiples of 64 or D): G[i][j] for
+// row0 <= i < row1, j >= 64 * (i / 64); nothing else is written.  The row-sharded pipeline computes G one block of rows at
+// a time so that the all-reduce of block b runs while block b + 1 is being computed; idiff_symmetrize_upper_f64
+// completes the matrix afterwards.
+IDIFF_API int idiff_centered_gram_rows_f64(const float *S, const double *mean, int M, int D, int row0, int row1, double *G,
+                                           void *stream) {
+  if (!S || !mean || !G || M <= 0 || D <= 0) return fail("centered_gram_rows: bad arguments");
+  if (row0 < 0 || row1 > D || row0 >= row1 || row0 % GT || (row1 % GT && row1 != D))
+    return fail("centered_gram_rows: rows [%d, %d) must be tile-aligned (%d) inside [0, %d)", row0, row1, GT, D);
+  const int tiles = ceil_div(D, GT), t0 = row0 / GT, t1 = ceil_div(row1, GT);
+  int count = 0;
+  for (int ti = t0; ti < t1; ++ti) count += tiles - ti;
+  hipLaunchKernelGGL(gram_kernel, dim3(count, 1), dim3(256), 0, (hipStream_t)stream, S, mean, M, D, tiles, G, t0, 0);
+  return launch_status("centered_gram_rows");
+}
+
+namespace {
+__global__ void __launch_bounds__(256) symmetrize_upper_kernel(double *__restrict__ G, int D) {
+  // lower <- upper, 32 x 32 tiles through LDS so that both sides are coalesced
+  __shared__ double tile[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    tile[r][tx] = (i < D && j < D) ? G[(int64_t)i * D + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int j = bj * 32 + r, i = bi * 32 + tx;      // element (j, i) of the lower triangle <- (i, j)
+    if (i < D && j < D && j > i) G[(int64_t)j * D + i] = tile[tx][r];
+  }
+}
+}  // namespace
+
+IDIFF_API int idiff_symmetrize_upper_f64(double *G, int D, void *stream) {
+  if (!G || D <= 0) return fail("symmetrize_upper: bad arguments");
+  const int nb = ceil_div(D, 32);
+  hipLaunchKernelGGL(symmetrize_upper_kernel, dim3(nb, nb), dim3(256), 0, (hipStream_t)stream, G, D);
+  return launch_status("symmetrize_upper");
 }
 
 IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double *offdiag, double *scratch, void *stream) {

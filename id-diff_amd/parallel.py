@@ -89,3 +89,19 @@ def all_reduce_sum(tensor):
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor
+
+
+def all_reduce_sum_async(tensor):
+    """Start an in-place sum over the default process group; returns a handle for ``wait`` (None without a group).
+
+    On RCCL the collective runs on the communicator's own stream after the work already queued on the current stream
+    (``tensor`` is complete when it starts), so the caller can go on queueing compute: the two overlap."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
+def wait(work):
+    """Make the current stream (GPU) / the caller (CPU) wait for an asynchronous collective."""
+    if work is not None:
+        work.wait()

@@ -215,6 +215,13 @@ int idiff_spectrum_f32(const float *S, int P, int M, int D, void *workspace, int
 /* scratch: P * 32 * D doubles (deterministic two-stage column sums). */
 int idiff_colmean_f64(const float *S, int P, int M, int D, double *mean, double *scratch, void *stream);
 int idiff_centered_gram_f64(const float *S, const double *mean, int P, int M, int D, double *G, void *stream);
+/* Row-sharded single point (one point's rows spread over the ranks): the upper triangle of the
+ * centred Gram for rows [row0, row1) only (tile-aligned: multiples of 64, or D), so that block b can be all-reduced
+ * while block b + 1 is computed; idiff_symmetrize_upper_f64 mirrors the reduced upper triangle afterwards.  G is
+ * [D][D] fp64 and should be zeroed first (the part left of a block's diagonal tile is not written). */
+int idiff_centered_gram_rows_f64(const float *S, const double *mean, int M, int D, int row0, int row1, double *G,
+                                 void *stream);
+int idiff_symmetrize_upper_f64(double *G, int D, void *stream);
 /* G [P][D][D] symmetric (both triangles), overwritten -> diag/offdiag [P][D] of a similar tridiagonal matrix.
  * D <= 128: one workgroup per matrix in LDS.  Larger D: two-stage -- blocked reduction to a band of half-width 32
  * (CholeskyQR2 + Householder-reconstruction panels, compact-WY rank-64 trailing updates on v_mfma_f64_16x16x4) and

@@ -256,8 +256,18 @@ def test_row_sharded_spectrum_single_rank_and_emulated_halves():
     a, b = S[:500].contiguous(), S[500:].contiguous()
     mean = (_lib.column_sums(a) + _lib.column_sums(b)) / M
     G = _lib.centered_gram(a, mean) + _lib.centered_gram(b, mean)
-    sv2 = _lib.sym_eigvals(G).clamp_min(0).sqrt().flip(0).float()
+    sv2 = _lib.sym_eigvals(G.clone()).clamp_min(0).sqrt().flip(0).float()
     torch.testing.assert_close(sv2, ref, rtol=2e-6, atol=1e-6)
+    # the blocked form the pipeline uses: upper-triangle row blocks + one mirror = the full Gram, bit for bit
+    for blocks in ((0, 384), (0, 128, 384), (0, 64, 192, 256, 384)):
+        Gb = torch.zeros(D, D, device=DEV, dtype=torch.float64)
+        for r0, r1 in zip(blocks[:-1], blocks[1:]):
+            _lib.centered_gram_rows(a, mean, Gb, r0, r1)
+        assert float(torch.tril(Gb, -64).abs().max()) == 0.0           # nothing written below the diagonal tiles
+        _lib.symmetrize_upper(Gb)
+        assert torch.equal(Gb, _lib.centered_gram(a, mean))
+    with pytest.raises(RuntimeError, match="tile-aligned"):
+        _lib.centered_gram_rows(a, mean, torch.zeros(D, D, device=DEV, dtype=torch.float64), 10, 100)
     assert float(_lib.column_sums(S[:0]).abs().sum()) == 0.0 and float(_lib.centered_gram(S[:0], mean).abs().sum()) == 0.0
     with pytest.raises(RuntimeError, match="total_rows >= D"):
         dim_reduction.row_sharded_spectrum(S[:100].contiguous(), 100)

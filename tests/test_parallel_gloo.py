@@ -55,9 +55,18 @@ def test_gather_two_ranks_ragged_and_idle_rank():
 # ---- row-sharded single point: the two all-reduces, with plain-torch stand-ins for the HIP stages
 def _torch_ops():
     col_sums = lambda S: S.double().sum(0)
-    gram = lambda S, mean: (S.double() - mean).T @ (S.double() - mean)
+
+    def gram_rows(S, mean, G, r0, r1):            # upper-triangle rows [r0, r1), nothing left of the block's diagonal tile
+        c = S.double() - mean
+        G[r0:r1, r0:] = c[:, r0:r1].T @ c[:, r0:]
+        return G
+
+    def symmetrize(G):
+        G.copy_(torch.triu(G) + torch.triu(G, 1).T)
+        return G
+
     eigvals = lambda G: torch.linalg.eigvalsh(G)
-    return col_sums, gram, eigvals
+    return col_sums, gram_rows, symmetrize, eigvals
 
 
 def _rows_worker(rank, world, port, M, D, q):
@@ -69,7 +78,7 @@ def _rows_worker(rank, world, port, M, D, q):
     parallel.init_from_env(backend="gloo")
     S = torch.randn(M, D, generator=torch.Generator().manual_seed(5)) + 3.0      # every rank draws the same matrix
     lo, hi = parallel.my_rows(M, rank, world)
-    sv = dim_reduction.row_sharded_spectrum(S[lo:hi].contiguous(), M, ops=_torch_ops())
+    sv = dim_reduction.row_sharded_spectrum(S[lo:hi].contiguous(), M, ops=_torch_ops(), block_rows=5)   # 3 blocks, async
     q.put((rank, (lo, hi), sv))
     dist.barrier()
     dist.destroy_process_group()
