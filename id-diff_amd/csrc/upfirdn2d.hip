@@ -211,6 +211,67 @@ upfirdn2d_planes_whole(const float *__restrict__ x, const float *__restrict__ k,
   }
 }
 
+// ---------------------------------------------------------------- minor == 1, plain FIR on small planes
+// up == down == 1, kh, kw <= 4 (the FIR in front of a stride-2 convolution, up_or_down_sampling.py:144-178): thread =
+// (plane, output row).  It walks its row with the three previous inputs of each of the four input rows in registers:
+// four LDS reads per output instead of sixteen, every lane busy whatever the row length (a 17 x 17 output on a 32 x 8
+// thread tile left 62 % of the lanes idle).  Planes sit in LDS with a pitch of in_w + 1 words (rows of one plane on
+// distinct banks); results go through LDS once more so that the stores are contiguous.
+__global__ void __launch_bounds__(256)
+upfirdn2d_planes_rowslide(const float *__restrict__ x, const float *__restrict__ k, float *__restrict__ out, UfdParams p, int ppb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *taps = lds;                        // [4][4] flipped, zero beyond kh x kw
+  float *pl = lds + 16;                     // [ppb][in_h][in_w + 1]
+  const int tid = threadIdx.x;
+  const int pitch = p.in_w + 1, psz = p.in_h * p.in_w, lpsz = p.in_h * pitch, osz = p.out_h * p.out_w;
+  float *ob = pl + ppb * lpsz;              // [ppb][out_h * out_w]
+  if (tid < 16) {
+    const int ky = tid >> 2, kx = tid & 3;
+    taps[tid] = (ky < p.kh && kx < p.kw) ? k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)] : 0.f;
+  }
+  const int plane0 = blockIdx.x * ppb;
+  const int nplanes = min(ppb, p.major - plane0);
+  const float *src = x + (int64_t)plane0 * psz;
+  for (int i = tid; i < nplanes * psz; i += 256) {
+    const int q = i / psz, r = i - q * psz, iy = r / p.in_w, ix = r - iy * p.in_w;
+    pl[q * lpsz + iy * pitch + ix] = src[i];
+  }
+  __syncthreads();
+  const int q = tid / p.out_h, oy = tid - q * p.out_h;
+  if (q < nplanes) {
+    float t[4][4], c[4][3];
+    const float *row[4];
+    bool rv[4];
+    const int by = oy - p.pad_y0, bx0 = -p.pad_x0;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int iy = by + ky;
+      rv[ky] = ky < p.kh && iy >= 0 && iy < p.in_h;
+      row[ky] = pl + q * lpsz + (rv[ky] ? iy : 0) * pitch;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) t[ky][kx] = rv[ky] ? taps[ky * 4 + kx] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { const int ix = bx0 + j; c[ky][j] = (rv[ky] && ix >= 0 && ix < p.in_w) ? row[ky][ix] : 0.f; }
+    }
+    float *orow = ob + q * osz + oy * p.out_w;
+    for (int ox = 0; ox < p.out_w; ++ox) {
+      const int ix3 = bx0 + ox + 3;
+      const bool in3 = ix3 >= 0 && ix3 < p.in_w;
+      float acc = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky) {
+        const float c3 = (in3 && rv[ky]) ? row[ky][ix3] : 0.f;    // a row outside the image contributes exact zeros
+        acc += c[ky][0] * t[ky][0] + c[ky][1] * t[ky][1] + c[ky][2] * t[ky][2] + c3 * t[ky][3];
+        c[ky][0] = c[ky][1]; c[ky][1] = c[ky][2]; c[ky][2] = c3;
+      }
+      orow[ox] = acc;
+    }
+  }
+  __syncthreads();
+  float *dst = out + (int64_t)plane0 * osz;
+  for (int i = tid; i < nplanes * osz; i += 256) dst[i] = ob[i];
+}
+
 // ---------------------------------------------------------------- minor % 4 == 0, row-structured
 // grid.x = (plane, oy); a thread keeps its channel vector c4 and walks output columns, so the only integer
 // divisions are the two that split blockIdx.x (uniform) -- the per-element 64-bit div/mod of a flat grid-stride
@@ -371,6 +432,16 @@ IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, in
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)major * p.out_h * p.out_w * minor;
 
+  if (minor == 1 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh <= 4 && kw <= 4 && p.out_h <= 128 &&
+      (int64_t)in_h * in_w <= 4096) {
+    // plain FIR on small planes: one thread per (plane, output row)
+    const int lpsz = in_h * (in_w + 1), osz = p.out_h * p.out_w;
+    int ppb = max(1, min(256 / p.out_h, (int)((60 * 1024 / 4 - 16) / (lpsz + osz))));
+    ppb = max(1, min(ppb, max(1, major / 512)));             // keep >= ~2 workgroups per CU when there are few planes
+    const size_t lds_bytes = (16 + (size_t)ppb * (lpsz + osz)) * sizeof(float);
+    hipLaunchKernelGGL(upfirdn2d_planes_rowslide, dim3(ceil_div(major, ppb)), dim3(256), lds_bytes, st, x, k, out, p, ppb);
+    return launch_status("upfirdn2d_planes_rowslide");
+  }
   if (minor == 1 && kh * kw <= kMaxTaps && (int64_t)in_h * in_w <= 8192 && (int64_t)p.out_h * p.out_w <= 16384) {
     // whole planes in LDS: <= 32 KB per plane; as many planes per workgroup as fit 32 KB / ~16 outputs per thread
     const int psz = in_h * in_w, osz = p.out_h * p.out_w;

@@ -13,10 +13,22 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps
+FLOOR = None   # seconds per call of the same entry point on a 4 KB tensor: host issue + launch + drain, no data
 def say(name, nbytes, dt):
-    print(f"{name:58s} {dt*1e6:8.1f} us  {nbytes/dt/1e9:7.0f} GB/s  ({nbytes/dt/8e12*100:4.1f}% of 8 TB/s)", flush=True)
+    raw = nbytes / dt
+    note = ""
+    if FLOOR is not None:
+        corrected = nbytes / max(dt - FLOOR, 1e-7)
+        note = f"  floor {FLOOR*1e6:4.1f} us -> {corrected/1e9:6.0f} GB/s net"
+        if dt < 2.0 * FLOOR:
+            note += "  LAUNCH-BOUND"
+    print(f"{name:58s} {dt*1e6:8.1f} us  {raw/1e9:7.0f} GB/s  ({raw/8e12*100:4.1f}% of 8 TB/s){note}", flush=True)
 
 k = torch.tensor(np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0, dtype=torch.float32, device=dev)
+# launch floor of a raw C-ABI call (what every row below pays before the first byte moves)
+_x0 = torch.randn(1, 1, 32, 32, device=dev); _o0 = torch.empty(1, 1, 33, 33, device=dev)
+FLOOR = timeit(lambda: _lib.upfirdn2d_raw(_x0, k, _o0, 1, 32, 32, 1, 1, 1, 1, 1, 2, 2, 2, 2), reps=200)
+print(f"launch floor (upfirdn2d on one 32x32 plane, back-to-back calls): {FLOOR*1e6:.1f} us per call", flush=True)
 # op.upfirdn2d (NCHW, minor = 1) at the three ncsnpp families, B = 128
 for shape, up, down, pad in [((128, 128, 32, 32), 1, 2, (1, 1)), ((128, 256, 16, 16), 1, 2, (1, 1)), ((128, 256, 16, 16), 2, 1, (2, 1)),
                              ((128, 256, 8, 8), 2, 1, (2, 1)), ((128, 3, 32, 32), 1, 1, (2, 2)), ((128, 128, 16, 16), 1, 1, (2, 2))]:
@@ -35,9 +47,13 @@ for (B, H, C, up, down, pad) in [(512, 32, 128, 1, 2, (1, 1)), (512, 16, 256, 2,
     kk = k * (4 if up == 2 else 1)
     def f(): _lib.upfirdn2d_raw(x, kk, out, B, H, H, C, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
     say(f"upfirdn2d NHWC B={B} {H}x{H}x{C} up{up} down{down}", 4 * (x.numel() + out.numel()) + 64, timeit(f))
+_xs = torch.randn(1, 4, 4, 4, device=dev); _bs = torch.randn(4, device=dev)
+FLOOR = timeit(lambda: op.fused_leaky_relu(_xs, _bs), reps=200)     # the op API: autograd Function + torch.empty_like + launch
+print(f"launch floor (op.fused_leaky_relu on 64 elements): {FLOOR*1e6:.1f} us per call", flush=True)
 for shape in [(128, 128, 32, 32), (128, 256, 16, 16), (128, 256, 8, 8), (128, 256, 4, 4)]:
     x = torch.randn(*shape, device=dev); b = torch.randn(shape[1], device=dev)
     say(f"fused_leaky_relu {shape}", 4 * (2 * x.numel() + shape[1]), timeit(lambda: op.fused_leaky_relu(x, b)))
+FLOOR = None
 for (B, HW, C, G) in [(512, 1024, 128, 32), (512, 256, 256, 32), (512, 1024, 256, 32)]:
     x = torch.randn(B, HW, C, device=dev)
     ns = _lib.groupnorm_nsplit(B, HW, C)
