@@ -126,10 +126,10 @@ def lib():
 
 def set_option(name, value):
     """Flip a library debug switch (``IDIFF_NO_WINOGRAD`` ...); returns the previous value."""
-    prev = lib().idiff_set_option(name.encode(), int(bool(value)))
+    prev = lib().idiff_set_option(name.encode(), int(value))
     if prev < 0:
         raise KeyError(f"unknown libidiff_hip option {name!r}")
-    return bool(prev)
+    return prev if prev > 1 else bool(prev)
 
 
 def _check(rc, what):

@@ -36,8 +36,9 @@ inline int launch_status(const char *what) {
 // ---- process-level debug switches (A/B experiments, parity tests).  Read from the environment ONCE, when the library
 // is loaded (no getenv on any launch path); idiff_set_option() flips them afterwards.
 enum Option { OPT_NO_WINOGRAD, OPT_NO_COLSTATS, OPT_NO_PIPE, OPT_SCALAR_EPILOGUE, OPT_DBUF_ONLY, OPT_TRIDIAG_ONESTAGE,
-              OPT_UFD_ROWS, OPT_CHASE_WAVEFRONT, OPT_COUNT };
+              OPT_UFD_ROWS, OPT_CHASE_WAVEFRONT, OPT_WINO_NGROUP, OPT_COUNT };
 bool option(Option o);
+int option_value(Option o);   // the integer behind a switch (IDIFF_WINO_NGROUP: output-channel tiles per scheduling group)
 
 // hipFuncSetAttribute is per DEVICE: one bit per device ordinal, so a process that drives several GPUs sets the
 // attribute on each of them (a process-wide `static bool` would leave the second device at the 64 KB default).

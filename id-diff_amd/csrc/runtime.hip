@@ -14,17 +14,19 @@ void set_error(const char *fmt, ...) {
 
 namespace {
 const char *const kOptionNames[OPT_COUNT] = {"IDIFF_NO_WINOGRAD", "IDIFF_NO_COLSTATS", "IDIFF_NO_PIPE", "IDIFF_SCALAR_EPILOGUE",
-                                             "IDIFF_DBUF_ONLY", "IDIFF_TRIDIAG_ONESTAGE", "IDIFF_UFD_ROWS", "IDIFF_CHASE_WAVEFRONT"};
+                                             "IDIFF_DBUF_ONLY", "IDIFF_TRIDIAG_ONESTAGE", "IDIFF_UFD_ROWS", "IDIFF_CHASE_WAVEFRONT",
+                                             "IDIFF_WINO_NGROUP"};
 struct OptionTable {
   int v[OPT_COUNT];
   OptionTable() {
-    for (int i = 0; i < OPT_COUNT; ++i) { const char *e = getenv(kOptionNames[i]); v[i] = (e && *e && strcmp(e, "0") != 0) ? 1 : 0; }
+    for (int i = 0; i < OPT_COUNT; ++i) { const char *e = getenv(kOptionNames[i]); v[i] = (e && *e) ? atoi(e) : 0; }
   }
 };
 OptionTable g_options;     // constructed when the shared object is loaded
 }  // namespace
 
 bool option(Option o) { return __atomic_load_n(&g_options.v[o], __ATOMIC_RELAXED) != 0; }
+int option_value(Option o) { return __atomic_load_n(&g_options.v[o], __ATOMIC_RELAXED); }
 
 int set_dynamic_lds_once(AttrGuard &g, const void *const *fns, int n_fns, int bytes, const char *what) {
   int dev = 0;
@@ -54,6 +56,6 @@ IDIFF_API int idiff_set_option(const char *name, int value) {
   using namespace idiff;
   if (!name) return -1;
   for (int i = 0; i < OPT_COUNT; ++i)
-    if (strcmp(name, kOptionNames[i]) == 0) return __atomic_exchange_n(&g_options.v[i], value ? 1 : 0, __ATOMIC_RELAXED);
+    if (strcmp(name, kOptionNames[i]) == 0) return __atomic_exchange_n(&g_options.v[i], value, __ATOMIC_RELAXED);
   return -1;
 }

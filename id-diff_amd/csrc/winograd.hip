@@ -71,7 +71,7 @@ struct WinoParams {
   float *out;
   int B, H, W, Cin, Cout;
   int tiles_x, tiles_per_img, total_tiles;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, ngroup;   // ngroup: output-channel tiles scheduled together (tile_n innermost inside a group)
   uint32_t x_bytes, u_bytes;
   idiff_epilogue ep;
   int has_ep;
@@ -90,7 +90,11 @@ winograd_kernel(const WinoParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  // groups of `ngroup` output-channel tiles: inside a group tile_n is innermost (the workgroups of an XCD share the input
+  // patches of a run of tile_m and stream only ngroup filter slabs), the groups follow one another
+  const int per_group = p.tiles_m * p.ngroup;
+  const int grp = bid / per_group, in_grp = bid - grp * per_group;
+  const int tile_n = grp * p.ngroup + in_grp % p.ngroup, tile_m = in_grp / p.ngroup;
   const int tile0 = tile_m * WG_TILES, n0 = tile_n * WG_COUT;
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave index in an SGPR: roles, operand halves and buffer descriptors stay provably wave-uniform (no waterfall
@@ -440,6 +444,12 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
   p.x = x; p.u = u; p.out = out; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.tiles_x = W / 2; p.tiles_per_img = (H / 2) * (W / 2); p.total_tiles = B * p.tiles_per_img;
   p.tiles_m = ceil_div(p.total_tiles, WG_TILES); p.tiles_n = Cout / WG_COUT;
+  {
+    // two output-channel tiles per scheduling group: the workgroups of an XCD then stream two filter slabs instead of
+    // four (1.5-3 % on the Cout = 256 layers; the slabs of four tiles plus the live input lines overflow the 4 MB L2)
+    const int want = option_value(OPT_WINO_NGROUP);
+    p.ngroup = (want > 0 && p.tiles_n % want == 0) ? want : ((p.tiles_n > 2 && p.tiles_n % 2 == 0) ? 2 : p.tiles_n);
+  }
   p.x_bytes = (uint32_t)x_bytes; p.u_bytes = (uint32_t)((int64_t)16 * Cin * Cout * 4);
   if (ep) {
     p.ep = *ep; p.has_ep = 1;

@@ -177,6 +177,17 @@ def row_sharded_spectrum(S_local, total_rows, ops=None, block_rows=None):
     return eig.clamp_min(0.0).sqrt().flip(0).to(torch.float32)
 
 
+def checked_spectra(spectra):
+    """Host copy of gathered spectra.  The eigensolver poisons its output with NaN instead of returning a wrong spectrum
+    (band-reduction residual above tolerance, a stalled chase: include/idiff_hip.h, idiff_symtridiag_f64); this is where
+    the values first reach the host, so this is where that turns into an exception."""
+    host = spectra.cpu()
+    if bool(torch.isnan(host).any()):
+        raise RuntimeError("the spectrum kernels reported a failure (NaN singular values): non-finite score vectors, or the "
+                           "two-stage eigensolver gave up -- rerun with IDIFF_TRIDIAG_ONESTAGE=1 to use the unblocked sweep")
+    return host
+
+
 def build_many(builder, xs, batchsize, seeds):
     """S [P, M, D] for P small (vector) points with ONE score_fn call over all P*M rows: the k-sphere workload is
     launch-bound one point at a time (M = 1501 rows of a 7-layer MLP), so points are batched (BASELINE config 2)."""
@@ -274,7 +285,7 @@ def get_manifold_dimension(config, name=None, return_svd=False):
                 rows = batching(tuple(x.shape), batchsize)[2]
                 S_local = builder.build(x.to(device), batchsize, seed=point_seed(p), row_range=parallel.my_rows(rows, rank, world))
                 spectra.append(row_sharded_spectrum(S_local, rows))
-        info = {'singular_values': [s.tolist() for s in torch.stack(spectra).cpu()]}
+        info = {'singular_values': [s.tolist() for s in checked_spectra(torch.stack(spectra))]}
         if return_svd:
             return info
         if rank == 0:
@@ -310,7 +321,7 @@ def get_manifold_dimension(config, name=None, return_svd=False):
         n_sv = min(batching(tuple(x.shape), batchsize)[2], x.numel())
     local = torch.stack(local) if local else torch.empty(0, n_sv, device=device)
     spectra = parallel.gather_spectra(local, len(points), n_sv, device)
-    info = {'singular_values': [s.tolist() for s in spectra.cpu()]}
+    info = {'singular_values': [s.tolist() for s in checked_spectra(spectra)]}
     if return_svd:
         return info
     if rank == 0:
@@ -367,7 +378,7 @@ def conditional_spectra(builder, loader, num_datapoints, seed=42, levels=None, n
             x0, _, b0 = points[0]
             n_sv = min(batching(tuple(x0.shape), b0)[2], x0.numel())
             local = torch.stack(local) if local else torch.empty(0, n_sv, device=device)
-            spectra = parallel.gather_spectra(local, len(points), n_sv, device).cpu()
+            spectra = checked_spectra(parallel.gather_spectra(local, len(points), n_sv, device))
         else:
             spectra = torch.empty(0, 0)
         out.append({'level': level, 't': float(t_slice),

@@ -28,5 +28,12 @@ for H, Cin, Cout in shapes:
     tw = timeit(lambda: _lib.conv2d_winograd(x, u, o2, B, H, H, Cin, Cout, epilogue=ep))
     err = float((o1.double() - o2.double()).norm() / o1.double().norm())
     fl = 2.0 * B * H * H * Cin * Cout * 9
+    extra = ""
+    for ng in (1, 2):
+        if (Cout // 64) % ng == 0 and Cout // 64 > ng:
+            _lib.set_option("IDIFF_WINO_NGROUP", ng)
+            tg = timeit(lambda: _lib.conv2d_winograd(x, u, o2, B, H, H, Cin, Cout, epilogue=ep))
+            _lib.set_option("IDIFF_WINO_NGROUP", 0)
+            extra += f" | ngroup{ng} {tg:7.3f} ms"
     say(f"{H:2d}x{H:<2d} {Cin:3d}->{Cout:3d}: direct {td:7.3f} ms {fl/td/1e9:6.1f} TF | winograd {tw:7.3f} ms {fl/tw/1e9:6.1f} TF-equiv "
-        f"({fl/2.25/tw/1e9:5.1f} TF executed) | x{td/tw:4.2f} | rel diff {err:.2e}")
+        f"({fl/2.25/tw/1e9:5.1f} TF executed) | x{td/tw:4.2f} | rel diff {err:.2e}" + extra)

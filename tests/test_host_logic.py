@@ -348,3 +348,11 @@ def test_missing_checkpoint_is_an_error_unless_opted_in():
     cfg = read_config('configs/dimension_estimation/paper/euclidean_data/ksphere/10dim.py')
     cfg.model.name = 'ksphere_exact'                    # analytic score: nothing to restore
     create_lightning_module(cfg).load_from_checkpoint(None)
+
+
+def test_nan_spectra_raise_instead_of_yielding_an_id():
+    """The eigensolver reports trouble as NaN (never a silently wrong spectrum); the driver turns that into an error."""
+    ok = torch.tensor([[3.0, 2.0, 1.0]])
+    assert torch.equal(dim_reduction.checked_spectra(ok), ok)
+    with pytest.raises(RuntimeError, match="reported a failure"):
+        dim_reduction.checked_spectra(torch.tensor([[3.0, float("nan"), 1.0]]))
