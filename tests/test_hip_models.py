@@ -13,7 +13,9 @@ from oracle import dim as odim, ksphere as oks, models as omodels, sde as osde
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-# fp32 networks evaluated with a different (but exact-fp32) summation order than ATen's CPU kernels
+# fp32 networks evaluated with a different (but exact-fp32) summation order than ATen's CPU kernels.  Measured on the
+# 16x16 nf=8 NCSN++ (scripts/relerr_probe.py): HIP vs oracle 1.2e-6; HIP vs an fp64 evaluation of the same weights
+# 1.0e-6, the oracle's own fp32 vs fp64 9.7e-7 -- the HIP path is as close to the exact network as the reference path is.
 NET_RTOL = 2e-5
 
 
@@ -177,7 +179,7 @@ def test_score_matrix_and_spectrum_ncsnpp_small_vs_oracle():
     x = torch.rand(3, 16, 16, generator=torch.Generator().manual_seed(1))
     sde_c, sde_h = osde.VESDE(0.01, 50, 1000), sde_lib.VESDE(0.01, 50, 1000)
     S, S_ref = _pipeline_pair(mutils.get_score_fn(sde_h, model), osde.get_score_fn(sde_c, ref_model), sde_h, sde_c, x, 100, 1e-5)
-    assert S.shape == (1156, 768) and rel_err(S.cpu(), S_ref) < 5e-5   # (256//100+1)*4=12 batches, extra 56
+    assert S.shape == (1156, 768) and rel_err(S.cpu(), S_ref) < NET_RTOL   # (256//100+1)*4=12 batches, extra 56
     sv = _lib.spectrum(S).cpu()
     ref64 = odim.spectrum_f64(S.cpu())
     keep = ref64 > 2e-5 * ref64[0]
@@ -420,7 +422,7 @@ def test_vp_score_matrix_and_spectrum_vs_oracle(golden):
     x = torch.from_numpy(z["val_images"][2])
     sde_c, sde_h = osde.VPSDE(0.1, 20., 1000), sde_lib.VPSDE(0.1, 20., 1000)
     S, S_ref = _pipeline_pair(mutils.get_score_fn(sde_h, model), osde.get_score_fn(sde_c, ref_model), sde_h, sde_c, x, 100, 1e-3)
-    assert S.shape == (1156, 768) and rel_err(S.cpu(), S_ref) < 5e-5
+    assert S.shape == (1156, 768) and rel_err(S.cpu(), S_ref) < NET_RTOL
     sv = _lib.spectrum(S).cpu()
     ref64 = odim.spectrum_f64(S.cpu())
     keep = ref64 > 2e-5 * ref64[0]
@@ -474,7 +476,7 @@ def test_conditional_manifold_dimension_vs_reference(golden):
     S_ref = odim.score_matrix(osde.get_score_fn(sde_c, ref_model), sde_c, x0, B, t_lvl,
                               noise=torch.cat([nz, pad]).reshape(num_batches, B, *x0.shape))
     S = builder.build(x0.to(DEV), B, t=t_lvl, noise=nz.to(DEV))
-    assert rel_err(S.cpu(), S_ref) < 5e-5
+    assert rel_err(S.cpu(), S_ref) < NET_RTOL
     bound = float(torch.linalg.matrix_norm(S.cpu().double() - S_ref.double(), ord=2))
     sv = _lib.spectrum(S).cpu().double()
     assert float((sv - odim.spectrum_f64(S_ref)).abs().max()) <= 1.5 * bound + 1e-7 * float(sv[0])
