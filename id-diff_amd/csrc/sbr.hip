@@ -1183,7 +1183,10 @@ int sbr_chase(int D, double *diag, double *offd, double *scratch, hipStream_t st
   double *AB = scratch;
   double *vs = AB + (int64_t)(D + PAD) * LDB;
   double *scal = scratch + sbr_scratch_doubles(D) - 16;     // [0] residual^2, [1] ||G||_F^2, [2] abort word
-  if (!option(OPT_CHASE_WAVEFRONT)) {
+  // the systolic form needs all its ceil((D + PAD - 2) / BW) workgroups resident at once (they wait on each other): with
+  // 256 threads and ~100 registers each the chip holds 8 per CU; stay well inside that and chase wavefront by wavefront beyond
+  constexpr int MAX_SYSTOLIC_NODES = 1024;                   // D <= 32768
+  if (!option(OPT_CHASE_WAVEFRONT) && ceil_div(D + PAD - 2, BW) <= MAX_SYSTOLIC_NODES) {
     SysArgs a;
     a.AB = AB; a.mbox = reinterpret_cast<unsigned long long *>(vs); a.diag = diag; a.offd = offd;
     a.abort_flag = reinterpret_cast<int *>(scal + 2); a.D = D; a.Dp = D + PAD;
