@@ -370,8 +370,10 @@ def spectrum_workspace_bytes(P, M, D):
     return lib().idiff_spectrum_workspace_bytes(P, M, D)
 
 
-def spectrum(S, workspace=None, return_eig=False):
-    """Singular values (descending, fp32) of the column-centred matrices S [P, M, D] or [M, D]."""
+def spectrum(S, workspace=None, return_eig=False, full=False):
+    """Singular values (descending, fp32, min(M, D) of them as torch.linalg.svd gives) of the column-centred matrices
+    S [P, M, D] or [M, D].  ``full=True`` keeps all D values of the Gram route (the drivers gather fixed-width rows and cut
+    each point's list to its own min(M, D) on the host)."""
     _dev(S, "scores")
     squeeze = S.ndim == 2
     if squeeze:
@@ -387,6 +389,8 @@ def spectrum(S, workspace=None, return_eig=False):
     _check(lib().idiff_spectrum_f32(S.data_ptr(), P, M, D, workspace.data_ptr(),
                                     workspace.numel() * workspace.element_size(), sv.data_ptr(), _ptr(eig), _stream()),
            "idiff_spectrum_f32")
+    if M < D and not full:
+        sv = sv[:, :M].contiguous()           # the Gram route yields D values, the last D - M of them zeros up to rounding
     if squeeze:
         sv = sv[0]
         eig = eig[0] if eig is not None else None

@@ -952,7 +952,8 @@ IDIFF_API int64_t idiff_spectrum_workspace_bytes(int P, int M, int D) {
 IDIFF_API int idiff_spectrum_f32(const float *S, int P, int M, int D, void *workspace, int64_t workspace_bytes, float *sv,
                                  double *eig_out, void *stream) {
   if (!S || !workspace || !sv || P <= 0 || M <= 0 || D <= 0) return fail("spectrum: bad arguments");
-  if (M < D) return fail("spectrum: needs M >= D (got %d x %d)", M, D);
+  // M < D is fine: the Gram matrix is D x D either way and has D - min(M - 1, D) zero eigenvalues; the caller keeps the
+  // leading min(M, D) singular values, which is what torch.linalg.svd returns (dim_reduction.py:197)
   if (P > 65535) return fail("spectrum: P too large");
   if (workspace_bytes < idiff_spectrum_workspace_bytes(P, M, D)) return fail("spectrum: workspace too small");
   if (((uintptr_t)workspace & 7) != 0) return fail("spectrum: workspace must be 8-byte aligned");

@@ -119,13 +119,13 @@ class SpectrumPipeline:
     def _launch(self, S, ready):
         self.side.wait_event(ready)                      # S is complete on the producing stream
         with torch.cuda.stream(self.side):
-            sv = _lib.spectrum(S)
+            sv = _lib.spectrum(S, full=True)
         S.record_stream(self.side)                       # keep S alive until the side stream is done with it
         self.pending.append(sv)
 
     def submit(self, S):
         if self.side is None:
-            self.pending.append(_lib.spectrum(S))
+            self.pending.append(_lib.spectrum(S, full=True))
             return
         ready = torch.cuda.Event()
         ready.record()
@@ -264,14 +264,6 @@ def get_manifold_dimension(config, name=None, return_svd=False):
             with open(os.path.join(save_path, f'{name}.pkl'), 'wb') as f:
                 pickle.dump(info, f)
         return None
-    for x, batchsize in points:          # refuse before any GPU work, not in the middle of the run
-        rows = batching(tuple(x.shape), batchsize)[2]
-        if rows < x.numel():
-            raise RuntimeError(
-                f"a loader batch of {batchsize} gives a {rows} x {x.numel()} score matrix: the Gram-matrix spectrum "
-                f"kernel needs rows >= columns (use a training batch size that keeps (ambient // B + 1) * 4 * B >= D, "
-                f"and drop_last for a short final batch)")
-
     builder = ScoreMatrixBuilder(score_fn, pl_module.sde, pl_module.sampling_eps, device,
                                  config.get('dim_estimation.inflight_rows', None))
     def point_seed(p):
@@ -314,14 +306,12 @@ def get_manifold_dimension(config, name=None, return_svd=False):
                 x, batchsize = points[p]
                 pipe.submit(builder.build(x.to(device), batchsize, seed=point_seed(p)))
             local = pipe.results()
-    if local:
-        n_sv = local[-1].numel()
-    if n_sv is None:  # a rank without points still takes part in the exchange
-        x, batchsize = points[0]
-        n_sv = min(batching(tuple(x.shape), batchsize)[2], x.numel())
+    n_sv = points[0][0].numel()              # fixed-width rows for the exchange (a rank without points takes part too)
     local = torch.stack(local) if local else torch.empty(0, n_sv, device=device)
     spectra = parallel.gather_spectra(local, len(points), n_sv, device)
-    info = {'singular_values': [s.tolist() for s in checked_spectra(spectra)]}
+    # torch.linalg.svd returns min(M, D) values per point (dim_reduction.py:197): a short loader batch gives a shorter list
+    keep = [min(batching(tuple(x.shape), b)[2], x.numel()) for x, b in points]
+    info = {'singular_values': [s[:k].tolist() for s, k in zip(checked_spectra(spectra), keep)]}
     if return_svd:
         return info
     if rank == 0:
@@ -375,10 +365,10 @@ def conditional_spectra(builder, loader, num_datapoints, seed=42, levels=None, n
                                           seed=seed + 1000003 * (p + 1) + 7919 * level))
             local = pipe.results()
         if points:
-            x0, _, b0 = points[0]
-            n_sv = min(batching(tuple(x0.shape), b0)[2], x0.numel())
+            n_sv = points[0][0].numel()
             local = torch.stack(local) if local else torch.empty(0, n_sv, device=device)
             spectra = checked_spectra(parallel.gather_spectra(local, len(points), n_sv, device))
+            spectra = [s[:min(batching(tuple(x.shape), b)[2], x.numel())] for s, (x, _, b) in zip(spectra, points)]
         else:
             spectra = torch.empty(0, 0)
         out.append({'level': level, 't': float(t_slice),

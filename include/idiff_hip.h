@@ -202,8 +202,8 @@ int idiff_resample2x_nhwc_f32(const float *x, float *y, int B, int H, int W, int
 /* ------------------------------------------------------------------ spectrum of the centred score matrix */
 
 /* Replaces `scores - scores.mean(0)` + `torch.linalg.svd(...)` of dim_reduction.py:193-198 for a batch of P
- * score matrices S[p] (M x D fp32, row-major, contiguous): singular values, descending, min(M, D) of them
- * (M >= D required).  Method: fp64 column means -> fp64 Gram of the centred columns on v_mfma_f64_16x16x4 ->
+ * score matrices S[p] (M x D fp32, row-major, contiguous): D singular values per matrix, descending; for M < D the
+ * reference's min(M, D) values are the leading M of them (the rest are zeros up to rounding).  Method: fp64 column means -> fp64 Gram of the centred columns on v_mfma_f64_16x16x4 ->
  * tridiagonalisation (fp64, idiff_symtridiag_f64) -> Sturm bisection -> sqrt.  Products of fp32 inputs are exact in
  * fp64, so the squared condition number costs nothing at the 1e-4 tolerance.
  * workspace: idiff_spectrum_workspace_bytes(P, M, D) bytes; sv: [P, D] fp32.

@@ -236,9 +236,21 @@ def test_stage_exports():
     np.testing.assert_allclose(eig.cpu().numpy()[0], ref.numpy(), rtol=1e-9, atol=1e-9 * float(ref[-1]))
 
 
+def test_fewer_rows_than_columns():
+    """torch.linalg.svd returns min(M, D) values (dim_reduction.py:197 never checks the shape): a short last loader batch
+    must not fail mid-run.  Both solver paths (D <= 128 in LDS, two-stage)."""
+    for M, D in ((3, 5), (40, 100), (150, 260)):
+        S = torch.randn(M, D, generator=torch.Generator().manual_seed(M)) + 2.0
+        sv = _lib.spectrum(S.to(DEV)).cpu()
+        Sd = S.double()
+        exact = torch.linalg.svdvals(Sd - Sd.mean(0, keepdim=True))
+        assert sv.shape == (M,)
+        # the centred matrix has rank M - 1: its last singular value is rounding noise in every implementation
+        np.testing.assert_allclose(sv.numpy()[:-1], exact.numpy()[:-1], rtol=2e-6)
+        assert float(sv[-1]) <= 2e-6 * float(exact[0])
+
+
 def test_errors():
-    with pytest.raises(RuntimeError, match="M >= D"):
-        _lib.spectrum(torch.zeros(3, 5, device=DEV))
     with pytest.raises(RuntimeError, match="no CPU path"):
         _lib.spectrum(torch.zeros(5, 3))
 
