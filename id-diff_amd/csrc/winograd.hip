@@ -44,6 +44,7 @@
 //   (29.8k of 131k cycles per workgroup at Cin = 128).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -63,6 +64,7 @@ constexpr int STAGE_FLOATS = V_FLOATS;            // U never touches LDS
 constexpr int TAIL_FLOATS = 4 * WG_TILES * 2 * 64;     // the tail's exchange: [4 rows][tiles][2][64 cout]
 constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(2 * STAGE_FLOATS > TAIL_FLOATS ? 2 * STAGE_FLOATS : TAIL_FLOATS);   // 64 KB
 constexpr int64_t X_LIMIT = 0xFFFF0000ll;          // one buffer descriptor, with room for the invalid-pixel bias
+constexpr int PEEL_MIN_WORKGROUPS = 4 * 512;      // four rounds of 2 workgroups on each of 256 CUs
 constexpr uint32_t INVALID_PIXEL = 0xFFFF8000u;    // beyond any valid extent (the scalar step offset is not range-checked)
 
 struct WinoParams {
@@ -70,9 +72,10 @@ struct WinoParams {
   const float *u;
   float *out;
   int B, H, W, Cin, Cout;
-  int tiles_x, tiles_per_img, total_tiles;
+  int tiles_x, tiles_y, tiles_per_img, total_tiles;
+  int tx_shift, tpi_shift;        // log2 of tiles_x / tiles_per_img when both are powers of two, else -1 (division)
   int tiles_m, tiles_n, ngroup;   // ngroup: output-channel tiles scheduled together (tile_n innermost inside a group)
-  uint32_t x_bytes, u_bytes;
+  uint32_t x_bytes, u_bytes, out_bytes, res_bytes;
   idiff_epilogue ep;
   int has_ep;
 };
@@ -80,6 +83,23 @@ struct WinoParams {
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+// tile index -> (image, tile row, tile column); the maps of the score networks are powers of two, where this is two
+// shifts and two masks instead of two ~20-instruction integer divisions
+__device__ __forceinline__ void split_tile(const WinoParams &p, int T, int &img, int &ty, int &tx) {
+  if (p.tx_shift >= 0) {
+    img = T >> p.tpi_shift;
+    const int rem = T & (p.tiles_per_img - 1);
+    ty = rem >> p.tx_shift; tx = rem & (p.tiles_x - 1);
+  } else {
+    img = T / p.tiles_per_img;
+    const int rem = T - img * p.tiles_per_img;
+    ty = rem / p.tiles_x; tx = rem - ty * p.tiles_x;
+  }
+}
+
+// PEEL: step 0 is peeled and its MFMAs take C = 0 as an inline constant, so no accumulator is initialised (1-3 % on the
+// large maps); launches of only a few rounds of workgroups (the 4x4 maps) measured 7 % faster with the plain loop.
+template <bool PEEL>
 __global__ void __launch_bounds__(THREADS, 2)   // two waves per SIMD (256 VGPRs): two 256-thread workgroups per CU
 winograd_kernel(const WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -115,8 +135,8 @@ winograd_kernel(const WinoParams p) {
     const int T = tile0 + tl;
     const bool tv = T < p.total_tiles;
     const int TT = tv ? T : 0;
-    const int img = TT / p.tiles_per_img, rem = TT - img * p.tiles_per_img;
-    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    int img, ty, tx;
+    split_tile(p, TT, img, ty, tx);
     const int y = 2 * ty - 1 + r, x0 = 2 * tx - 1;
     const bool yok = tv && y >= 0 && y < p.H;
 #pragma unroll
@@ -164,11 +184,8 @@ winograd_kernel(const WinoParams p) {
     for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(Vd + j * 4 * V_SLOT) = c[j];
   };
 
-  floatx16 acc[8];   // [j][channel half]
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  floatx16 acc[8];   // [j][channel half]; PEEL: first written by the MFMAs of step 0 (the 2 x 128 v_mov_b32 of an explicit
+                     // initialisation were 11 % of a wave's non-MFMA VALU work)
 
   const int fr = lane & 31, fh = lane >> 5;
   const int frag = fr * KC + 4 * (fh ^ ((fr >> 3) & 1));
@@ -179,14 +196,20 @@ winograd_kernel(const WinoParams p) {
     bfr[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[j], slab, 0));
     bfr[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[j] + 32 * 32, slab, 0));
   };
-  auto compute = [&](int buf, int j0, int s) {
+  auto compute = [&](int buf, int j0, int s, auto first) {
     const float *S = lds + buf * STAGE_FLOATS;
 #pragma unroll
     for (int j = j0; j < j0 + 2; ++j) {
       const float4 a = *reinterpret_cast<const float4 *>(S + a_frag + 4 * j * V_SLOT);
       const float4 b0 = bfr[j][0], b1 = bfr[j][1];
-      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[2 * j], 0, 0, 0);
-      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[2 * j + 1], 0, 0, 0);
+      if constexpr (decltype(first)::value) {
+        const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, zero, 0, 0, 0);
+        acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, zero, 0, 0, 0);
+      } else {
+        acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[2 * j], 0, 0, 0);
+        acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[2 * j + 1], 0, 0, 0);
+      }
       acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[2 * j], 0, 0, 0);
       acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[2 * j + 1], 0, 0, 0);
       acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[2 * j], 0, 0, 0);
@@ -198,6 +221,21 @@ winograd_kernel(const WinoParams p) {
       load_b(j, min(s + 1, nsteps - 1));
     }
   };
+  auto step = [&](int s, auto first) {
+    const int buf = s & 1;
+    if (early) {
+      if (s + 1 < nsteps) stage(buf ^ 1);   // loaded one step ago
+      if (s + 2 < nsteps) fetch();
+    }
+    compute(buf, 0, s, first);
+    __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of the two halves from being hoisted together
+    compute(buf, 2, s, first);
+    if (!early) {
+      if (s + 1 < nsteps) stage(buf ^ 1);
+      if (s + 2 < nsteps) fetch();
+    }
+    __syncthreads();
+  };
 
 #pragma unroll
   for (int j = 0; j < 4; ++j) load_b(j, 0);
@@ -206,62 +244,67 @@ winograd_kernel(const WinoParams p) {
   if (nsteps > 1) fetch();
   __syncthreads();
 
-  for (int s = 0; s < nsteps; ++s) {
-    const int buf = s & 1;
-    if (early) {
-      if (s + 1 < nsteps) stage(buf ^ 1);   // loaded one step ago
-      if (s + 2 < nsteps) fetch();
-    }
-    compute(buf, 0, s);
-    __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of the two halves from being hoisted together
-    compute(buf, 2, s);
-    if (!early) {
-      if (s + 1 < nsteps) stage(buf ^ 1);
-      if (s + 2 < nsteps) fetch();
-    }
-    __syncthreads();
+  if constexpr (PEEL) {
+    step(0, std::true_type());
+    for (int s = 1; s < nsteps; ++s) step(s, std::false_type());
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int s = 0; s < nsteps; ++s) step(s, std::false_type());
   }
 
   // ---------------------------------------------------------------- tail
-  // This thread finishes 4 channels (n .. n+3) of tiles 2g and 2g+1: output pixels (2ty + a, 2tx + b).  Their addresses
-  // and every epilogue operand that comes from memory (bias, per-sample bias and scale, the eight 16-byte residual
-  // pieces) are requested BEFORE the transform-domain exchange, so their latency hides under it (the residual read
+  // This thread finishes 4 channels (n .. n+3) of tiles 2g and 2g+1: output pixels (2ty + a, 2tx + b).  Everything here
+  // is VALU work that no MFMA hides (a wave's non-MFMA VALU instructions were split about evenly between the K loop and
+  // prologue + tail at Cin = 256), so the tail is written to issue as few of them as it can: 32-bit byte offsets into
+  // buffer descriptors of `out` and `residual` (one VGPR per tile; the four pixels of a tile differ by wave-uniform
+  // amounts that ride in the scalar offset), bias + per-sample bias and out_scale x per-sample scale folded once per
+  // tile, an out-of-range offset instead of a predicate for tiles beyond the end.  Every epilogue operand that comes
+  // from memory is requested BEFORE the transform-domain exchange, so its latency hides under it (the residual read
   // issued at its point of use cost 0.3 ms of a 3.1 ms launch).
   const idiff_epilogue &ep = p.ep;
-  const bool want_stats = p.has_ep && ep.colstats != nullptr;
+  const bool has_ep = p.has_ep != 0;
+  const bool want_stats = has_ep && ep.colstats != nullptr;
   const int cq = tid & 15, g = tid >> 4;
   const int n = n0 + 4 * cq;
-  const bool per_image = p.ep.rows_per_group == p.H * p.W;   // the usual per-sample bias / scale: group = image
-  const int tiles_y = p.tiles_per_img / p.tiles_x;
-  int64_t m_of[2][4];          // [tile][2a + b]
-  bool t_ok[2];
-  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), rb[2], res[2][4];
-  float rs[2] = {1.f, 1.f};
+  const bool per_image = ep.rows_per_group == p.H * p.W;   // the usual per-sample bias / scale: group = image
+  const bool grouped = has_ep && !per_image && (ep.rowbias || ep.rowscale);   // any other row group: cold path below
+  const bool has_res = has_ep && ep.residual != nullptr;
+  const bool scaled = has_ep && (ep.out_scale != 1.f || ep.rowscale != nullptr);
+  const int act = has_ep ? ep.act : (int)IDIFF_ACT_NONE;
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)ep.residual, 0, (int)p.res_bytes, 0x00020000);
+  const int ld_res = (int)ep.ld_residual;
+  int m00[2];                  // row of `out` of pixel (0, 0) of the tile
+  uint32_t ooff[2];            // its byte offset (+ this thread's channels), INVALID_PIXEL beyond the last tile
+  float4 badd[2], res[2][4];
+  float sc[2];
   {
-    int T = tile0 + 2 * g;
-    int img = T / p.tiles_per_img;
-    int rem = T - img * p.tiles_per_img;
-    int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-    if (p.has_ep && ep.bias) bias = *reinterpret_cast<const float4 *>(ep.bias + n);
+    int T = tile0 + 2 * g, img, ty, tx;
+    split_tile(p, T, img, ty, tx);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_ep && ep.bias) bias = *reinterpret_cast<const float4 *>(ep.bias + n);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      t_ok[t] = T < p.total_tiles;
-      const int64_t m00 = ((int64_t)img * p.H + 2 * ty) * p.W + 2 * tx;
+      const bool ok = T < p.total_tiles;
+      m00[t] = (img * p.H + 2 * ty) * p.W + 2 * tx;
+      ooff[t] = ok ? ((uint32_t)m00[t] * (uint32_t)p.Cout + (uint32_t)n) * 4u : INVALID_PIXEL;
+      badd[t] = bias;
+      sc[t] = has_ep ? ep.out_scale : 1.f;
+      if (has_ep && per_image && ok) {
+        if (ep.rowbias) badd[t] = f4add(bias, *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)img * ep.ld_rowbias + n));
+        if (ep.rowscale) sc[t] *= ep.rowscale[img];
+      }
+      if (has_res) {
+        const uint32_t roff = ok ? ((uint32_t)m00[t] * (uint32_t)ld_res + (uint32_t)n) * 4u : INVALID_PIXEL;
 #pragma unroll
-      for (int ab = 0; ab < 4; ++ab) m_of[t][ab] = m00 + (ab >> 1) * p.W + (ab & 1);
-      rb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t_ok[t] && p.has_ep) {
-        if (per_image) {
-          if (ep.rowbias) rb[t] = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)img * ep.ld_rowbias + n);
-          if (ep.rowscale) rs[t] = ep.rowscale[img];
-        }
-        if (ep.residual) {
-#pragma unroll
-          for (int ab = 0; ab < 4; ++ab) res[t][ab] = *reinterpret_cast<const float4 *>(ep.residual + m_of[t][ab] * ep.ld_residual + n);
-        }
+        for (int ab = 0; ab < 4; ++ab)
+          res[t][ab] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)roff, ((ab >> 1) * p.W + (ab & 1)) * ld_res * 4, 0));
       }
       ++T;
-      if (++tx == p.tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++img; } }
+      if (++tx == p.tiles_x) { tx = 0; if (++ty == p.tiles_y) { ty = 0; ++img; } }
     }
   }
 
@@ -290,32 +333,39 @@ winograd_kernel(const WinoParams p) {
       const float4 z1 = *reinterpret_cast<const float4 *>(zr + 1 * WG_TILES * 2 * 64);
       const float4 z2 = *reinterpret_cast<const float4 *>(zr + 2 * WG_TILES * 2 * 64);
       const float4 z3 = *reinterpret_cast<const float4 *>(zr + 3 * WG_TILES * 2 * 64);
-      if (!t_ok[t]) continue;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const int64_t m = m_of[t][2 * a + b];
         float v[4];
         if (a == 0) { v[0] = z0.x + z1.x + z2.x; v[1] = z0.y + z1.y + z2.y; v[2] = z0.z + z1.z + z2.z; v[3] = z0.w + z1.w + z2.w; }
         else { v[0] = z1.x - z2.x - z3.x; v[1] = z1.y - z2.y - z3.y; v[2] = z1.z - z2.z - z3.z; v[3] = z1.w - z2.w - z3.w; }
-        v[0] += bias.x; v[1] += bias.y; v[2] += bias.z; v[3] += bias.w;
-        if (p.has_ep) {
-          float4 rbv = rb[t];
-          float rsv = rs[t];
-          if (!per_image) {
-            const int64_t grp = m / ep.rows_per_group;
-            rbv = ep.rowbias ? *reinterpret_cast<const float4 *>(ep.rowbias + grp * ep.ld_rowbias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rsv = ep.rowscale ? ep.rowscale[grp] : 1.f;
+        v[0] += badd[t].x; v[1] += badd[t].y; v[2] += badd[t].z; v[3] += badd[t].w;
+        float rsv = 1.f;
+        if (grouped) {
+          const int64_t grp = ((int64_t)m00[t] + a * p.W + b) / ep.rows_per_group;
+          if (ep.rowbias) {
+            const float4 rbv = *reinterpret_cast<const float4 *>(ep.rowbias + grp * ep.ld_rowbias + n);
+            v[0] += rbv.x; v[1] += rbv.y; v[2] += rbv.z; v[3] += rbv.w;
           }
-          v[0] = idiff::act_apply(v[0] + rbv.x, ep.act); v[1] = idiff::act_apply(v[1] + rbv.y, ep.act);
-          v[2] = idiff::act_apply(v[2] + rbv.z, ep.act); v[3] = idiff::act_apply(v[3] + rbv.w, ep.act);
-          if (ep.residual) {
-            const float4 r4 = res[t][2 * a + b];
-            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] *= ep.out_scale; v[e] *= rsv; }
+          if (ep.rowscale) rsv = ep.rowscale[grp];
         }
-        *reinterpret_cast<float4 *>(p.out + m * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (act != IDIFF_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = idiff::act_apply(v[e], act);
+        }
+        if (has_res) {
+          const float4 r4 = res[t][2 * a + b];
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        if (scaled) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= sc[t];
+          if (grouped) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= rsv;
+          }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, make_float4(v[0], v[1], v[2], v[3])), rO, (int)ooff[t],
+                                               (a * p.W + b) * p.Cout * 4, 0);
         if (want_stats) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { s1[e] += (double)v[e]; s2[e] += (double)v[e] * (double)v[e]; }
@@ -395,7 +445,7 @@ IDIFF_API int idiff_conv2d_winograd_ok(int B, int H, int W, int Cin, int Cout) {
 
 IDIFF_API int idiff_conv2d_winograd_colstats_split(int B, int H, int W, int Cin, int Cout) {
   if (!idiff_conv2d_winograd_ok(B, H, W, Cin, Cout) || idiff::option(idiff::OPT_NO_COLSTATS)) return 0;
-  if ((int64_t)B * H * W * Cin * 4 >= X_LIMIT) return 0;
+  if ((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) * 4 >= X_LIMIT) return 0;
   const int tpi = (H / 2) * (W / 2);
   return tpi % WG_TILES == 0 ? tpi / WG_TILES : 0;
 }
@@ -419,9 +469,15 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
   if (!geometry_ok(B, H, W, Cin, Cout))
     return fail("conv2d_winograd: geometry B=%d H=%d W=%d Cin=%d Cout=%d not supported (ask idiff_conv2d_winograd_ok)", B, H, W, Cin, Cout);
   if (!x || !u || !out) return fail("conv2d_winograd: null pointer");
-  if (((uintptr_t)x & 15) || ((uintptr_t)u & 15)) return fail("conv2d_winograd: x and u must be 16-byte aligned");
-  const int64_t x_bytes = (int64_t)B * H * W * Cin * 4;
-  if (x_bytes >= X_LIMIT) {
+  if (((uintptr_t)x & 15) || ((uintptr_t)u & 15) || ((uintptr_t)out & 15)) return fail("conv2d_winograd: x, u and out must be 16-byte aligned");
+  if (ep && ep->residual && (((uintptr_t)ep->residual & 15) || ep->ld_residual % 4))
+    return fail("conv2d_winograd: residual must be 16-byte aligned with a row pitch that is a multiple of 4");
+  const int64_t x_bytes = (int64_t)B * H * W * Cin * 4, out_bytes = (int64_t)B * H * W * Cout * 4;
+  if (ep && ep->residual && (ep->ld_residual < Cout || ep->ld_residual > 0x7fffffff / 4))
+    return fail("conv2d_winograd: ld_residual %lld is not a row pitch for %d channels", (long long)ep->ld_residual, Cout);
+  const int64_t res_bytes = (ep && ep->residual) ? (int64_t)B * H * W * ep->ld_residual * 4 : 0;
+  // the kernel addresses x, out and residual through one buffer descriptor each (32-bit byte offsets)
+  if (x_bytes >= X_LIMIT || out_bytes >= X_LIMIT || res_bytes >= X_LIMIT) {
     if (ep && ep->colstats) return fail("conv2d_winograd: colstats is not available for inputs beyond one buffer descriptor");
     if (B < 2) return fail("conv2d_winograd: a single image exceeds one buffer descriptor");
     const int rpg = (ep && ep->rows_per_group > 0) ? ep->rows_per_group : 1;
@@ -442,7 +498,11 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
   }
   WinoParams p = {};
   p.x = x; p.u = u; p.out = out; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-  p.tiles_x = W / 2; p.tiles_per_img = (H / 2) * (W / 2); p.total_tiles = B * p.tiles_per_img;
+  p.tiles_x = W / 2; p.tiles_y = H / 2; p.tiles_per_img = (H / 2) * (W / 2); p.total_tiles = B * p.tiles_per_img;
+  p.tx_shift = p.tpi_shift = -1;
+  if ((p.tiles_x & (p.tiles_x - 1)) == 0 && (p.tiles_per_img & (p.tiles_per_img - 1)) == 0) {
+    p.tx_shift = __builtin_ctz((unsigned)p.tiles_x); p.tpi_shift = __builtin_ctz((unsigned)p.tiles_per_img);
+  }
   p.tiles_m = ceil_div(p.total_tiles, WG_TILES); p.tiles_n = Cout / WG_COUT;
   {
     // two output-channel tiles per scheduling group: the workgroups of an XCD then stream two filter slabs instead of
@@ -451,6 +511,7 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
     p.ngroup = (want > 0 && p.tiles_n % want == 0) ? want : ((p.tiles_n > 2 && p.tiles_n % 2 == 0) ? 2 : p.tiles_n);
   }
   p.x_bytes = (uint32_t)x_bytes; p.u_bytes = (uint32_t)((int64_t)16 * Cin * Cout * 4);
+  p.out_bytes = (uint32_t)out_bytes; p.res_bytes = (uint32_t)res_bytes;
   if (ep) {
     p.ep = *ep; p.has_ep = 1;
     if (p.ep.rows_per_group <= 0) p.ep.rows_per_group = 1;
@@ -459,11 +520,15 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
   } else {
     p.has_ep = 0; p.ep.rows_per_group = 1; p.ep.out_scale = 1.f;
   }
+  const void *fns[2] = {reinterpret_cast<const void *>(winograd_kernel<false>), reinterpret_cast<const void *>(winograd_kernel<true>)};
   {
     static AttrGuard guard;
-    const void *fn = reinterpret_cast<const void *>(winograd_kernel);
-    if (int rc = set_dynamic_lds_once(guard, &fn, 1, (int)LDS_BYTES, "conv2d_winograd")) return rc;
+    if (int rc = set_dynamic_lds_once(guard, fns, 2, (int)LDS_BYTES, "conv2d_winograd")) return rc;
   }
-  hipLaunchKernelGGL(winograd_kernel, dim3(p.tiles_m * p.tiles_n), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, p);
+  const int nwg = p.tiles_m * p.tiles_n;
+  if (nwg >= PEEL_MIN_WORKGROUPS)
+    hipLaunchKernelGGL(winograd_kernel<true>, dim3(nwg), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(winograd_kernel<false>, dim3(nwg), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, p);
   return launch_status("conv2d_winograd");
 }
