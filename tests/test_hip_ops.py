@@ -232,6 +232,51 @@ def test_conv2d_winograd_splits_inputs_beyond_one_descriptor():
     torch.cuda.empty_cache()
 
 
+def test_conv2d_winograd_row_groups_and_residual_pitch():
+    """Epilogue row groups that are not whole images (rows_per_group = one map row) and a residual that is a column
+    slice of a wider tensor (ld_residual > Cout): the tail's cold path and its second buffer descriptor."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout = 3, 6, 8, 16, 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    rowb = torch.randn(B * H, Cout, generator=g)             # one bias row per map row
+    rsc = torch.rand(B * H, generator=g) + 0.5
+    wide = torch.randn(B, H, W, Cout + 32, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    u = _lib.winograd_pack(w.permute(0, 2, 3, 1).contiguous().to(DEV), Cin, Cout)
+    wided = wide.to(DEV)
+    out = torch.empty(B, H, W, Cout, device=DEV)
+    _lib.conv2d_winograd(xd, u, out, B, H, W, Cin, Cout,
+                         epilogue=_lib.make_epilogue(bias=b.to(DEV), rowbias=rowb.to(DEV), rows_per_group=W, act="lrelu",
+                                                     residual=wided, ld_residual=Cout + 32, out_scale=1.25, rowscale=rsc.to(DEV)))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)        # [B, H, W, Cout]
+    ref = F.leaky_relu(ref + rowb.double().view(B, H, 1, Cout), 0.2) + wide.double()[..., :Cout]
+    ref = ref * 1.25 * rsc.double().view(B, H, 1, 1)
+    assert rel_err(out.cpu(), ref) < 3e-6
+
+
+def test_conv2d_winograd_splits_outputs_beyond_one_descriptor():
+    """The output (and a residual of the same extent) passes 4 GB while the input does not: the host cuts the batch on
+    that extent too (the kernel stores through a 32-bit buffer descriptor)."""
+    g = torch.Generator(device=DEV).manual_seed(2)
+    B, H, Cin, Cout = 4200, 32, 8, 256                       # out = 4.4 GB, x = 0.14 GB
+    x = torch.randn(B, H * H, Cin, device=DEV, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device=DEV, generator=g) / (9 * Cin) ** 0.5
+    u = _lib.winograd_pack(w, Cin, Cout)
+    res = torch.randn(B, H * H, Cout, device=DEV, generator=g)
+    out = torch.full((B, H * H, Cout), float("nan"), device=DEV)
+    _lib.conv2d_winograd(x, u, out, B, H, H, Cin, Cout, epilogue=_lib.make_epilogue(residual=res, out_scale=0.5))
+    for b0 in (0, B // 2 - 1, B // 2, B - 1):
+        ref = torch.empty(1, H * H, Cout, device=DEV)
+        _lib.conv2d_winograd(x[b0:b0 + 1].contiguous(), u, ref, 1, H, H, Cin, Cout,
+                             epilogue=_lib.make_epilogue(residual=res[b0:b0 + 1].contiguous(), out_scale=0.5))
+        assert torch.equal(out[b0:b0 + 1], ref), b0
+    assert not bool(torch.isnan(out[::97]).any())
+    del x, out, res
+    torch.cuda.empty_cache()
+
+
 def test_conv2d_winograd_rejects_what_it_cannot_take():
     assert not _lib.conv2d_winograd_ok(2, 7, 8, 32, 64)      # odd height
     assert not _lib.conv2d_winograd_ok(2, 8, 8, 4, 64)       # Cin % 8
