@@ -25,6 +25,7 @@
 // Workgroup ids are remapped so that consecutive M-tiles (which share conv halo rows and the weight
 // panel) land on the same XCD's L2.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -51,6 +52,8 @@ struct IgemmParams {
   const float *A2;            // LINEAR, optional: columns K1.. of A live in a second matrix with the same row pitch
   int K1;                     // (the concatenation [A | A2] is never materialised); 0 = single source
   uint32_t a2_bytes;
+  uint32_t c_bytes, res_bytes;  // extents of one batch slice of C and of the residual; buf_ep = they fit a buffer descriptor
+  int buf_ep;
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -411,13 +414,7 @@ igemm_pipe_kernel(const IgemmParams p) {
       *reinterpret_cast<float4 *>(b_dst + (row_base + i * ROW_STEP) * LDS_PITCH + kc) = b_reg[i];
   };
 
-  floatx16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  floatx16 acc[TM][TN];   // first written by the MFMAs of k-tile 0, which take C = 0 as an inline constant: no TM*TN*16 v_mov_b32
 
   const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
   const int nkt = (p.K + BK - 1) / BK;
@@ -427,7 +424,7 @@ igemm_pipe_kernel(const IgemmParams p) {
   if (nkt > 1) fetch();
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
+  auto ktile = [&](int kt, auto first) {
     const int buf = DBUF ? (kt & 1) : 0;
     if (DBUF) {
       if (kt + 1 < nkt) stage(buf ^ 1);   // tile kt+1: loaded one iteration ago
@@ -446,7 +443,12 @@ igemm_pipe_kernel(const IgemmParams p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          if (decltype(first)::value && g == 0) {
+            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, zero, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
@@ -460,7 +462,9 @@ igemm_pipe_kernel(const IgemmParams p) {
       if (kt + 2 < nkt) fetch();
       __syncthreads();
     }
-  }
+  };
+  ktile(0, std::true_type());
+  for (int kt = 1; kt < nkt; ++kt) ktile(kt, std::false_type());
 
   float *Cb = p.C + (int64_t)batch * p.strideC;
   const idiff_epilogue &ep = p.ep;
@@ -469,7 +473,121 @@ igemm_pipe_kernel(const IgemmParams p) {
   // consumes this tensor then needs no pass of its own over HBM (idiff_epilogue.colstats)
   const bool want_stats = p.has_ep && ep.colstats != nullptr;
   double *red = reinterpret_cast<double *>(lds);   // [WARPS_M][BN][2]; operand staging is finished
-  if (p.vec_ep) {
+  if (p.vec_ep && p.buf_ep) {
+    // The form every contraction of the score networks takes.  As the vector form below (each wave turns its 32-row
+    // blocks through a private LDS patch and finishes runs of four columns with 16-byte accesses), with the address
+    // and predicate arithmetic taken out of the per-row work -- at K = 256 the epilogue's ~40 VALU instructions per row
+    // pass were a fifth of a wave's time next to 512 MFMAs: C and the residual are addressed through buffer descriptors
+    // (one 32-bit offset per thread + a wave-uniform row step; rows >= M fall outside the descriptor and columns >= N
+    // start from an out-of-range offset, so nothing is predicated), bias + per-group bias and the two scales are folded
+    // once per 32-row block when a block lies inside one row group (rows_per_group % 32 == 0).
+    constexpr int C4 = WTN / 4;
+    constexpr int RPP = 64 / C4;
+    constexpr int PASSES = 32 / RPP;
+    constexpr uint32_t OOB_BASE = 0xF0000000u;       // launch_pipe: extents < 0xE0000000, BM rows < 0x0FFFFFF0 bytes
+    float *tr = lds + (tid >> 6) * (32 * WTN);
+    const int c4 = lane % C4, r0 = lane / C4;
+    const int n = n0 + wn0 + c4 * 4;
+    const bool n_ok = n < p.N;
+    const bool has_ep = p.has_ep != 0;
+    const bool has_res = has_ep && ep.residual != nullptr;
+    const bool has_rb = has_ep && ep.rowbias != nullptr, has_rs = has_ep && ep.rowscale != nullptr;
+    const bool scaled = has_ep && (ep.out_scale != 1.f || has_rs);
+    const int act = has_ep ? ep.act : (int)IDIFF_ACT_NONE;
+    const bool block_groups = ep.rows_per_group % 32 == 0;   // a 32-row block never straddles a row group
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void *)Cb, 0, (int)p.c_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)ep.residual, 0, (int)p.res_bytes, 0x00020000);
+    const int mrow0 = m0 + wm0 + r0;
+    const uint32_t ldc_b = (uint32_t)p.ldc * 4u, ldr_b = (uint32_t)ep.ld_residual * 4u;
+    const uint32_t c_off = n_ok ? (uint32_t)mrow0 * ldc_b + (uint32_t)n * 4u : OOB_BASE;
+    const uint32_t r_off = n_ok ? (uint32_t)mrow0 * ldr_b + (uint32_t)n * 4u : OOB_BASE;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n_ok && has_ep && ep.bias) bias4 = *reinterpret_cast<const float4 *>(ep.bias + n);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      // the block's residual rows are requested before its accumulators go through the LDS patch: a read issued at its
+      // point of use is a dependent HBM round trip per row pass (the residual-fed K = 256 contractions ran at 105
+      // TFLOP/s against 123 for the same shape without one)
+      float4 resv[PASSES];
+      if (has_res) {
+#pragma unroll
+        for (int t = 0; t < PASSES; ++t)
+          resv[t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)(r_off + (uint32_t)(i * 32 + RPP * t) * ldr_b), 0, 0));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + row_l) * WTN + j * 32 + col_l] = acc[i][j][r];
+      float4 badd = bias4;
+      float sc = has_ep ? ep.out_scale : 1.f;
+      const int mblk = m0 + wm0 + i * 32;             // wave-uniform
+      if (block_groups && mblk < p.M && (has_rb || has_rs)) {
+        const int grp = mblk / ep.rows_per_group;
+        if (has_rb && n_ok) {
+          const float4 rb = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)grp * ep.ld_rowbias + n);
+          badd = make_float4(bias4.x + rb.x, bias4.y + rb.y, bias4.z + rb.z, bias4.w + rb.w);
+        }
+        if (has_rs) sc *= ep.rowscale[grp];
+      }
+#pragma unroll
+      for (int t = 0; t < PASSES; ++t) {
+        const int row = r0 + RPP * t;
+        const float4 a4 = *reinterpret_cast<const float4 *>(tr + row * WTN + c4 * 4);
+        const uint32_t step = (uint32_t)(i * 32 + RPP * t);
+        float v[4] = {a4.x + badd.x, a4.y + badd.y, a4.z + badd.z, a4.w + badd.w};
+        float rsv = 1.f;
+        if (!block_groups && (has_rb || has_rs)) {
+          const int m = mrow0 + (int)step;
+          if (m < p.M && n_ok) {
+            const int grp = m / ep.rows_per_group;
+            if (has_rb) {
+              const float4 rb = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)grp * ep.ld_rowbias + n);
+              v[0] += rb.x; v[1] += rb.y; v[2] += rb.z; v[3] += rb.w;
+            }
+            if (has_rs) rsv = ep.rowscale[grp];
+          }
+        }
+        if (act != IDIFF_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = idiff::act_apply(v[e], act);
+        }
+        if (has_res) {
+          const float4 rs = resv[t];
+          v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+        }
+        if (scaled) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= sc;
+          if (!block_groups && has_rs) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= rsv;
+          }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, make_float4(v[0], v[1], v[2], v[3])), rC,
+                                               (int)(c_off + step * ldc_b), 0, 0);
+        if (want_stats) {      // whole tiles only (idiff_gemm_colstats_split): every row is a row of C
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1[e] += (double)v[e]; s2[e] += (double)v[e] * (double)v[e]; }
+        }
+      }
+    }
+    if (want_stats) {
+#pragma unroll
+      for (int off = C4; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off, 64); s2[e] += __shfl_xor(s2[e], off, 64); }
+      __syncthreads();                               // every wave is done with its patch
+      if (lane < C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int slot = ((wave / WARPS_N) * BN + wn0 + c4 * 4 + e) * 2;
+          red[slot] = s1[e]; red[slot + 1] = s2[e];
+        }
+      }
+    }
+  } else if (p.vec_ep) {
+    // The same with 64-bit addresses, for C or residual extents beyond one buffer descriptor.
     // One dword per lane per store makes short-K contractions store-issue bound (a 128x128 tile is 256 wave-level
     // stores, ~100 cycles each through the CU's one address unit: 0.8 of the 1.24 ms of the K = 128 shortcut GEMMs).
     // Each wave turns its 32-row blocks through a private 8 KB LDS patch instead and finishes runs of four columns:
@@ -602,6 +720,13 @@ int launch_pipe(IgemmParams &p, int batch, hipStream_t st) {
                     (!p.has_ep || ((!e.bias || aligned16(e.bias)) && (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) &&
                                    (!e.residual || (aligned16(e.residual) && e.ld_residual % 4 == 0))));
     p.vec_ep = al && !idiff::option(idiff::OPT_SCALAR_EPILOGUE);
+    // 32-bit addressing of C and the residual (igemm_pipe_kernel's first epilogue form): extents below 0xE0000000 so that
+    // an out-of-range start stays out of range after the row steps of one tile are added
+    const int64_t c_bytes = ((int64_t)(p.M - 1) * p.ldc + p.N) * 4;
+    const int64_t res_bytes = (p.has_ep && e.residual) ? ((int64_t)(p.M - 1) * e.ld_residual + p.N) * 4 : 0;
+    const int64_t pitch = p.ldc > e.ld_residual ? p.ldc : e.ld_residual;
+    p.buf_ep = p.vec_ep && c_bytes < 0xE0000000ll && res_bytes < 0xE0000000ll && (int64_t)BM * pitch * 4 < 0x0FFFFFF0ll;
+    p.c_bytes = p.buf_ep ? (uint32_t)c_bytes : 0; p.res_bytes = p.buf_ep ? (uint32_t)res_bytes : 0;
   }
   dim3 grid(p.tiles_m * p.tiles_n, batch);
   hipLaunchKernelGGL(kern, grid, dim3(WARPS_M * WARPS_N * 64), lds_bytes, st, p);
