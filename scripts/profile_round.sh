@@ -15,6 +15,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/scripts/wino_shapes.py 2240 > $O/shapes_write.log 2>&1 || echo "write pass failed"
 python3 $R/scripts/parse_wino_traffic.py $O/shapes_fetch.log $O/fetch $O/write $O/${TAG}_wino_traffic.json > $O/traffic_summary.txt 2>&1 || echo "traffic parse failed"
 cat $O/traffic_summary.txt
+# bench.py only quotes a traffic table that carries the hash of the winograd.hip in the tree: put the fresh one where it looks
+[ -s $O/${TAG}_wino_traffic.json ] && cp $O/${TAG}_wino_traffic.json $R/profiles/${TAG}_wino_traffic.json
 echo "[2] PMC of the dominant kernel (16x16 256->256)"
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do
   n=$(echo $set | cut -d' ' -f1)
