@@ -144,6 +144,29 @@ def test_gemm_epilogue_terms():
     assert rel_err(y.cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,grp", [(300, 72, 64, 32), (130, 200, 96, 10), (517, 256, 256, 517)])
+def test_gemm_writes_only_its_block(M, N, K, grp):
+    """C is a column block of a wider, taller buffer and the residual a column block of another: the epilogue's buffer
+    descriptors must drop the rows and columns of the last tiles that lie outside [M, N] (M and N are not multiples of
+    the 128-row / 128-column tile) and touch nothing else; row groups that are and are not multiples of 32 rows."""
+    g = torch.Generator().manual_seed(M + N)
+    ldc, ldr = N + 24, N + 40
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ngrp = (M + grp - 1) // grp
+    rb, rsc = torch.randn(ngrp, N, generator=g), torch.rand(ngrp, generator=g) + 0.5
+    res = torch.randn(M, ldr, generator=g)
+    full = torch.full((M + 140, ldc), float("nan"), device=DEV)
+    _lib.gemm(a.to(DEV), w.to(DEV), out=full, M=M, N=N, K=K, lda=K, ldb=K, ldc=ldc,
+              epilogue=_lib.make_epilogue(bias=b.to(DEV), rowbias=rb.to(DEV), rows_per_group=grp, act="silu",
+                                          residual=res.to(DEV), ld_residual=ldr, out_scale=0.75, rowscale=rsc.to(DEV)))
+    rows = torch.arange(M) // grp
+    ref = (F.silu(a.double() @ w.double().T + b.double() + rb.double()[rows]) + res.double()[:, :N]) * 0.75 * rsc.double()[rows][:, None]
+    got = full.cpu()
+    assert rel_err(got[:M, :N], ref) < 2e-6
+    assert bool(torch.isnan(got[:M, N:]).all()) and bool(torch.isnan(got[M:]).all())
+
+
 def test_gemm_batched_strided():
     g = torch.Generator().manual_seed(6)
     B, HW, C = 3, 64, 16
