@@ -11,12 +11,23 @@ from id_diff_amd.models import utils as mutils
 def say(*a): print(*a, flush=True)
 dev = torch.device("cuda:0")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2240
-cfg = read_config('configs/dimension_estimation/paper/image_data/cifar_shaped/ncsnpp.py')
+which = sys.argv[2] if len(sys.argv) > 2 else "config3"
+cfg = read_config({"config3": 'configs/dimension_estimation/paper/image_data/cifar_shaped/ncsnpp.py',
+                   "config5": 'configs/dimension_estimation/extra_experiments/styleGAN/style_gan_64d_BeatGAN.py'}[which])
+cfg.model.allow_random_init = True
 torch.manual_seed(0)
-model = mutils.create_model(cfg).to(dev).eval()
+model = mutils.create_model(cfg)
+if which == "config5":     # the U-Net zero-initialises its output layers: give every all-zero parameter small values
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for prm in model.parameters():
+            if float(prm.abs().sum()) == 0.0:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.02)
+model = model.to(dev).eval()
 sde, eps = sde_lib.configure_sde(cfg)
 score_fn = mutils.get_score_fn(sde, model)
-x = torch.rand(rows, 3, 32, 32, device=dev); t = torch.full((rows,), 1e-5, device=dev)
+side = int(cfg.data.image_size)
+x = torch.rand(rows, 3, side, side, device=dev); t = torch.full((rows,), 1e-5, device=dev)
 with torch.no_grad():
     score_fn(x, t); score_fn(x, t); torch.cuda.synchronize()
 
