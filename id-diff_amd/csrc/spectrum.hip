@@ -133,7 +133,114 @@ gram_kernel(const float *__restrict__ S, const double *__restrict__ mean, int M,
       }
 }
 
-// diagonal tiles are computed in full by the kernel above (both triangles inside the tile come from the
+// The same product for matrices that give the chip enough tiles of 128 x 128 (D >= 1024, D % 4 == 0, one matrix): the
+// 64 x 64 kernel above converts and centres every operand element in every wave that reads it (12 VALU instructions
+// beside 4 MFMAs per k-step) and waits on unprefetched loads: 25 TFLOP/s, 0.31 of the fp64 MFMA peak.  Here a wave owns
+// 64 x 64 outputs as 4 x 4 MFMA tiles (16 MFMAs per 8 eight-byte LDS reads), the operands are converted to fp64 and
+// centred ONCE, by the thread that stages them (16-byte global loads, two stages of [16 rows][128 cols] fp64 per
+// operand = 64 KB of LDS, one barrier per stage), and the loads of stage t+2 are in flight while stage t multiplies.
+// Only tiles with tj >= ti are computed; diagonal tiles come out whole (and exactly symmetric: the products commute and
+// are summed in the same order), idiff_symmetrize_upper_f64's kernel mirrors the rest.
+// The reduction over rows runs in the same order and the same groups of four as in gram_kernel, so the two agree bit for
+// bit (checked by tests/test_hip_spectrum.py).
+constexpr int GBT = 128;      // tile edge
+constexpr int BROWS = 16;    // rows of S per stage
+constexpr size_t GRAM_BIG_LDS = (size_t)2 * 2 * BROWS * GBT * sizeof(double);   // 64 KB
+
+__global__ void __launch_bounds__(256, 2)
+gram_big_kernel(const float *__restrict__ S, const double *__restrict__ mean, int M, int D, int tiles,
+                double *__restrict__ G, int ti_first) {
+  extern __shared__ __attribute__((aligned(16))) double glds[];   // [stage][operand][BROWS][GBT]
+  int t = blockIdx.x, ti = ti_first;
+  while (t >= tiles - ti) { t -= tiles - ti; ++ti; }
+  const int tj = ti + t;
+  const int i0 = ti * GBT, j0 = tj * GBT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+  const int fl = lane & 15, fk = lane >> 4;
+
+  // staging map: thread -> 4 consecutive columns of rows sr and sr + 8 of both operands
+  const int sc = (tid & 31) * 4, sr = tid >> 5;
+  const bool ci_ok = i0 + sc < D, cj_ok = j0 + sc < D;          // D % 4 == 0: a run of four is inside or outside as a whole
+  double mi4[4] = {0.0, 0.0, 0.0, 0.0}, mj4[4] = {0.0, 0.0, 0.0, 0.0};
+  if (ci_ok) { for (int e = 0; e < 4; ++e) mi4[e] = mean[i0 + sc + e]; }
+  if (cj_ok) { for (int e = 0; e < 4; ++e) mj4[e] = mean[j0 + sc + e]; }
+  const float *Si = S + i0 + sc, *Sj = S + j0 + sc;
+  float4 pi[2], pj[2];
+  int f_m0 = 0;                     // first row of the stage held in pi / pj
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int m = m0 + sr + 8 * q;
+      const bool ok = m < M;
+      pi[q] = (ok && ci_ok) ? *reinterpret_cast<const float4 *>(Si + (int64_t)m * D) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pj[q] = (ok && cj_ok) ? *reinterpret_cast<const float4 *>(Sj + (int64_t)m * D) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f_m0 = m0;
+  };
+  auto stage = [&](int buf) {
+    double *base = glds + (size_t)buf * 2 * BROWS * GBT;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = sr + 8 * q;
+      const bool ok = f_m0 + row < M;          // rows past the end contribute 0, not -mean
+      double *di = base + row * GBT + sc, *dj = base + BROWS * GBT + row * GBT + sc;
+      const double vi[4] = {(double)pi[q].x - mi4[0], (double)pi[q].y - mi4[1], (double)pi[q].z - mi4[2], (double)pi[q].w - mi4[3]};
+      const double vj[4] = {(double)pj[q].x - mj4[0], (double)pj[q].y - mj4[1], (double)pj[q].z - mj4[2], (double)pj[q].w - mj4[3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { di[e] = ok ? vi[e] : 0.0; dj[e] = ok ? vj[e] : 0.0; }
+    }
+  };
+
+  doublex4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (doublex4){0.0, 0.0, 0.0, 0.0};
+
+  const int nst = (M + BROWS - 1) / BROWS;
+  fetch(0);
+  stage(0);
+  if (nst > 1) fetch(BROWS);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) stage(buf ^ 1);
+    if (st + 2 < nst) fetch((st + 2) * BROWS);
+    const double *Ai = glds + (size_t)buf * 2 * BROWS * GBT + wi + fl;
+    const double *Bj = glds + (size_t)buf * 2 * BROWS * GBT + BROWS * GBT + wj + fl;
+#pragma unroll
+    for (int ks = 0; ks < BROWS / 4; ++ks) {
+      const int row = ks * 4 + fk;
+      double a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a[q] = Ai[row * GBT + q * 16]; b[q] = Bj[row * GBT + q * 16]; }
+#pragma unroll
+      for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb)
+          acc[qa][qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qa], b[qb], acc[qa][qb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wi + qa * 16 + fk + 4 * r;
+        const int gj = j0 + wj + qb * 16 + fl;
+        if (gi < D && gj < D) G[(int64_t)gi * D + gj] = acc[qa][qb][r];
+      }
+}
+
+// Matrices the large-tile kernel takes (IDIFF_GRAM_SMALL_TILES=1 forces the 64 x 64 kernel, for A/B runs)
+bool gram_big_ok(const float *S, int D) {
+  return D >= 1024 && D % 4 == 0 && ((uintptr_t)S & 15) == 0 && !idiff::option(idiff::OPT_GRAM_SMALL_TILES);
+}
+
+// diagonal tiles are computed in full by gram_kernel (both triangles inside the tile come from the
 // same products in a different order); force exact symmetry afterwards so the Householder sweep may read
 // rows where the textbook reads columns.
 __global__ void __launch_bounds__(256)
@@ -772,15 +879,22 @@ IDIFF_API int idiff_colmean_f64(const float *S, int P, int M, int D, double *mea
 IDIFF_API int idiff_centered_gram_f64(const float *S, const double *mean, int P, int M, int D, double *G, void *stream) {
   if (!S || !mean || !G || P <= 0 || M <= 0 || D <= 0) return fail("centered_gram: bad arguments");
   if (P > 65535) return fail("centered_gram: P too large");
-  const int tiles = ceil_div(D, GT);
   hipStream_t st = (hipStream_t)stream;
+  if (P == 1 && gram_big_ok(S, D)) {
+    const int tb = ceil_div(D, GBT);
+    hipLaunchKernelGGL(gram_big_kernel, dim3(tb * (tb + 1) / 2), dim3(256), GRAM_BIG_LDS, st, S, mean, M, D, tb, G, 0);
+    if (int rc = launch_status("centered_gram")) return rc;
+    return idiff_symmetrize_upper_f64(G, D, stream);
+  }
+  const int tiles = ceil_div(D, GT);
   hipLaunchKernelGGL(gram_kernel, dim3(tiles * (tiles + 1) / 2, P), dim3(256), 0, st, S, mean, M, D, tiles, G, 0, 1);
   hipLaunchKernelGGL(symmetrize_diag_tiles_kernel, dim3(tiles, P), dim3(256), 0, st, G, D);
   return launch_status("centered_gram");
 }
 
 // Rows [row0, row1) of the UPPER triangle of the centred Gram matrix (row0, row1 multiples of 64 or D): G[i][j] for
-// row0 <= i < row1, j >= 64 * (i / 64); nothing else is written.  The row-sharded pipeline computes G one block of rows at
+// row0 <= i < row1, j >= T * (i / T) with T = 64, or 128 when the rows are multiples of 128 and the large-matrix kernel
+// takes them; nothing else is written.  The row-sharded pipeline computes G one block of rows at
 // a time so that the all-reduce of block b runs while block b + 1 is being computed; idiff_symmetrize_upper_f64
 // completes the matrix afterwards.
 IDIFF_API int idiff_centered_gram_rows_f64(const float *S, const double *mean, int M, int D, int row0, int row1, double *G,
@@ -788,6 +902,13 @@ IDIFF_API int idiff_centered_gram_rows_f64(const float *S, const double *mean, i
   if (!S || !mean || !G || M <= 0 || D <= 0) return fail("centered_gram_rows: bad arguments");
   if (row0 < 0 || row1 > D || row0 >= row1 || row0 % GT || (row1 % GT && row1 != D))
     return fail("centered_gram_rows: rows [%d, %d) must be tile-aligned (%d) inside [0, %d)", row0, row1, GT, D);
+  if (gram_big_ok(S, D) && row0 % GBT == 0 && (row1 % GBT == 0 || row1 == D)) {
+    const int tb = ceil_div(D, GBT), b0 = row0 / GBT, b1 = ceil_div(row1, GBT);
+    int count = 0;
+    for (int ti = b0; ti < b1; ++ti) count += tb - ti;
+    hipLaunchKernelGGL(gram_big_kernel, dim3(count), dim3(256), GRAM_BIG_LDS, (hipStream_t)stream, S, mean, M, D, tb, G, b0);
+    return launch_status("centered_gram_rows");
+  }
   const int tiles = ceil_div(D, GT), t0 = row0 / GT, t1 = ceil_div(row1, GT);
   int count = 0;
   for (int ti = t0; ti < t1; ++ti) count += tiles - ti;

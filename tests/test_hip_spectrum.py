@@ -285,6 +285,35 @@ def test_row_sharded_spectrum_single_rank_and_emulated_halves():
         dim_reduction.row_sharded_spectrum(S[:100].contiguous(), 100)
 
 
+@pytest.mark.parametrize("M,D", [(4480, 3072), (1501, 1028), (37, 1024), (2050, 1156)])
+def test_large_tile_gram_equals_the_small_tile_kernel(M, D):
+    """D >= 1024 takes the 128 x 128-tile Gram kernel (operands converted and centred once at staging, prefetched):
+    same reduction order as the 64 x 64 kernel, so the two must agree bit for bit; both against an fp64 matmul; D and M
+    that are not multiples of the tile / stage; the row-block entry point on 128-row blocks."""
+    g = torch.Generator().manual_seed(M + D)
+    S = (torch.randn(M, D, generator=g) * torch.linspace(0.05, 2.0, D) + 0.3).to(DEV)
+    mean = _lib.column_sums(S) / M
+    G = _lib.centered_gram(S, mean)
+    prev = _lib.set_option("IDIFF_GRAM_SMALL_TILES", 1)
+    try:
+        G_small = _lib.centered_gram(S, mean)
+    finally:
+        _lib.set_option("IDIFF_GRAM_SMALL_TILES", int(prev))
+    assert torch.equal(G, G_small)
+    assert torch.equal(G, G.T)
+    Sc = S.double() - mean
+    ref = Sc.T @ Sc
+    assert float((G - ref).abs().max() / ref.abs().max()) < 1e-13
+    nb = (D + 127) // 128
+    cuts = sorted({0, 128 * (nb // 3), 128 * (2 * nb // 3), D})
+    Gb = torch.zeros(D, D, device=DEV, dtype=torch.float64)
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        _lib.centered_gram_rows(S, mean, Gb, r0, r1)
+    assert float(torch.tril(Gb, -128).abs().max()) == 0.0
+    _lib.symmetrize_upper(Gb)
+    assert torch.equal(Gb, G)
+
+
 def _rows_gpu_worker(rank, world, port, q):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
