@@ -102,18 +102,17 @@ class KernelProbe:
             if M is None:
                 M, K = a.shape
                 N = bt.shape[0]
-            if K > 128 or M * batch < 65536:                    # only the HBM-bound 1x1 / NIN contractions
+            if M * batch < 65536:                               # the network's 1x1 / NIN / attention contractions, not the embeddings
                 return None
             res = 4.0 * M * N * batch if (epilogue is not None and epilogue.residual) else 0.0
-            return "igemm_pipe_kernel K<=128 (1x1 / NIN)", 4.0 * batch * (M * K + N * K + M * N) + res, f"{M}x{N}x{K}"
+            group = "igemm_pipe_kernel K<=128 (1x1 / NIN)" if K <= 128 else "igemm_pipe_kernel K>=256 (1x1 / NIN / attention products)"
+            return group, (2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N) + res), f"{M}x{N}x{K}"
 
         def gemm_2src(a1, a2, bt, out, epilogue=None):
             M, K1 = a1.shape
             K, N = K1 + a2.shape[1], bt.shape[0]
-            if K > 256:
-                return None
             res = 4.0 * M * N if (epilogue is not None and epilogue.residual) else 0.0
-            return "igemm_pipe_kernel two-source shortcut", 4.0 * (M * K + N * K + M * N) + res, f"{M}x{N}x{K}"
+            return "igemm_pipe_kernel two-source shortcut", (2.0 * M * N * K, 4.0 * (M * K + N * K + M * N) + res), f"{M}x{N}x{K}"
 
         def ufd(x, k, out, major, in_h, in_w, minor, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
             return "upfirdn2d_nhwc", 4.0 * (x.numel() + out.numel()) + 4.0 * k.numel(), f"{major}x{in_h}x{in_w}x{minor} up{up_x} down{down_x}"
@@ -134,8 +133,13 @@ class KernelProbe:
         if not recs:
             return None
         ms = sum(r[0].elapsed_time(r[1]) for r in recs)
-        work = sum(r[2] for r in recs)
-        return {"launches": len(recs), "avg_us": ms * 1e3 / len(recs), "rate": work / (ms * 1e-3), "keys": [r[3] for r in recs]}
+        out = {"launches": len(recs), "avg_us": ms * 1e3 / len(recs), "keys": [r[3] for r in recs]}
+        if isinstance(recs[0][2], tuple):       # contractions carry (flops, compulsory bytes): the roofline picks the bound
+            out["flops_rate"] = sum(r[2][0] for r in recs) / (ms * 1e-3)
+            out["rate"] = sum(r[2][1] for r in recs) / (ms * 1e-3)
+        else:
+            out["rate"] = sum(r[2] for r in recs) / (ms * 1e-3)
+        return out
 
 
 def winograd_traffic(keys):
@@ -162,10 +166,23 @@ def roofline_report(probe):
     tfl = dom["rate"] / 1e12
     traffic = winograd_traffic(dom["keys"])
     kernels = []
-    for name in ("gn_apply_rows", "igemm_pipe_kernel K<=128 (1x1 / NIN)", "igemm_pipe_kernel two-source shortcut", "upfirdn2d_nhwc",
-                 "softmax_rows"):
+    for name in ("gn_apply_rows", "igemm_pipe_kernel K<=128 (1x1 / NIN)", "igemm_pipe_kernel K>=256 (1x1 / NIN / attention products)",
+                 "igemm_pipe_kernel two-source shortcut", "upfirdn2d_nhwc", "softmax_rows"):
         g = probe.group(name)
-        if g:
+        if not g:
+            continue
+        if "flops_rate" in g:
+            # roofline of a contraction: attainable = min(MFMA peak, arithmetic intensity x HBM peak) over the sampled launches
+            tf, gbs = g["flops_rate"] / 1e12, g["rate"] / 1e9
+            intensity = g["flops_rate"] / g["rate"]                    # flop per compulsory byte
+            mfma_bound = intensity * HBM_PEAK_GBS / 1e3 >= FP32_MFMA_PEAK_TFLOPS
+            kernels.append({"kernel": name, "bound": "mfma" if mfma_bound else "hbm",
+                            "achieved": tf if mfma_bound else gbs, "peak": FP32_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+                            "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                            "frac": tf / FP32_MFMA_PEAK_TFLOPS if mfma_bound else gbs / HBM_PEAK_GBS,
+                            "flop_per_byte": intensity, "tflops": tf, "gbs": gbs,
+                            "launches_sampled": g["launches"], "avg_launch_us": g["avg_us"]})
+        else:
             kernels.append({"kernel": name, "bound": "hbm", "achieved": g["rate"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": g["rate"] / 1e9 / HBM_PEAK_GBS, "launches_sampled": g["launches"], "avg_launch_us": g["avg_us"]})
     return {"bound": "mfma", "kernel": "winograd_kernel (3x3 conv as F(2x2,3x3): 16 [tiles x Cin] x [Cin x Cout] contractions per launch, "

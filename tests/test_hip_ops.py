@@ -418,7 +418,7 @@ def test_groupnorm_vs_cpu(B, HW, C, C2, G, act):
     assert rel_err(y.cpu(), ref) < 2e-6
 
 
-@pytest.mark.parametrize("rows,cols", [(1000, 256), (64, 16), (10, 1024), (5, 1500), (3, 1)])
+@pytest.mark.parametrize("rows,cols", [(1000, 256), (64, 16), (10, 1024), (5, 1500), (3, 1), (7, 512), (70001, 64), (33, 260)])
 def test_softmax_rows(rows, cols):
     x = torch.randn(rows, cols, generator=torch.Generator().manual_seed(cols)) * 5
     d = x.to(DEV)
