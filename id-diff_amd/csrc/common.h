@@ -45,6 +45,12 @@ int option_value(Option o);   // the integer behind a switch (IDIFF_WINO_NGROUP:
 struct AttrGuard { unsigned long long done_mask = 0; };
 int set_dynamic_lds_once(AttrGuard &g, const void *const *fns, int n_fns, int bytes, const char *what);
 
+// conv_narrow.hip: 3x3 / stride 1 / pad 1 convolution to <= 4 output channels on the vector ALUs (the image heads)
+bool conv3x3_narrow_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_lo, int pad_hi,
+                       const idiff_epilogue *ep);
+int conv3x3_narrow(const float *x, const float *wt, float *out, int B, int H, int W, int Cin, int Cout,
+                   const idiff_epilogue *ep, hipStream_t stream);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

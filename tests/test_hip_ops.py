@@ -202,6 +202,36 @@ def test_conv2d_nhwc_vs_cpu(B, H, W, Cin, Cout, k, stride, pad, pad_hi):
     assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,Cout", [(3, 32, 32, 3), (2, 5, 28, 3), (1, 2, 2, 1), (4, 16, 9, 4), (2, 64, 64, 2)])
+def test_conv2d_narrow_head_vs_cpu(B, H, W, Cout):
+    """The 128 -> 3 image heads run on the vector ALUs (conv_narrow.hip) instead of a padded MFMA column: against the fp64
+    CPU convolution and against the implicit GEMM (IDIFF_NO_PIPE), with the epilogue terms the score function uses
+    (bias, activation, out_scale, the per-sample -1/std); widths that are not multiples of the eight-pixel butterfly."""
+    g = torch.Generator().manual_seed(B * W + Cout)
+    Cin = 128
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    rsc = -(torch.rand(B, generator=g) + 0.5)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wt = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    out = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+    _lib.conv2d_nhwc(xd, wt, out, B, H, W, Cin, Cout, 3, 3, 1, 1, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 2e-6
+    ep = dict(bias=b.to(DEV), act="silu", out_scale=0.5, rowscale=rsc.to(DEV), rows_per_group=H * W)
+    _lib.conv2d_nhwc(xd, wt, out, B, H, W, Cin, Cout, 3, 3, 1, 1, epilogue=_lib.make_epilogue(**ep))
+    ref2 = F.silu(ref) * 0.5 * rsc.double()[:, None, None, None]
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref2) < 2e-6
+    direct = torch.empty_like(out)
+    prev = _lib.set_option("IDIFF_NO_PIPE", 1)
+    try:
+        _lib.conv2d_nhwc(xd, wt, direct, B, H, W, Cin, Cout, 3, 3, 1, 1, epilogue=_lib.make_epilogue(**ep))
+    finally:
+        _lib.set_option("IDIFF_NO_PIPE", int(prev))
+    assert rel_err(out.cpu(), direct.double().cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 32, 32, 128, 128), (5, 16, 16, 256, 64), (7, 8, 8, 64, 128),
                                               (9, 4, 4, 32, 64), (2, 6, 10, 8, 64), (1, 2, 2, 16, 64), (33, 4, 4, 8, 64)])
 def test_conv2d_winograd_vs_cpu(B, H, W, Cin, Cout):
