@@ -373,7 +373,30 @@ winograd_kernel(const WinoParams p) {
       }
     }
   }
-  if (want_stats) {
+  if (want_stats && p.tiles_per_img < WG_TILES) {
+    // Maps smaller than a workgroup (8x8: 16 tiles, 4x4: 4 tiles per sample): the workgroup holds WG_TILES / tiles_per_img
+    // whole samples and writes one slot per (sample, channel), layout [B][1][Cout][2].  A thread's two tiles lie in one
+    // sample (tiles_per_img is even); the 16 (tile pair, 4-channel) partial sums of the workgroup meet in LDS and
+    // 64 x samples threads add up the tile pairs of their sample in a fixed order.
+    __syncthreads();                                          // every z has been read: the area is free again
+    double *red = reinterpret_cast<double *>(lds);           // [16 tile pairs][64 channels][2]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[((g * WG_COUT) + 4 * cq + e) * 2] = s1[e];
+      red[((g * WG_COUT) + 4 * cq + e) * 2 + 1] = s2[e];
+    }
+    __syncthreads();
+    const int pairs = p.tiles_per_img >> 1, samples = WG_TILES / p.tiles_per_img;
+    for (int o = tid; o < samples * WG_COUT; o += THREADS) {
+      const int smp = o / WG_COUT, ch = o - smp * WG_COUT;
+      const int64_t img = (int64_t)tile_m * samples + smp;
+      if (img >= p.B) continue;
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < pairs; ++k) { a += red[((smp * pairs + k) * WG_COUT + ch) * 2]; b += red[((smp * pairs + k) * WG_COUT + ch) * 2 + 1]; }
+      double *dst = ep.colstats + (img * p.Cout + n0 + ch) * 2;
+      dst[0] = a; dst[1] = b;
+    }
+  } else if (want_stats) {
     // lanes l, l+16, l+32, l+48 hold the same four channels; then one slot per (wave, channel)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -447,7 +470,9 @@ IDIFF_API int idiff_conv2d_winograd_colstats_split(int B, int H, int W, int Cin,
   if (!idiff_conv2d_winograd_ok(B, H, W, Cin, Cout) || idiff::option(idiff::OPT_NO_COLSTATS)) return 0;
   if ((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) * 4 >= X_LIMIT) return 0;
   const int tpi = (H / 2) * (W / 2);
-  return tpi % WG_TILES == 0 ? tpi / WG_TILES : 0;
+  if (tpi % WG_TILES == 0) return tpi / WG_TILES;
+  // maps smaller than a workgroup's 32 tiles (8x8, 4x4): whole samples per workgroup, one slot per sample
+  return (tpi >= 2 && tpi % 2 == 0 && WG_TILES % tpi == 0) ? 1 : 0;
 }
 
 IDIFF_API int64_t idiff_winograd_weight_floats(int Cin, int Cout) { return (int64_t)16 * Cin * Cout; }
@@ -515,8 +540,9 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
   if (ep) {
     p.ep = *ep; p.has_ep = 1;
     if (p.ep.rows_per_group <= 0) p.ep.rows_per_group = 1;
-    if (ep->colstats && p.tiles_per_img % WG_TILES)
-      return fail("conv2d_winograd: colstats needs whole workgroups per sample (ask idiff_conv2d_winograd_colstats_split)");
+    if (ep->colstats && p.tiles_per_img % WG_TILES && !(p.tiles_per_img >= 2 && p.tiles_per_img % 2 == 0 && WG_TILES % p.tiles_per_img == 0))
+      return fail("conv2d_winograd: colstats needs whole workgroups per sample or whole samples per workgroup "
+                  "(ask idiff_conv2d_winograd_colstats_split)");
   } else {
     p.has_ep = 0; p.ep.rows_per_group = 1; p.ep.out_scale = 1.f;
   }
