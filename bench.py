@@ -97,6 +97,9 @@ class KernelProbe:
         def gn_apply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None):
             return "gn_apply_rows", 8.0 * B * HW * (C + (C2 or 0)), f"{B}x{HW}x{C + (C2 or 0)}"
 
+        def gn_apply_cs(x, C, x2, C2, B, HW, G, ws1, ns1, ws2, ns2, eps, gamma, beta, act, y, mod=None):
+            return "gn_apply_rows", 8.0 * B * HW * (C + (C2 or 0)), f"{B}x{HW}x{C + (C2 or 0)}"
+
         def gemm(a, bt, out=None, epilogue=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, batch=1,
                  stride_a=0, stride_b=0, stride_c=0):
             if M is None:
@@ -120,7 +123,8 @@ class KernelProbe:
         def softmax(x, y, rows, cols, scale):
             return "softmax_rows", 8.0 * rows * cols, f"{rows}x{cols}"
 
-        for name, fn in (("conv2d_winograd", wino), ("groupnorm_apply", gn_apply), ("gemm", gemm), ("gemm_2src", gemm_2src),
+        for name, fn in (("conv2d_winograd", wino), ("groupnorm_apply", gn_apply), ("groupnorm_apply_colstats", gn_apply_cs),
+                         ("gemm", gemm), ("gemm_2src", gemm_2src),
                          ("upfirdn2d_raw", ufd), ("softmax_rows", softmax)):
             self._wrap(name, fn)
 

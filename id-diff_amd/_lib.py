@@ -49,6 +49,8 @@ _SIGNATURES = {
     "idiff_groupnorm_nsplit": (c_i, [c_i, c_i, c_i]),
     "idiff_groupnorm_stats_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
     "idiff_groupnorm_apply_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i64, c_i, c_p, c_p]),
+    "idiff_groupnorm_apply_colstats_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_p, c_i64,
+                                                 c_i, c_p, c_p]),
     "idiff_softmax_rows_f32": (c_i, [c_p, c_p, c_i64, c_i, c_f, c_p]),
     "idiff_affine_act_f32": (c_i, [c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_i64, c_p]),
     "idiff_add_scale_f32": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_p]),
@@ -308,6 +310,14 @@ def groupnorm_apply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None
                                            beta.data_ptr(), _ptr(mod), mod.stride(0) if mod is not None else 0,
                                            ACT[act], y.data_ptr(), _stream()),
            "idiff_groupnorm_apply_f32")
+
+
+def groupnorm_apply_colstats(x, C, x2, C2, B, HW, G, ws1, ns1, ws2, ns2, eps, gamma, beta, act, y, mod=None):
+    """GroupNorm apply whose statistics come from the producers' epilogue column sums (finalize + apply in one launch)."""
+    _check(lib().idiff_groupnorm_apply_colstats_f32(x.data_ptr(), C, _ptr(x2), C2, B, HW, G, ws1.data_ptr(), ns1, _ptr(ws2), ns2,
+                                                    eps, gamma.data_ptr(), beta.data_ptr(), _ptr(mod),
+                                                    mod.stride(0) if mod is not None else 0, ACT[act], y.data_ptr(), _stream()),
+           "idiff_groupnorm_apply_colstats_f32")
 
 
 def softmax_rows(x, y, rows, cols, scale):

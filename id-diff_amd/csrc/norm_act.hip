@@ -123,7 +123,8 @@ gn_apply_kernel(const float *__restrict__ x, int C, const float *__restrict__ x2
 __global__ void __launch_bounds__(256)
 gn_apply_rows_kernel(const float *__restrict__ x, int C, const float *__restrict__ x2, int C2, int HW, int G,
                      const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
-                     const float *__restrict__ mod, int64_t ld_mod, int act, float *__restrict__ y, int rows_per_block) {
+                     const float *__restrict__ mod, int64_t ld_mod, int act, float *__restrict__ y, int rows_per_block,
+                     const double *__restrict__ ws1, int ns1, const double *__restrict__ ws2, int ns2, float eps) {
   const int Ctot = C + C2, CVt = Ctot >> 2, cpg = Ctot / G;
   const int RP = 256 / CVt;
   const int tid = threadIdx.x;
@@ -131,9 +132,44 @@ gn_apply_rows_kernel(const float *__restrict__ x, int C, const float *__restrict
   if (r0 >= RP) return;
   const int b = blockIdx.y, c = c4 * 4;
   float mu[4], s[4], t[4];   // y = act((x - mu) * s + t): the mean is subtracted first, as torch does
+  // ws1 != nullptr: the statistics come straight from the per-tile column sums the producing contractions wrote
+  // (gn_finalize2_kernel's arithmetic, redone by every thread for the group(s) of its four channels: <= 64 cached loads
+  // against thousands of streamed elements), which saves the separate finalize launch per GroupNorm
+  float st_mean[4], st_rstd[4];
+  if (ws1) {
+    int g_prev = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = (c + j) / cpg;
+      if (g != g_prev) {
+        double sum = 0, sq = 0;
+        for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) {
+          const bool first = cc < C;
+          const double *w = first ? ws1 + ((int64_t)b * ns1 * C + cc) * 2 : ws2 + ((int64_t)b * ns2 * C2 + (cc - C)) * 2;
+          const int ns = first ? ns1 : ns2, Cs = first ? C : C2;
+          for (int sp = 0; sp < ns; ++sp) { sum += w[(int64_t)sp * Cs * 2]; sq += w[(int64_t)sp * Cs * 2 + 1]; }
+        }
+        const double n = (double)cpg * HW;
+        const double mean = sum / n;
+        double var = sq / n - mean * mean;
+        if (var < 0) var = 0;
+        st_mean[j] = (float)mean;
+        st_rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+        g_prev = g;
+      } else {
+        st_mean[j] = st_mean[j - 1]; st_rstd[j] = st_rstd[j - 1];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float *st = stats + 2 * ((int64_t)b * G + (c + j) / cpg);
+      st_mean[j] = st[0]; st_rstd[j] = st[1];
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float *st = stats + 2 * ((int64_t)b * G + (c + j) / cpg);
+    const float st[2] = {st_mean[j], st_rstd[j]};
     float sc = st[1] * gamma[c + j], sh = beta[c + j];
     if (mod) {
       const float m1 = 1.0f + mod[(int64_t)b * ld_mod + c + j];
@@ -487,10 +523,36 @@ IDIFF_API int idiff_groupnorm_finalize_f32(const double *ws1, int nsplit1, int C
   return launch_status("groupnorm_finalize");
 }
 
+namespace {
+int groupnorm_apply_impl(const float *x, int C, const float *x2, int C2, int B, int HW, int G, const float *stats,
+                         const double *ws1, int ns1, const double *ws2, int ns2, float eps, const float *gamma,
+                         const float *beta, const float *mod, int64_t ld_mod, int act, float *y, void *stream);
+}
+
 IDIFF_API int idiff_groupnorm_apply_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G,
                                         const float *stats, const float *gamma, const float *beta, const float *mod,
                                         int64_t ld_mod, int act, float *y, void *stream) {
-  if (!x || !stats || !gamma || !beta || !y) return fail("groupnorm_apply: null pointer");
+  if (!stats) return fail("groupnorm_apply: null pointer");
+  return groupnorm_apply_impl(x, C, x2, C2, B, HW, G, stats, nullptr, 0, nullptr, 0, 0.f, gamma, beta, mod, ld_mod, act, y, stream);
+}
+
+IDIFF_API int idiff_groupnorm_apply_colstats_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G,
+                                                 const double *ws1, int nsplit1, const double *ws2, int nsplit2, float eps,
+                                                 const float *gamma, const float *beta, const float *mod, int64_t ld_mod,
+                                                 int act, float *y, void *stream) {
+  if (!ws1 || nsplit1 <= 0) return fail("groupnorm_apply_colstats: the first source's column sums are required");
+  if (!x2) { ws2 = nullptr; nsplit2 = 0; }
+  if (x2 && (!ws2 || nsplit2 <= 0)) return fail("groupnorm_apply_colstats: the second source needs its column sums too");
+  if ((C + (x2 ? C2 : 0)) / 4 > 256 || B > 65535)
+    return fail("groupnorm_apply_colstats: more than 1024 channels or 65535 samples (use idiff_groupnorm_finalize_f32 + idiff_groupnorm_apply_f32)");
+  return groupnorm_apply_impl(x, C, x2, C2, B, HW, G, nullptr, ws1, nsplit1, ws2, nsplit2, eps, gamma, beta, mod, ld_mod, act, y, stream);
+}
+
+namespace {
+int groupnorm_apply_impl(const float *x, int C, const float *x2, int C2, int B, int HW, int G, const float *stats,
+                         const double *ws1, int ns1, const double *ws2, int ns2, float eps, const float *gamma,
+                         const float *beta, const float *mod, int64_t ld_mod, int act, float *y, void *stream) {
+  if (!x || !gamma || !beta || !y) return fail("groupnorm_apply: null pointer");
   if (!x2) C2 = 0;
   const int Ctot = C + C2;
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || Ctot % G != 0 || C % 4 || C2 % 4) return fail("groupnorm_apply: bad shape");
@@ -505,13 +567,14 @@ IDIFF_API int idiff_groupnorm_apply_f32(const float *x, int C, const float *x2, 
     const int rows_per_block = ceil_div(ceil_div(HW, xblocks), RP) * RP;
     xblocks = ceil_div(HW, rows_per_block);
     hipLaunchKernelGGL(gn_apply_rows_kernel, dim3(xblocks, B), dim3(256), 0, (hipStream_t)stream, x, C, x2, C2, HW, G, stats,
-                       gamma, beta, mod, ld_mod, act, y, rows_per_block);
+                       gamma, beta, mod, ld_mod, act, y, rows_per_block, ws1, ns1, ws2, ns2, eps);
     return launch_status("groupnorm_apply_rows");
   }
   hipLaunchKernelGGL(gn_apply_kernel, dim3(streaming_grid(total_vec, 256)), dim3(256), 0, (hipStream_t)stream, x, C, x2,
                      C2, HW, G, stats, gamma, beta, mod, ld_mod, act, y, total_vec);
   return launch_status("groupnorm_apply");
 }
+}  // namespace
 
 IDIFF_API int idiff_softmax_rows_f32(const float *x, float *y, int64_t rows, int cols, float scale, void *stream) {
   if (rows < 0 || cols <= 0) return fail("softmax: bad shape");

@@ -339,9 +339,16 @@ class NCSNpp(HipScoreModel):
         HW = x.H * x.W
         C2 = x2.C if x2 is not None else 0
         G = gn.num_groups
+        if x.stats is not None and (x2 is None or x2.stats is not None) and x.C + C2 <= 1024 and B <= 65535:
+            # both sources carry the column sums their producing contraction wrote: no pass over the activations, and the
+            # statistics are finished inside the apply kernel (one launch per GroupNorm)
+            ws2, ns2 = x2.stats if x2 is not None else (None, 0)
+            y = self._new(B, x.H, x.W, x.C + C2, x.buf)
+            _lib.groupnorm_apply_colstats(x.buf, x.C, x2.buf if x2 is not None else None, C2, B, HW, G, x.stats[0], x.stats[1],
+                                          ws2, ns2, gn.eps, gn.weight.detach(), gn.bias.detach(), act, y.buf, mod=mod)
+            return y
         stats = torch.empty(B * G * 2, device=x.buf.device, dtype=torch.float32)
         if x.stats is not None and (x2 is None or x2.stats is not None):
-            # both sources carry the column sums their producing contraction wrote: no pass over the activations
             ws2, ns2 = x2.stats if x2 is not None else (None, 0)
             _lib.groupnorm_finalize(x.stats[0], x.stats[1], x.C, ws2, ns2, C2, B, HW, G, gn.eps, stats)
         else:

@@ -162,6 +162,12 @@ int idiff_groupnorm_finalize_f32(const double *ws1, int nsplit1, int C1, const d
 int idiff_groupnorm_apply_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G,
                               const float *stats, const float *gamma, const float *beta, const float *mod,
                               int64_t ld_mod, int act, float *y, void *stream);
+/* idiff_groupnorm_finalize_f32 + idiff_groupnorm_apply_f32 in one launch: the statistics are taken from the producers'
+ * column sums (same arithmetic, same result) inside the apply kernel.  C + C2 <= 1024, B <= 65535. */
+int idiff_groupnorm_apply_colstats_f32(const float *x, int C, const float *x2, int C2, int B, int HW, int G,
+                                       const double *ws1, int nsplit1, const double *ws2, int nsplit2, float eps,
+                                       const float *gamma, const float *beta, const float *mod, int64_t ld_mod,
+                                       int act, float *y, void *stream);
 
 /* Row softmax of x [rows, cols] scaled by `scale` before the exponent (layerspp.py:82-84). In place allowed. */
 int idiff_softmax_rows_f32(const float *x, float *y, int64_t rows, int cols, float scale, void *stream);

@@ -367,6 +367,35 @@ def test_winograd_colstats_feed_groupnorm(B, H, Cin, Cout):
     assert _lib.conv2d_winograd_colstats_split(4, 6, 10, Cin, Cout) == 0      # 15 tiles per sample
 
 
+@pytest.mark.parametrize("B,HW,C,C2,G,ns1,ns2", [(5, 256, 128, 0, 32, 2, 0), (3, 64, 256, 128, 32, 1, 1), (4, 16, 64, 64, 32, 1, 1),
+                                                  (2, 1024, 128, 128, 32, 8, 4), (3, 64, 24, 0, 6, 1, 0)])
+def test_groupnorm_apply_from_column_sums(B, HW, C, C2, G, ns1, ns2):
+    """idiff_groupnorm_apply_colstats_f32 = idiff_groupnorm_finalize_f32 + idiff_groupnorm_apply_f32, bit for bit (one and
+    two sources, groups that straddle the sources, several row tiles per sample), and both = torch's group_norm."""
+    g = torch.Generator().manual_seed(B * HW + C)
+    x = torch.randn(B, HW, C, generator=g) * 2 + 0.5
+    x2 = torch.randn(B, HW, C2, generator=g) - 0.3 if C2 else None
+    gamma, beta = torch.randn(C + C2, generator=g), torch.randn(C + C2, generator=g)
+
+    def colsums(t, ns):       # [B, ns, C, 2]: sums and sums of squares over ns equal row ranges
+        parts = t.double().view(B, ns, HW // ns, t.shape[-1])
+        return torch.stack([parts.sum(2), (parts ** 2).sum(2)], -1).contiguous().to(DEV)
+    ws1 = colsums(x, ns1)
+    ws2 = colsums(x2, ns2) if C2 else None
+    xd, x2d = x.to(DEV), (x2.to(DEV) if C2 else None)
+    ga, be = gamma.to(DEV), beta.to(DEV)
+    stats = torch.empty(B * G * 2, device=DEV)
+    _lib.groupnorm_finalize(ws1, ns1, C, ws2, ns2, C2, B, HW, G, 1e-6, stats)
+    y_two = torch.empty(B, HW, C + C2, device=DEV)
+    _lib.groupnorm_apply(xd, C, x2d, C2, B, HW, G, stats, ga, be, "silu", y_two)
+    y_one = torch.empty_like(y_two)
+    _lib.groupnorm_apply_colstats(xd, C, x2d, C2, B, HW, G, ws1, ns1, ws2, ns2, 1e-6, ga, be, "silu", y_one)
+    assert torch.equal(y_one, y_two)
+    full = torch.cat([x, x2], -1) if C2 else x
+    ref = F.silu(F.group_norm(full.double().permute(0, 2, 1), G, gamma.double(), beta.double(), 1e-6)).permute(0, 2, 1)
+    assert rel_err(y_one.cpu(), ref) < 3e-6
+
+
 @pytest.mark.parametrize("M,K1,K2,N", [(1000, 128, 128, 128), (4100, 256, 256, 64), (77, 32, 32, 200)])
 def test_gemm_two_sources(M, K1, K2, N):
     """[A1 | A2] @ W^T with the concatenation never formed (the split shortcut of the up path)."""
