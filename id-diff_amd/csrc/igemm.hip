@@ -373,7 +373,19 @@ igemm_pipe_kernel(const IgemmParams p) {
     const int k = f_kt * BK + kc;
     const bool kok = k < p.K;
     uint32_t koffb = (uint32_t)f_kt * (BK * 4u);
-    if (CONV) {
+    if (CONV && p.Cin == 4) {
+      // the 4-channel stems (image + padding channel): a 16-byte load is one whole tap, so the eight float4 columns of a
+      // k-tile are eight taps and K = KH*KW*4 takes ceil(KH*KW / 8) k-tiles (two for 3x3); the tap is lane-dependent
+      // but fixed per thread and k-tile.  a_base carries + kc * 4 for the channel offset of the wide layers: undone here.
+      const int tap = f_kt * 8 + (tid & 7);
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      const uint32_t tapoff = (uint32_t)((ky * p.W + kx) * 4 - kc) * 4u;
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) {
+        const bool ok = tap < ntaps && ((a_mask[i] >> tap) & 1u);
+        a_reg[i] = buf_load4(rA, ok ? a_base[i] + tapoff : OOB);
+      }
+    } else if (CONV) {
       // k-tiles walk the taps of one 32-channel slice before moving to the next slice (the reduction order is
       // free): the same input lines are then re-read one (kx) or KW (ky) k-tiles later instead of Cin/32 and
       // KW*Cin/32 tiles later, i.e. while they are still in the XCD's L2
@@ -892,7 +904,7 @@ IDIFF_API int idiff_conv2d_nhwc_f32(const float *x, const float *wt, float *out,
   p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.KW = KW; p.stride = stride; p.pad = pad;
   fill_epilogue(p, ep);
   const int64_t a_bytes = (int64_t)B * H * W * Cin * 4, b_bytes = (int64_t)Cout * p.K * 4;
-  const bool fast_ok = Cin % BK == 0 && KH * KW <= 32 && b_bytes < BUF_LIMIT && !idiff::option(idiff::OPT_NO_PIPE);
+  const bool fast_ok = (Cin % BK == 0 || Cin == 4) && KH * KW <= 32 && b_bytes < BUF_LIMIT && !idiff::option(idiff::OPT_NO_PIPE);
   if (ep && ep->colstats && !(fast_ok && a_bytes < BUF_LIMIT))
     return fail("conv2d: colstats requested for a problem the pipelined kernel does not take "
                 "(ask idiff_conv2d_colstats_split first)");
@@ -932,7 +944,7 @@ IDIFF_API int idiff_gemm_colstats_split(int M, int N, int K, int64_t lda, int64_
 
 IDIFF_API int idiff_conv2d_colstats_split(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_lo,
                                           int pad_hi) {
-  if (B <= 0 || Cin % BK || KH * KW > 32 || idiff::option(idiff::OPT_NO_PIPE) || idiff::option(idiff::OPT_NO_COLSTATS)) return 0;
+  if (B <= 0 || (Cin % BK && Cin != 4) || KH * KW > 32 || idiff::option(idiff::OPT_NO_PIPE) || idiff::option(idiff::OPT_NO_COLSTATS)) return 0;
   const int OH = (H + pad_lo + pad_hi - KH) / stride + 1, OW = (W + pad_lo + pad_hi - KW) / stride + 1;
   if (OH <= 0 || OW <= 0) return 0;
   if ((int64_t)B * H * W * Cin * 4 >= BUF_LIMIT || (int64_t)Cout * KH * KW * Cin * 4 >= BUF_LIMIT) return 0;

@@ -184,6 +184,8 @@ def test_gemm_batched_strided():
     (2, 34, 34, 8, 16, 3, 2, 0, None),    # stride-2 VALID conv behind the FIR (conv_downsample_2d)
     (2, 9, 7, 8, 12, 3, 2, 0, 1),         # F.pad(0,1,0,1) + stride 2
     (2, 32, 32, 4, 128, 3, 1, 1, None),   # stem (3 -> 4 padded channels)
+    (3, 33, 33, 4, 128, 3, 2, 0, None),   # input-pyramid stem behind the FIR: 4 channels, stride 2
+    (5, 9, 11, 4, 256, 3, 1, 1, None),    # 4 channels, M and N tails
     (2, 32, 32, 128, 3, 3, 1, 1, None),   # head
     (5, 4, 4, 512, 256, 1, 1, 0, None),   # 1x1
 ])
@@ -541,7 +543,7 @@ def test_perturb_randn_stream():
     torch.testing.assert_close(other.cpu(), (0.5 * x[None] + 0.01 * z).cpu(), rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout", [(8, 32, 128, 128), (16, 16, 256, 256), (40, 16, 64, 96)])
+@pytest.mark.parametrize("B,H,Cin,Cout", [(8, 32, 128, 128), (16, 16, 256, 256), (40, 16, 64, 96), (8, 32, 4, 128)])
 def test_fused_colstats_feed_groupnorm(B, H, Cin, Cout):
     """epilogue.colstats: per-tile column sums written by the conv + idiff_groupnorm_finalize_f32 give the same
     GroupNorm statistics as the stand-alone statistics pass over the stored tensor."""
@@ -567,7 +569,7 @@ def test_fused_colstats_feed_groupnorm(B, H, Cin, Cout):
     torch.testing.assert_close(st_a, st_b, rtol=1e-6, atol=1e-7)
     # samples smaller than a row tile: not available, the caller keeps the stand-alone pass
     assert _lib.conv2d_colstats_split(4096, 8, 8, Cin, Cout, 3, 3, 1, 1) == 0   # 64-row samples inside 128-row tiles
-    assert _lib.conv2d_colstats_split(B, H, H, 4, Cout, 3, 3, 1, 1) == 0     # general kernel (Cin % 32 != 0)
+    assert _lib.conv2d_colstats_split(B, H, H, 12, Cout, 3, 3, 1, 1) == 0    # general kernel (Cin % 32 != 0 and not a 4-channel stem)
 
 
 @pytest.mark.parametrize("up,down,pad", [(1, 2, (1, 1)), (2, 1, (2, 1)), (1, 1, (2, 2)), (2, 3, (3, 0)), (1, 1, (0, 0))])
