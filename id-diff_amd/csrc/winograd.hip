@@ -103,6 +103,9 @@ template <bool PEEL>
 __global__ void __launch_bounds__(THREADS, 2)   // two waves per SIMD (256 VGPRs): two 256-thread workgroups per CU
 winograd_kernel(const WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef IDIFF_WINO_STAMP   // diagnostic build only (scripts/wino_clock.py): the clock the chip holds inside this kernel
+  const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
@@ -266,7 +269,11 @@ winograd_kernel(const WinoParams p) {
   // issued at its point of use cost 0.3 ms of a 3.1 ms launch).
   const idiff_epilogue &ep = p.ep;
   const bool has_ep = p.has_ep != 0;
+#ifdef IDIFF_WINO_STAMP
+  const bool want_stats = false;          // epilogue.colstats carries the stamp buffer in this build
+#else
   const bool want_stats = has_ep && ep.colstats != nullptr;
+#endif
   const int cq = tid & 15, g = tid >> 4;
   const int n = n0 + 4 * cq;
   const bool per_image = ep.rows_per_group == p.H * p.W;   // the usual per-sample bias / scale: group = image
@@ -421,6 +428,14 @@ winograd_kernel(const WinoParams p) {
       dst[0] = a; dst[1] = b;
     }
   }
+#ifdef IDIFF_WINO_STAMP
+  if (has_ep && ep.colstats && tid == 0) {
+    // shader-clock ticks and 100 MHz ticks of this workgroup's lifetime, in a buffer nothing else reads
+    uint64_t *st = reinterpret_cast<uint64_t *>(ep.colstats) + 2 * (int64_t)blockIdx.x;
+    st[0] = __builtin_amdgcn_s_memtime() - stamp_t0;
+    st[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+  }
+#endif
 }
 
 // U = G g G^T in fp64, rounded once; g[ky][kx] = wt[cout][ky][kx][cin] (the K-contiguous panel of the direct kernel).
