@@ -128,15 +128,40 @@ gn_apply_rows_kernel(const float *__restrict__ x, int C, const float *__restrict
   const int Ctot = C + C2, CVt = Ctot >> 2, cpg = Ctot / G;
   const int RP = 256 / CVt;
   const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  // ws1 != nullptr: the statistics come straight from the per-tile column sums the producing contractions wrote
+  // (gn_finalize2_kernel's arithmetic in the same order, so the same bits), which saves the separate finalize launch per
+  // GroupNorm.  Thread g < G finishes group g of this sample once per workgroup and hands it over in LDS (every thread
+  // redoing the sums of its own group read as many bytes as the workgroup streams when a sample has 32 row tiles).
+  __shared__ float sh_stats[2 * 256];
+  const bool shared_stats = ws1 != nullptr && G <= 256;
+  if (shared_stats) {
+    if (tid < G) {
+      double sum = 0, sq = 0;
+      for (int cc = tid * cpg; cc < (tid + 1) * cpg; ++cc) {
+        const bool first = cc < C;
+        const double *w = first ? ws1 + ((int64_t)b * ns1 * C + cc) * 2 : ws2 + ((int64_t)b * ns2 * C2 + (cc - C)) * 2;
+        const int ns = first ? ns1 : ns2, Cs = first ? C : C2;
+        for (int sp = 0; sp < ns; ++sp) { sum += w[(int64_t)sp * Cs * 2]; sq += w[(int64_t)sp * Cs * 2 + 1]; }
+      }
+      const double n = (double)cpg * HW;
+      const double mean = sum / n;
+      double var = sq / n - mean * mean;
+      if (var < 0) var = 0;
+      sh_stats[2 * tid] = (float)mean;
+      sh_stats[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+  }
   const int r0 = tid / CVt, c4 = tid - r0 * CVt;
   if (r0 >= RP) return;
-  const int b = blockIdx.y, c = c4 * 4;
+  const int c = c4 * 4;
   float mu[4], s[4], t[4];   // y = act((x - mu) * s + t): the mean is subtracted first, as torch does
-  // ws1 != nullptr: the statistics come straight from the per-tile column sums the producing contractions wrote
-  // (gn_finalize2_kernel's arithmetic, redone by every thread for the group(s) of its four channels: <= 64 cached loads
-  // against thousands of streamed elements), which saves the separate finalize launch per GroupNorm
   float st_mean[4], st_rstd[4];
-  if (ws1) {
+  if (shared_stats) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { st_mean[j] = sh_stats[2 * ((c + j) / cpg)]; st_rstd[j] = sh_stats[2 * ((c + j) / cpg) + 1]; }
+  } else if (ws1) {          // more than 256 groups: every thread finishes the group(s) of its own four channels
     int g_prev = -1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
