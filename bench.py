@@ -359,7 +359,7 @@ def timed_region(work, warmup, steps, dev):
 def main(argv=None, workload_factory=Workload):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--inflight", type=int, default=2240, help="score rows per launch set (measured best of 512..4480)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
