@@ -902,27 +902,39 @@ __device__ __forceinline__ void msg_send(unsigned long long *box, const double *
   }
 }
 
-// threads [0, GRAN) wait for their granule of tag `tag` and put it into `dst` (LDS); returns false (to those threads) on abort
-__device__ __forceinline__ void msg_recv(const unsigned long long *box, double *dst, unsigned tag, int *abort_flag) {
-  const int tid = threadIdx.x;
-  if (tid < GRAN) {
+// threads [base, base + GRAN) wait for their granule of tag `tag` and put it into `dst` (LDS); a thread that gives up (the
+// abort word is set, or it sets it itself after SPIN_LIMIT polls) returns true
+__device__ __forceinline__ bool msg_recv(const unsigned long long *box, double *dst, unsigned tag, int *abort_flag, int base) {
+  const int i = (int)threadIdx.x - base;
+  if (i >= 0 && i < GRAN) {
     long spins = 0;
     for (;;) {
-      const unsigned long long u = __hip_atomic_load(box + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned)(u >> 32) == tag) { reinterpret_cast<unsigned *>(dst)[tid] = (unsigned)u; break; }
+      const unsigned long long u = __hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(u >> 32) == tag) { reinterpret_cast<unsigned *>(dst)[i] = (unsigned)u; return false; }
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 255) == 0) {
-        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (spins > SPIN_LIMIT) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+        if (spins > SPIN_LIMIT) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
       }
     }
   }
+  return false;
+}
+
+// one thread publishes 32-bit half `h` (0 .. GRAN) of a message whose double h / 2 is `val`
+__device__ __forceinline__ void msg_send_half(unsigned long long *box, int h, double val, unsigned tag) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(val);
+  const unsigned half = (h & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+  __hip_atomic_store(box + h, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
+  // A sweep costs the two hand-offs of the cycle (s, t) -> (s, t + 1) -> (s + 1, t) plus twice the path from "messages
+  // in" to "messages out", so that path is kept short: both messages are awaited at once by different threads, three
+  // workgroup barriers lie between them and the sends, which go straight from the lanes that hold the values; the window
+  // shift for the next sweep and the left application of the new reflector run after the sends.
   __shared__ double v[MSG], pq[2 * BW], x2[BW], dpart[2][BW];
-  __shared__ double msg_in[MSG], msg_out[MSG], colbuf[MSG], rowbuf[BW], edge[4][BW], xcol[BW];
-  __shared__ double sc[2];
+  __shared__ double msg_in[MSG], colbuf[MSG], rowbuf[BW], edge[4][BW], xcol[BW];
   __shared__ int ab;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = blockIdx.x, Dp = g.Dp;
@@ -949,60 +961,33 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
   }
   __syncthreads();
   for (int s = 0; s < S; ++s) {
+    // ---- messages in: the column of sweep s - 1 from node t + 1 (threads 0 .. 65) and the reflector of sweep s from
+    //      node t - 1 (threads 128 .. 193) are awaited side by side; node 0 makes its own reflector meanwhile
     if (s > 0) {
-      // ---- slide the window by one: W'[r][c] = W[r + 1][c + 1]; the new last column comes from the mirror of the
-      //      old lower block's first row, node t + 1's column message of sweep s - 1, and its alpha
       const bool has = Dp - (s + (t + 1) * BW) >= 2;          // task (s - 1, t + 1) exists
-      if (has) msg_recv(mailbox(g, t, 1, (s - 1) & 1), msg_in, (unsigned)s, g.abort_flag);
+      if (has) { if (msg_recv(mailbox(g, t, 1, (s - 1) & 1), msg_in, (unsigned)s, g.abort_flag, 0)) ab = 1; }
       else if (tid < MSG) msg_in[tid] = 0.0;
-      if (r == BW) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rowbuf[c0 + j] = x[j];
-      }
-      if ((r & 15) == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) edge[wave][c0 + j] = x[j];
-      }
-      __syncthreads();
-      double y[9];                                             // row r + 1, columns c0 .. c0 + 8
-      const bool last_in_wave = (r & 15) == 15;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = __shfl_down(x[j], 4, 64);
-      y[8] = __shfl_down(x[0], 5, 64);                         // thread (r + 1, part + 1), meaningful for part < 3
-      if (last_in_wave) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = wave < 3 ? edge[wave + 1][c0 + j] : 0.0;
-        y[8] = (wave < 3 && part < 3) ? edge[wave + 1][c0 + 8] : 0.0;
-      }
-      if (part == 3) {
-        // new last column (window column BW - 1 = global column a + BW of the old window)
-        double nv;
-        if (r < BW - 1) nv = rowbuf[r + 1];
-        else if (r == BW - 1) nv = msg_in[0];
-        else if (r < 2 * BW - 1) nv = msg_in[r - BW + 1];
-        else nv = msg_in[BW];
-        y[8] = nv;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = y[j + 1];
-      __syncthreads();
     }
-    // ---- reflector of task (s, t)
     if (t == 0) {
-      if (wave == 0) {
+      if (wave == 2) {                                         // (waves 0 and 1 hold the threads that poll the column message)
         const double xv = lane < BW ? xcol[lane] : 0.0;
         const double tail = wave_sum(lane >= 1 && lane < BW ? xv * xv : 0.0);
         double alpha, v0, tl;
         make_house(__shfl(xv, 0, 64), tail, alpha, v0, tl);
         if (lane < BW) v[lane] = lane == 0 ? v0 : xv;
-        if (lane == 0) { sc[0] = tl; if (s < g.D) g.offd[s] = alpha; }
+        if (lane == 0) { v[BW] = tl; if (s < g.D) g.offd[s] = alpha; }
       }
     } else {
-      msg_recv(mailbox(g, t, 0, s & 1), v, (unsigned)(s + 1), g.abort_flag);     // v[0 .. BW) and tau = v[BW] in one piece
+      if (msg_recv(mailbox(g, t, 0, s & 1), v, (unsigned)(s + 1), g.abort_flag, 128)) ab = 1;     // v[0 .. BW) and tau = v[BW]
     }
-    __syncthreads();
-    if (__hip_atomic_load(g.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ab = 1;   // benign race: all write 1
-    const double tau = t == 0 ? sc[0] : v[BW];
+    __syncthreads();                                           // B1
+    if (ab) break;                                             // uniform: written before the barrier
+    if (s > 0 && part == 3 && r >= BW - 1) {
+      // the rows of the new last column that come from node t + 1 (the shift at the end of the previous sweep left them open)
+      x[7] = r == BW - 1 ? msg_in[0] : (r < 2 * BW - 1 ? msg_in[r - BW + 1] : msg_in[BW]);
+    }
+    // ---- two-sided application of the incoming reflector
+    const double tau = v[BW];
     if (tau != 0.0) {
       double ps = 0.0;
 #pragma unroll
@@ -1010,7 +995,7 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
       ps += __shfl_xor(ps, 1, 64);
       ps += __shfl_xor(ps, 2, 64);
       if (part == 0) pq[r] = tau * ps;
-      __syncthreads();
+      __syncthreads();                                         // B2
       const double pv = wave_sum(lane < BW ? pq[lane] * v[lane] : 0.0);
       const double kk = 0.5 * tau * pv;
       if (diag_row) {
@@ -1025,32 +1010,39 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
     }
     // ---- next reflector from the first column of the lower block.  The window's first column (rows 0 .. BW) is final
     //      as soon as alpha2 is known (the left application below only touches columns >= 1): both messages leave here,
-    //      the rest of the task runs off the critical path of the two neighbours.
+    //      straight from the threads that read x2 / colbuf; the rest of the task runs off the critical path of the neighbours
     if (part == 0) { if (diag_row) colbuf[r] = x[0]; else x2[r - BW] = x[0]; }
-    __syncthreads();
-    if (ab) break;                                            // uniform: `ab` was written before the barrier above
+    __syncthreads();                                           // B3
     double alpha2, v20, tau2;
     {
       const double xv = lane < BW ? x2[lane] : 0.0;
       const double tail = wave_sum(lane >= 1 && lane < BW ? xv * xv : 0.0);
       make_house(x2[0], tail, alpha2, v20, tau2);             // every wave computes the same numbers
-      if (wave == 0 && lane < BW) msg_out[lane] = lane == 0 ? v20 : xv;
-      if (tid == 0) { msg_out[BW] = tau2; colbuf[BW] = alpha2; }
     }
-    __syncthreads();
-    if (Dp - (s + 1 + (t + 1) * BW) >= 2) msg_send(mailbox(g, t + 1, 0, s & 1), msg_out, (unsigned)(s + 1));   // task (s, t + 1) exists
-    if (t > 0) {
-      msg_send(mailbox(g, t - 1, 1, s & 1), colbuf, (unsigned)(s + 1));
-    } else {
-      if (tid < BW) xcol[tid] = colbuf[tid + 1];
-      if (tid == 0 && s + 1 < g.D) g.diag[s + 1] = colbuf[0];
+    if (tid < GRAN) {
+      if (Dp - (s + 1 + (t + 1) * BW) >= 2) {                  // task (s, t + 1) exists: reflector (v20, x2[1 ..], tau2)
+        const int d = tid >> 1;
+        const double val = d == 0 ? v20 : (d < BW ? x2[d] : tau2);
+        msg_send_half(mailbox(g, t + 1, 0, s & 1), tid, val, (unsigned)(s + 1));
+      }
+    } else if (tid >= 128 && tid < 128 + GRAN) {
+      const int h = tid - 128, d = h >> 1;
+      if (t > 0) {                                             // column (colbuf[0 .. BW), alpha2) for node t - 1's next sweep
+        const double val = d < BW ? colbuf[d] : alpha2;
+        msg_send_half(mailbox(g, t - 1, 1, s & 1), h, val, (unsigned)(s + 1));
+      }
     }
+    if (t == 0) {
+      if (tid >= 192 && tid < 192 + BW) xcol[tid - 192] = tid - 192 + 1 < BW ? colbuf[tid - 192 + 1] : alpha2;
+      if (tid == 192 && s + 1 < g.D) g.diag[s + 1] = colbuf[0];
+    }
+    // ---- left application of the new reflector to the lower block
+    const double vr2 = diag_row ? 0.0 : (r == BW ? v20 : x2[r - BW]);
     if (!diag_row) {
-      const double vr = msg_out[r - BW];
       double dloc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        double dv = vr * x[j];
+        double dv = vr2 * x[j];
         dv += __shfl_xor(dv, 4, 64); dv += __shfl_xor(dv, 8, 64); dv += __shfl_xor(dv, 16, 64); dv += __shfl_xor(dv, 32, 64);
         dloc[j] = dv;
       }
@@ -1059,22 +1051,45 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
         for (int j = 0; j < 8; ++j) dpart[wave - 2][lane * 8 + j] = dloc[j];
       }
     }
-    __syncthreads();
+    __syncthreads();                                           // B4
     if (!diag_row) {
-      const double vr = msg_out[r - BW];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = c0 + j;
         const double dc = tau2 * (dpart[0][c] + dpart[1][c]);
         if (c == 0) x[j] = (r == BW) ? alpha2 : 0.0;
-        else x[j] -= dc * vr;
+        else x[j] -= dc * vr2;
       }
     }
-    __syncthreads();       // msg_out / colbuf / dpart are rewritten by the next sweep
+    // ---- shift the window for the next sweep: W'[r][c] = W[r + 1][c + 1]; the new last column is the mirror of the lower
+    //      block's first row for rows < BW - 1, the rest of it arrives with node t + 1's column message (filled in above)
+    if (s + 1 < S) {
+      if (r == BW) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rowbuf[c0 + j] = x[j];
+      }
+      if ((r & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) edge[wave][c0 + j] = x[j];
+      }
+      __syncthreads();                                         // E1
+      double y[9];                                             // row r + 1, columns c0 .. c0 + 8
+      const bool last_in_wave = (r & 15) == 15;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = __shfl_down(x[j], 4, 64);
+      y[8] = __shfl_down(x[0], 5, 64);                         // thread (r + 1, part + 1), meaningful for part < 3
+      if (last_in_wave) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = wave < 3 ? edge[wave + 1][c0 + j] : 0.0;
+        y[8] = (wave < 3 && part < 3) ? edge[wave + 1][c0 + 8] : 0.0;
+      }
+      if (part == 3) y[8] = r < BW - 1 ? rowbuf[r + 1] : 0.0;  // rows >= BW - 1: from the column message, next sweep
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = y[j + 1];
+    }
   }
 }
 
-// diag/offd come from the systolic kernel; poison them if the band reduction or the chase reported trouble
 __global__ void __launch_bounds__(256) finish_de_kernel(int D, double *__restrict__ diag, double *__restrict__ offd,
                                                         const double *__restrict__ resid2, const double *__restrict__ fro2,
                                                         double tol2, const int *__restrict__ abort_flag) {
