@@ -930,11 +930,12 @@ __device__ __forceinline__ void msg_send_half(unsigned long long *box, int h, do
 
 __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
   // A sweep costs the two hand-offs of the cycle (s, t) -> (s, t + 1) -> (s + 1, t) plus twice the path from "messages
-  // in" to "messages out", so that path is kept short: both messages are awaited at once by different threads, three
-  // workgroup barriers lie between them and the sends, which go straight from the lanes that hold the values; the window
-  // shift for the next sweep and the left application of the new reflector run after the sends.
-  __shared__ double v[MSG], pq[2 * BW], x2[BW], dpart[2][BW];
-  __shared__ double msg_in[MSG], colbuf[MSG], rowbuf[BW], edge[4][BW], xcol[BW];
+  // in" to "messages out", so that path is kept short: both messages are awaited at once by different threads; what the
+  // outgoing messages need (row products, the lower block's first column, two sums over rows) takes ONE more workgroup
+  // barrier; every double of a message is sent by the thread that holds it; the bulk of the two-sided update, the left
+  // application of the new reflector and the window shift for the next sweep run after the sends.
+  __shared__ double v[MSG], pq[2 * BW], dpart[2][BW], red[5];
+  __shared__ double msg_in[MSG], rowbuf[BW], edge[4][BW], xcol[BW];
   __shared__ int ab;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = blockIdx.x, Dp = g.Dp;
@@ -986,58 +987,82 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
       // the rows of the new last column that come from node t + 1 (the shift at the end of the previous sweep left them open)
       x[7] = r == BW - 1 ? msg_in[0] : (r < 2 * BW - 1 ? msg_in[r - BW + 1] : msg_in[BW]);
     }
-    // ---- two-sided application of the incoming reflector
+    // ---- what the two messages need, first: the row products pq (local to a row's four threads), the first column of the
+    //      lower block after the right application (local to its rows), and two sums over rows -- pv over the upper block,
+    //      the tail norm over the lower block's first column -- which meet in LDS behind ONE barrier
     const double tau = v[BW];
+    double pqr = 0.0;
     if (tau != 0.0) {
       double ps = 0.0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) ps += x[j] * v[c0 + j];
       ps += __shfl_xor(ps, 1, 64);
       ps += __shfl_xor(ps, 2, 64);
-      if (part == 0) pq[r] = tau * ps;
-      __syncthreads();                                         // B2
-      const double pv = wave_sum(lane < BW ? pq[lane] * v[lane] : 0.0);
-      const double kk = 0.5 * tau * pv;
+      pqr = tau * ps;
+    }
+    if (part == 0) pq[r] = pqr;
+    const double v0c = v[0];
+    const double x2r = (!diag_row && part == 0) ? x[0] - pqr * v0c : 0.0;      // lower block, column 0, after the right application
+    {
+      const double term = part != 0 ? 0.0 : (diag_row ? pqr * v[r] : (r > BW ? x2r * x2r : 0.0));
+      const double sum = wave_sum(term);
+      if (lane == 0) red[wave] = sum;
+      if (r == BW && part == 0) red[4] = x2r;
+    }
+    __syncthreads();                                           // B2
+    const double pv = red[0] + red[1];
+    const double kk = 0.5 * tau * pv;
+    double alpha2, v20, tau2;
+    make_house(red[4], red[2] + red[3], alpha2, v20, tau2);   // every thread computes the same numbers
+    // ---- both messages leave here, each double from the thread that holds it (rows' part-0 threads), the two scalars
+    //      from two threads of their own; the window's first column is final once alpha2 is known
+    {
+      const bool refl_to = Dp - (s + 1 + (t + 1) * BW) >= 2;  // task (s, t + 1) exists
+      if (part == 0) {
+        if (diag_row) {
+          const double vr = v[r], wr = pqr - kk * vr, w0 = pq[0] - kk * v0c;
+          const double colval = x[0] - (vr * w0 + wr * v0c);   // upper block, column 0, after the two-sided application
+          if (t > 0) {
+            unsigned long long *box = mailbox(g, t - 1, 1, s & 1);
+            msg_send_half(box, 2 * r, colval, (unsigned)(s + 1));
+            msg_send_half(box, 2 * r + 1, colval, (unsigned)(s + 1));
+          } else {
+            if (r == 0) { if (s + 1 < g.D) g.diag[s + 1] = colval; }
+            else xcol[r - 1] = colval;
+          }
+        } else if (refl_to) {
+          unsigned long long *box = mailbox(g, t + 1, 0, s & 1);
+          const double val = r == BW ? v20 : x2r;
+          msg_send_half(box, 2 * (r - BW), val, (unsigned)(s + 1));
+          msg_send_half(box, 2 * (r - BW) + 1, val, (unsigned)(s + 1));
+        }
+      } else if (tid == 1) {
+        if (t > 0) {
+          unsigned long long *box = mailbox(g, t - 1, 1, s & 1);
+          msg_send_half(box, 2 * BW, alpha2, (unsigned)(s + 1));
+          msg_send_half(box, 2 * BW + 1, alpha2, (unsigned)(s + 1));
+        } else {
+          xcol[BW - 1] = alpha2;
+        }
+      } else if (tid == 2 && refl_to) {
+        unsigned long long *box = mailbox(g, t + 1, 0, s & 1);
+        msg_send_half(box, 2 * BW, tau2, (unsigned)(s + 1));
+        msg_send_half(box, 2 * BW + 1, tau2, (unsigned)(s + 1));
+      }
+    }
+    // ---- the bulk of the two-sided application
+    if (tau != 0.0) {
       if (diag_row) {
-        const double vr = v[r], wr = pq[r] - kk * vr;
+        const double vr = v[r], wr = pqr - kk * vr;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const double vc = v[c0 + j], wc = pq[c0 + j] - kk * vc; x[j] -= vr * wc + wr * vc; }
       } else {
-        const double qr = pq[r];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] -= qr * v[c0 + j];
+        for (int j = 0; j < 8; ++j) x[j] -= pqr * v[c0 + j];
       }
-    }
-    // ---- next reflector from the first column of the lower block.  The window's first column (rows 0 .. BW) is final
-    //      as soon as alpha2 is known (the left application below only touches columns >= 1): both messages leave here,
-    //      straight from the threads that read x2 / colbuf; the rest of the task runs off the critical path of the neighbours
-    if (part == 0) { if (diag_row) colbuf[r] = x[0]; else x2[r - BW] = x[0]; }
-    __syncthreads();                                           // B3
-    double alpha2, v20, tau2;
-    {
-      const double xv = lane < BW ? x2[lane] : 0.0;
-      const double tail = wave_sum(lane >= 1 && lane < BW ? xv * xv : 0.0);
-      make_house(x2[0], tail, alpha2, v20, tau2);             // every wave computes the same numbers
-    }
-    if (tid < GRAN) {
-      if (Dp - (s + 1 + (t + 1) * BW) >= 2) {                  // task (s, t + 1) exists: reflector (v20, x2[1 ..], tau2)
-        const int d = tid >> 1;
-        const double val = d == 0 ? v20 : (d < BW ? x2[d] : tau2);
-        msg_send_half(mailbox(g, t + 1, 0, s & 1), tid, val, (unsigned)(s + 1));
-      }
-    } else if (tid >= 128 && tid < 128 + GRAN) {
-      const int h = tid - 128, d = h >> 1;
-      if (t > 0) {                                             // column (colbuf[0 .. BW), alpha2) for node t - 1's next sweep
-        const double val = d < BW ? colbuf[d] : alpha2;
-        msg_send_half(mailbox(g, t - 1, 1, s & 1), h, val, (unsigned)(s + 1));
-      }
-    }
-    if (t == 0) {
-      if (tid >= 192 && tid < 192 + BW) xcol[tid - 192] = tid - 192 + 1 < BW ? colbuf[tid - 192 + 1] : alpha2;
-      if (tid == 192 && s + 1 < g.D) g.diag[s + 1] = colbuf[0];
     }
     // ---- left application of the new reflector to the lower block
-    const double vr2 = diag_row ? 0.0 : (r == BW ? v20 : x2[r - BW]);
+    const double vr2 = diag_row ? 0.0 : (r == BW ? v20 : __shfl(x2r, lane & ~3, 64));
     if (!diag_row) {
       double dloc[8];
 #pragma unroll
