@@ -911,7 +911,7 @@ __device__ __forceinline__ bool msg_recv(const unsigned long long *box, double *
     for (;;) {
       const unsigned long long u = __hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((unsigned)(u >> 32) == tag) { reinterpret_cast<unsigned *>(dst)[i] = (unsigned)u; return false; }
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(1);                            // (polling without it measured the same)
       if ((++spins & 255) == 0) {
         if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
         if (spins > SPIN_LIMIT) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
@@ -1004,32 +1004,35 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
     const double v0c = v[0];
     const double x2r = (!diag_row && part == 0) ? x[0] - pqr * v0c : 0.0;      // lower block, column 0, after the right application
     {
-      const double term = part != 0 ? 0.0 : (diag_row ? pqr * v[r] : (r > BW ? x2r * x2r : 0.0));
-      const double sum = wave_sum(term);
+      // sums over the wave's sixteen rows: only the part-0 lanes (every fourth) carry a term
+      double sum = part != 0 ? 0.0 : (diag_row ? pqr * v[r] : (r > BW ? x2r * x2r : 0.0));
+      sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
       if (lane == 0) red[wave] = sum;
       if (r == BW && part == 0) red[4] = x2r;
     }
     __syncthreads();                                           // B2
     const double pv = red[0] + red[1];
     const double kk = 0.5 * tau * pv;
+    // ---- both messages leave here, each double from the thread that holds it (rows' part-0 threads), the two scalars
+    //      from two threads of their own; the column's 32 entries do not wait for the new reflector
+    if (part == 0 && diag_row) {
+      const double vr = v[r], wr = pqr - kk * vr, w0 = pq[0] - kk * v0c;
+      const double colval = x[0] - (vr * w0 + wr * v0c);       // upper block, column 0, after the two-sided application
+      if (t > 0) {
+        unsigned long long *box = mailbox(g, t - 1, 1, s & 1);
+        msg_send_half(box, 2 * r, colval, (unsigned)(s + 1));
+        msg_send_half(box, 2 * r + 1, colval, (unsigned)(s + 1));
+      } else {
+        if (r == 0) { if (s + 1 < g.D) g.diag[s + 1] = colval; }
+        else xcol[r - 1] = colval;
+      }
+    }
     double alpha2, v20, tau2;
     make_house(red[4], red[2] + red[3], alpha2, v20, tau2);   // every thread computes the same numbers
-    // ---- both messages leave here, each double from the thread that holds it (rows' part-0 threads), the two scalars
-    //      from two threads of their own; the window's first column is final once alpha2 is known
     {
       const bool refl_to = Dp - (s + 1 + (t + 1) * BW) >= 2;  // task (s, t + 1) exists
       if (part == 0) {
         if (diag_row) {
-          const double vr = v[r], wr = pqr - kk * vr, w0 = pq[0] - kk * v0c;
-          const double colval = x[0] - (vr * w0 + wr * v0c);   // upper block, column 0, after the two-sided application
-          if (t > 0) {
-            unsigned long long *box = mailbox(g, t - 1, 1, s & 1);
-            msg_send_half(box, 2 * r, colval, (unsigned)(s + 1));
-            msg_send_half(box, 2 * r + 1, colval, (unsigned)(s + 1));
-          } else {
-            if (r == 0) { if (s + 1 < g.D) g.diag[s + 1] = colval; }
-            else xcol[r - 1] = colval;
-          }
         } else if (refl_to) {
           unsigned long long *box = mailbox(g, t + 1, 0, s & 1);
           const double val = r == BW ? v20 : x2r;
