@@ -272,6 +272,14 @@ upfirdn2d_planes_rowslide(const float *__restrict__ x, const float *__restrict__
   for (int i = tid; i < nplanes * osz; i += 256) dst[i] = ob[i];
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin, and every XCD has an L2 of its own: consecutive block indices -- here
+// neighbouring rows of one plane, which read the same input rows -- would each pull those rows through a different L2.
+// This bijection gives every XCD a contiguous run of the grid instead (blocks b and b + 8 share an XCD).
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 // ---------------------------------------------------------------- minor % 4 == 0, row-structured
 // grid.x = (plane, oy); a thread keeps its channel vector c4 and walks output columns, so the only integer
 // divisions are the two that split blockIdx.x (uniform) -- the per-element 64-bit div/mod of a flat grid-stride
@@ -287,7 +295,8 @@ upfirdn2d_nhwc_rows(const float *__restrict__ x, const float *__restrict__ k, fl
     taps[i] = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
   }
   __syncthreads();
-  const int plane = blockIdx.x / p.out_h, oy = blockIdx.x - plane * p.out_h;   // rows on grid.x (no 65535 limit)
+  const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int plane = bid / p.out_h, oy = bid - plane * p.out_h;   // rows on grid.x (no 65535 limit)
   const int c4 = threadIdx.x % cv, col0 = threadIdx.x / cv;
   if (col0 >= col_step) return;
   const int by = oy * p.down_y - p.pad_y0;
@@ -344,7 +353,8 @@ upfirdn2d_nhwc_up2_block(const float *__restrict__ x, const float *__restrict__ 
     taps[threadIdx.x] = k[(3 - ky) * 4 + (3 - kx)];
   }
   __syncthreads();
-  const int plane = blockIdx.x / p.in_h, i = blockIdx.x - plane * p.in_h;
+  const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int plane = bid / p.in_h, i = bid - plane * p.in_h;
   const int c4 = threadIdx.x % cv, col0 = threadIdx.x / cv;
   if (col0 >= col_step) return;
   float w[16];
