@@ -24,8 +24,16 @@ class VESDE(SDE):
         self.diffused_mean = data_mean
 
     def marginal_prob(self, x, t):
-        lo = torch.tensor(self.sigma_min).type_as(t)
-        hi = torch.tensor(self.sigma_max).type_as(t)
+        # sde_lib.py:342-347 of the reference: `torch.tensor(sigma).type_as(t)`.  The two scalars are kept per (device,
+        # dtype): made afresh they are a pageable host-to-device copy per call, and that copy is stream-ordered -- the host
+        # sat in it until the previous forward had drained (2 x 240 ms of blocking per point, a ~1 ms bubble on the GPU
+        # at every forward boundary).  Same tensors, same arithmetic, same bits.
+        key = (t.device, t.dtype, float(self.sigma_min), float(self.sigma_max))
+        cached = getattr(self, "_sigma_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, torch.tensor(self.sigma_min).type_as(t), torch.tensor(self.sigma_max).type_as(t))
+            self._sigma_cache = cached
+        lo, hi = cached[1], cached[2]
         return x, lo * (hi / lo) ** t
 
 
