@@ -333,7 +333,10 @@ def timed_region(work, warmup, steps, dev):
     for i in range(warmup):
         work.point(i)
     if warmup:
-        work.collect()
+        warm = work.collect()
+        # the exchange step is part of the warm-up too: the first all-gather of a communicator sets up its channels
+        # (tens of ms once), which is start-up cost, not throughput
+        parallel.gather_spectra(warm, world * warmup, warm.shape[1], dev)
     _sync(dev)
     if grouped:
         dist.barrier()

@@ -112,7 +112,12 @@ class SpectrumPipeline:
 
     def __init__(self, device, overlap=True):
         self.device = device
-        self.side = torch.cuda.Stream(device=device) if overlap else None
+        # A stream of another priority class gets a hardware queue of its own.  A default-priority stream shares the
+        # runtime's small pool of queues with every other stream of the process: once an RCCL communicator exists (its
+        # streams were made first) this one landed on the main stream's queue and the spectrum ran BETWEEN the score
+        # evaluations instead of beside them (+35 ms per point under torch.distributed.run, same kernels, same durations).
+        prio = int(os.environ.get("IDIFF_SIDE_STREAM_PRIORITY", "-1"))
+        self.side = torch.cuda.Stream(device=device, priority=prio) if overlap else None
         self.pending = []
         self.deferred = None      # (S, ready event) of the last submitted point, not yet enqueued
 
