@@ -55,15 +55,24 @@ _ALLOWED = {
     ("builtins", "bool"): bool, ("builtins", "str"): str, ("builtins", "bytes"): bytes, ("builtins", "complex"): complex,
     ("builtins", "slice"): slice, ("builtins", "range"): range,
 }
-# what torch.save emits for tensors / parameters / dtypes / sizes
-_TORCH_PREFIXES = ("torch._utils", "torch.storage", "torch._tensor", "torch.nn.parameter", "torch.serialization")
-_TORCH_NAMES = {("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch", "Tensor"), ("torch", "Generator")}
+# What torch.save emits for tensors / parameters / dtypes / sizes -- an EXACT (module, name) list, not a module prefix:
+# `torch.storage._load_from_bytes` (a nested torch.load without restrictions), `torch._utils._import_dotted_name` and
+# `torch.serialization.load` live in the same modules as the rebuild helpers and must stay stand-ins.
+_TORCH_ALLOWED = {
+    ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"), ("torch.nn.parameter", "Parameter"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+}
+_TORCH_STORAGES = {"UntypedStorage", "TypedStorage", "DoubleStorage", "FloatStorage", "HalfStorage", "BFloat16Storage",
+                   "LongStorage", "IntStorage", "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage",
+                   "ComplexDoubleStorage", "ComplexFloatStorage"}
 
 
 def _is_torch_global(module, name):
-    if (module, name) in _TORCH_NAMES or any(module == p or module.startswith(p + ".") for p in _TORCH_PREFIXES):
+    if (module, name) in _TORCH_ALLOWED:
         return True
-    if module == "torch" and (name.endswith("Storage") or isinstance(getattr(torch, name, None), torch.dtype)):
+    if module == "torch" and (name in _TORCH_STORAGES or isinstance(getattr(torch, name, None), torch.dtype)):
         return True
     return False
 

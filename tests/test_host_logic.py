@@ -335,6 +335,36 @@ def test_lightning_checkpoint_round_trip(tmp_path, monkeypatch):
     create_lightning_module(cfg).load_from_checkpoint(str(tmp_path / 'evil.ckpt'))
     assert not (tmp_path / 'pwned').exists()
 
+    # ... nor are the loaders that live NEXT to the tensor-rebuild helpers in torch's own modules: a nested,
+    # unrestricted torch.load (`torch.storage._load_from_bytes`), `torch._utils._import_dotted_name`, `torch.serialization.load`
+    import io
+    inner = io.BytesIO()
+    torch.save(Evil(), inner)
+
+    class Nested:
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (inner.getvalue(),))
+
+    class Dotted:
+        def __reduce__(self):
+            return (torch._utils._import_dotted_name, ('os.system',))
+
+    class SerLoad:
+        def __reduce__(self):
+            return (torch.serialization.load, (str(tmp_path / 'evil.ckpt'),), {'weights_only': False})
+
+    for i, bad_obj in enumerate((Nested(), Dotted(), SerLoad())):
+        for proto in (2, 4):
+            f_ckpt, f_pkl = str(tmp_path / f'evil{i}_{proto}.ckpt'), str(tmp_path / f'evil{i}_{proto}.pkl')
+            torch.save({'state_dict': state, 'hyper_parameters': bad_obj}, f_ckpt, pickle_protocol=proto)
+            with open(f_pkl, 'wb') as f:
+                pickle.dump({'model': bad_obj}, f, protocol=proto)
+            loaded = checkpoint_io.load_checkpoint(f_ckpt)
+            assert isinstance(loaded['hyper_parameters'], checkpoint_io.Foreign)
+            assert torch.equal(loaded['state_dict']['score_model.mlp.0.weight'], state['score_model.mlp.0.weight'])
+            checkpoint_io.load_config_pickle(f_pkl)
+            assert not (tmp_path / 'pwned').exists()
+
 
 def test_missing_checkpoint_is_an_error_unless_opted_in():
     """dim_reduction.py:128 `load_from_checkpoint(None)` raises in the reference; random weights need an explicit opt-in."""
