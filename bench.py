@@ -327,7 +327,7 @@ class Workload:
 
 def timed_region(work, warmup, steps, dev):
     """W untimed points, then EXACTLY `steps` points between barrier + synchronize on both sides; the region includes the
-    path's one exchange step.  Returns (max-over-ranks seconds, spectra of ALL ranks' points in rank-major order)."""
+    path's one exchange step.  Returns (max-over-ranks seconds, spectra and int32 IDs of ALL ranks' points in point order)."""
     rank, world = parallel.rank_world()
     grouped = dist.is_available() and dist.is_initialized()
     for i in range(warmup):
@@ -345,8 +345,10 @@ def timed_region(work, warmup, steps, dev):
     for i in range(warmup, warmup + steps):
         work.point(i)
     local = work.collect()
+    # the integer ID of every point, by the reference's rule (float64 numpy on the host), on the rank that owns the point
+    dims = [plot_utils.estimate_dim(s.tolist()) for s in local.cpu()]
     # point p of the weak-scaling job = (rank p % world, its step p // world): parallel.gather_spectra's round-robin layout
-    allsv = parallel.gather_spectra(local, world * steps, local.shape[1], dev)
+    allsv, alldims = parallel.gather_spectra(local, world * steps, local.shape[1], dev, dims=dims)
     _sync(dev)
     if grouped:
         dist.barrier()
@@ -356,7 +358,7 @@ def timed_region(work, warmup, steps, dev):
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    return elapsed, allsv
+    return elapsed, allsv, alldims
 
 
 def main(argv=None, workload_factory=Workload):
@@ -381,7 +383,7 @@ def main(argv=None, workload_factory=Workload):
 
     work = workload_factory(args, rank, dev)
     with torch.no_grad():
-        elapsed, allsv = timed_region(work, args.warmup, args.steps, dev)
+        elapsed, allsv, alldims = timed_region(work, args.warmup, args.steps, dev)
     rows, D = work.rows, work.D
     line = None
     if dev.type == "cuda":
@@ -415,7 +417,11 @@ def main(argv=None, workload_factory=Workload):
                        "inflight_rows": args.inflight, "points_per_gpu": args.steps,
                        "parallelism": f"points sharded over {world} rank(s), one all-gather of spectra",
                        "process_group": dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None},
-            "id_estimates": ids, "model_tflops_per_gpu": rows * args.steps * 21.79e9 / elapsed / 1e12,
+            "id_estimates": ids, "id_estimates_all_ranks": alldims.tolist(),
+            # SURVEY 8(d)'s 21.79 GFLOP/eval counts the 3x3 convs as direct convolutions; the Winograd kernels EXECUTE 2.25x
+            # fewer multiply-adds on them (10.87 GFLOP/eval), which is why the first figure can exceed the fp32 MFMA peak
+            "model_tflops_per_gpu_direct_conv_equivalent": rows * args.steps * 21.79e9 / elapsed / 1e12,
+            "model_tflops_per_gpu_executed": rows * args.steps * 10.87e9 / elapsed / 1e12,
         }
         if dev.type == "cuda":
             line["svd_wall_clock_ms_per_point"] = svd_ms

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "idiff_symband_ld": (c_i, []),
     "idiff_symband_f64": (c_i, [c_p, c_i, c_p, c_p]),
     "idiff_symtridiag_f64": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "idiff_symtridiag_plan": (c_i, [c_i]),
     "idiff_tridiag_eigvals_f64": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
 }
 
@@ -383,7 +384,8 @@ def spectrum_workspace_bytes(P, M, D):
 def spectrum(S, workspace=None, return_eig=False, full=False):
     """Singular values (descending, fp32, min(M, D) of them as torch.linalg.svd gives) of the column-centred matrices
     S [P, M, D] or [M, D].  ``full=True`` keeps all D values of the Gram route (the drivers gather fixed-width rows and cut
-    each point's list to its own min(M, D) on the host)."""
+    each point's list to its own min(M, D) on the host).  ``return_eig=True`` adds the Gram eigenvalues behind them (fp64,
+    ASCENDING, the same count as the singular values: ``sv[i] == sqrt(max(eig[-1 - i], 0))``)."""
     _dev(S, "scores")
     squeeze = S.ndim == 2
     if squeeze:
@@ -401,10 +403,44 @@ def spectrum(S, workspace=None, return_eig=False, full=False):
            "idiff_spectrum_f32")
     if M < D and not full:
         sv = sv[:, :M].contiguous()           # the Gram route yields D values, the last D - M of them zeros up to rounding
+        if eig is not None:
+            eig = eig[:, D - M:].contiguous()  # ascending: the SAME M values as sv (sv[i]^2 = eig[M - 1 - i])
     if squeeze:
         sv = sv[0]
         eig = eig[0] if eig is not None else None
     return (sv, eig) if return_eig else sv
+
+
+def symtridiag_plan(D):
+    """0 LDS-resident, 1 two-stage + systolic chase, 2 two-stage + wavefront chase, 3 one-stage (include/idiff_hip.h)."""
+    return lib().idiff_symtridiag_plan(int(D))
+
+
+# The eigensolver never returns a silently wrong spectrum: a band-reduction residual above tolerance or a stalled systolic
+# chase (its workgroups wait on each other; a device that cannot keep them all resident stalls it) poisons the outputs
+# with NaN.  These are the slower forms that do not share the failure: tried in turn, in the same process.
+_FALLBACKS = (("IDIFF_CHASE_WAVEFRONT", "bulge chasing one launch per wavefront"),
+              ("IDIFF_TRIDIAG_ONESTAGE", "one-stage Householder sweep"))
+
+
+def resolve_failed_spectrum(S, full=False, log=None):
+    """``spectrum(S)`` came back with NaN: solve the same matrices again with the fallback forms of the eigensolver, on
+    the current stream.  Synchronises (the rare path).  Raises if S itself is non-finite or every form fails."""
+    import warnings
+    if not bool(torch.isfinite(S).all()):
+        raise RuntimeError("the score matrix holds non-finite values (NaN / inf score vectors): no spectrum exists")
+    for name, what in _FALLBACKS:
+        prev = set_option(name, 1)
+        try:
+            sv = spectrum(S, full=full)
+        finally:
+            set_option(name, prev)
+        if not bool(torch.isnan(sv).any()):
+            msg = f"id-diff_amd: the two-stage eigensolver reported a failure; spectrum re-solved with {what} ({name})"
+            (log or warnings.warn)(msg)
+            return sv
+    raise RuntimeError("the spectrum kernels reported a failure (NaN singular values) and so did the wavefront chase and the "
+                       "one-stage sweep")
 
 
 # ---- the stages of the spectrum, for the row-sharded single-point pipeline (dim_reduction.row_sharded_spectrum)

@@ -884,10 +884,11 @@ struct SysArgs {
   double *diag, *offd;        // [D]
   int *abort_flag;
   int D, Dp;
+  long spin_limit;            // polls before a waiting thread gives up (IDIFF_CHASE_SPIN_LIMIT; tests force the abort path with 1)
 };
 constexpr int MSG = BW + 1;           // doubles per message
 constexpr int GRAN = 2 * MSG;         // granules per message
-constexpr long SPIN_LIMIT = 1L << 24;
+constexpr long SPIN_LIMIT = 1L << 24;  // default of SysArgs::spin_limit: tens of seconds
 
 __device__ __forceinline__ unsigned long long *mailbox(const SysArgs &g, int node, int kind, int slot) {
   return g.mbox + (((int64_t)node * 2 + kind) * 2 + slot) * 128;
@@ -903,8 +904,9 @@ __device__ __forceinline__ void msg_send(unsigned long long *box, const double *
 }
 
 // threads [base, base + GRAN) wait for their granule of tag `tag` and put it into `dst` (LDS); a thread that gives up (the
-// abort word is set, or it sets it itself after SPIN_LIMIT polls) returns true
-__device__ __forceinline__ bool msg_recv(const unsigned long long *box, double *dst, unsigned tag, int *abort_flag, int base) {
+// abort word is set, or it sets it itself after spin_limit polls) returns true
+__device__ __forceinline__ bool msg_recv(const unsigned long long *box, double *dst, unsigned tag, int *abort_flag, int base,
+                                         long spin_limit) {
   const int i = (int)threadIdx.x - base;
   if (i >= 0 && i < GRAN) {
     long spins = 0;
@@ -914,7 +916,7 @@ __device__ __forceinline__ bool msg_recv(const unsigned long long *box, double *
       __builtin_amdgcn_s_sleep(1);                            // (polling without it measured the same)
       if ((++spins & 255) == 0) {
         if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
-        if (spins > SPIN_LIMIT) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
+        if (spins > spin_limit) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
       }
     }
   }
@@ -966,7 +968,7 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
     //      node t - 1 (threads 128 .. 193) are awaited side by side; node 0 makes its own reflector meanwhile
     if (s > 0) {
       const bool has = Dp - (s + (t + 1) * BW) >= 2;          // task (s - 1, t + 1) exists
-      if (has) { if (msg_recv(mailbox(g, t, 1, (s - 1) & 1), msg_in, (unsigned)s, g.abort_flag, 0)) ab = 1; }
+      if (has) { if (msg_recv(mailbox(g, t, 1, (s - 1) & 1), msg_in, (unsigned)s, g.abort_flag, 0, g.spin_limit)) ab = 1; }
       else if (tid < MSG) msg_in[tid] = 0.0;
     }
     if (t == 0) {
@@ -979,7 +981,7 @@ __global__ void __launch_bounds__(256) chase_systolic_kernel(SysArgs g) {
         if (lane == 0) { v[BW] = tl; if (s < g.D) g.offd[s] = alpha; }
       }
     } else {
-      if (msg_recv(mailbox(g, t, 0, s & 1), v, (unsigned)(s + 1), g.abort_flag, 128)) ab = 1;     // v[0 .. BW) and tau = v[BW]
+      if (msg_recv(mailbox(g, t, 0, s & 1), v, (unsigned)(s + 1), g.abort_flag, 128, g.spin_limit)) ab = 1;     // v[0 .. BW) and tau = v[BW]
     }
     __syncthreads();                                           // B1
     if (ab) break;                                             // uniform: written before the barrier
@@ -1225,18 +1227,45 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
   return launch_status("sbr_to_band");
 }
 
+// The systolic chase is a persistent kernel whose ceil((D + PAD - 2) / BW) workgroups wait on each other, so ALL of them
+// must be resident at once.  How many the device holds is asked of the runtime (99 VGPRs at 256 threads: 4 workgroups
+// per CU on gfx950, 1024 on 256 CUs) per device, and only HALF of it is used: the kernel runs on a side stream beside the
+// convolutions, a second chase may run in another stream or process, and a partitioned / CU-masked device exposes fewer
+// CUs than the part number suggests.  Beyond the limit the chase runs wavefront by wavefront (chase_kernel), which needs
+// no co-residency.  IDIFF_FAKE_CU_COUNT replaces the CU count (tests of this selection).
+int systolic_node_limit() {
+  static int per_cu[64], cus[64];                 // cached per device ordinal (0 = not asked yet)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  const int slot = dev & 63;
+  int n = __atomic_load_n(&per_cu[slot], __ATOMIC_ACQUIRE), c = __atomic_load_n(&cus[slot], __ATOMIC_ACQUIRE);
+  if (n == 0 || c == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, chase_systolic_kernel, 256, 0) != hipSuccess || n <= 0) return 0;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) return 0;
+    __atomic_store_n(&cus[slot], c, __ATOMIC_RELEASE);
+    __atomic_store_n(&per_cu[slot], n, __ATOMIC_RELEASE);
+  }
+  const int fake = option_value(OPT_FAKE_CU_COUNT);
+  if (fake > 0) c = fake;
+  return n * c / 2;
+}
+
+// 1: the single-launch systolic chase takes a D x D matrix on the current device, 0: the wavefront chase does
+int sbr_chase_is_systolic(int D) {
+  return !option(OPT_CHASE_WAVEFRONT) && ceil_div(D + PAD - 2, BW) <= systolic_node_limit();
+}
+
 // Stage 2: the band left in scratch by sbr_to_band -> diag / offd.
 int sbr_chase(int D, double *diag, double *offd, double *scratch, hipStream_t st) {
   double *AB = scratch;
   double *vs = AB + (int64_t)(D + PAD) * LDB;
   double *scal = scratch + sbr_scratch_doubles(D) - 16;     // [0] residual^2, [1] ||G||_F^2, [2] abort word
-  // the systolic form needs all its ceil((D + PAD - 2) / BW) workgroups resident at once (they wait on each other): with
-  // 256 threads and ~100 registers each the chip holds 8 per CU; stay well inside that and chase wavefront by wavefront beyond
-  constexpr int MAX_SYSTOLIC_NODES = 1024;                   // D <= 32768
-  if (!option(OPT_CHASE_WAVEFRONT) && ceil_div(D + PAD - 2, BW) <= MAX_SYSTOLIC_NODES) {
+  if (!option(OPT_CHASE_WAVEFRONT) && ceil_div(D + PAD - 2, BW) <= systolic_node_limit()) {
     SysArgs a;
     a.AB = AB; a.mbox = reinterpret_cast<unsigned long long *>(vs); a.diag = diag; a.offd = offd;
     a.abort_flag = reinterpret_cast<int *>(scal + 2); a.D = D; a.Dp = D + PAD;
+    const int spin_opt = option_value(OPT_CHASE_SPIN_LIMIT);
+    a.spin_limit = spin_opt > 0 ? spin_opt : SPIN_LIMIT;
     const int T = ceil_div(a.Dp - 2, BW);                    // nodes with at least one sweep
     hipError_t e = hipMemsetAsync(vs, 0, (size_t)T * 512 * sizeof(unsigned long long), st);
     if (e == hipSuccess) e = hipMemsetAsync(scal + 2, 0, sizeof(double), st);

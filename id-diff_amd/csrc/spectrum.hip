@@ -659,16 +659,28 @@ bisect_kernel(const double *__restrict__ diag, const double *__restrict__ offd, 
   const int tid = threadIdx.x;
   // Gershgorin interval
   double lo = INFINITY, hi = -INFINITY;
+  bool poisoned = false;                 // fmin / fmax DROP a NaN operand: a poisoned tridiagonal must be seen explicitly
   for (int i = tid; i < D; i += 256) {
     const double el = i > 0 ? e[i - 1] : 0.0, er = i + 1 < D ? e[i] : 0.0;
     const double r = fabs(el) + fabs(er);
+    poisoned |= !(fabs(d[i]) + r < INFINITY);
     lo = fmin(lo, d[i] - r);
     hi = fmax(hi, d[i] + r);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
   if ((tid & 63) == 0) { red[tid >> 6] = lo; red[4 + (tid >> 6)] = hi; }
-  __syncthreads();
+  if (__syncthreads_or(poisoned)) {
+    // the tridiagonalisation reported a failure (NaN / inf diag or offdiag: band-reduction residual, stalled chase, non-finite
+    // scores): every output of this matrix is NaN -- never a silently wrong spectrum (sqrt(fmax(NaN, 0)) would be 0)
+    const int jj = blockIdx.x * 256 + tid;
+    const double nanv = __longlong_as_double(0x7ff8000000000000ll);
+    if (jj < D) {
+      if (eig) eig[(int64_t)p * D + jj] = nanv;
+      if (sv) sv[(int64_t)p * D + jj] = (float)nanv;
+    }
+    return;
+  }
   lo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
   hi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
   const double span = fmax(fmax(fabs(lo), fabs(hi)), 1e-300);
@@ -766,16 +778,28 @@ bisect_tiled_kernel(const double *__restrict__ diag, const double *__restrict__ 
   const double *d = diag + (int64_t)p * D, *e = offd + (int64_t)p * D;
   const int tid = threadIdx.x;
   double lo = INFINITY, hi = -INFINITY;
+  bool poisoned = false;                 // fmin / fmax DROP a NaN operand: a poisoned tridiagonal must be seen explicitly
   for (int i = tid; i < D; i += 256) {
     const double el = i > 0 ? e[i - 1] : 0.0, er = i + 1 < D ? e[i] : 0.0;
     const double r = fabs(el) + fabs(er);
+    poisoned |= !(fabs(d[i]) + r < INFINITY);
     lo = fmin(lo, d[i] - r);
     hi = fmax(hi, d[i] + r);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
   if ((tid & 63) == 0) { red[tid >> 6] = lo; red[4 + (tid >> 6)] = hi; }
-  __syncthreads();
+  if (__syncthreads_or(poisoned)) {
+    // the tridiagonalisation reported a failure (NaN / inf diag or offdiag: band-reduction residual, stalled chase, non-finite
+    // scores): every output of this matrix is NaN -- never a silently wrong spectrum (sqrt(fmax(NaN, 0)) would be 0)
+    const int jj = blockIdx.x * 256 + tid;
+    const double nanv = __longlong_as_double(0x7ff8000000000000ll);
+    if (jj < D) {
+      if (eig) eig[(int64_t)p * D + jj] = nanv;
+      if (sv) sv[(int64_t)p * D + jj] = (float)nanv;
+    }
+    return;
+  }
   lo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
   hi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
   const double span = fmax(fmax(fabs(lo), fabs(hi)), 1e-300);
@@ -846,6 +870,7 @@ int64_t sbr_scratch_doubles(int D);                                             
 int sbr_tridiagonalize(double *G, int D, double *diag, double *offd, double *scratch, hipStream_t st);  // sbr.hip
 int sbr_to_band(double *G, int D, double *scratch, hipStream_t st);
 int sbr_band_ld();
+int sbr_chase_is_systolic(int D);
 }
 
 using namespace idiff;
@@ -940,6 +965,15 @@ IDIFF_API int idiff_symmetrize_upper_f64(double *G, int D, void *stream) {
   const int nb = ceil_div(D, 32);
   hipLaunchKernelGGL(symmetrize_upper_kernel, dim3(nb, nb), dim3(256), 0, (hipStream_t)stream, G, D);
   return launch_status("symmetrize_upper");
+}
+
+// Which tridiagonalisation idiff_symtridiag_f64 would run for a D x D matrix on the current device, given the switches:
+// 0 LDS-resident (D <= 128), 1 two-stage with the single-launch systolic chase, 2 two-stage with the wavefront chase
+// (too many nodes to be co-resident on this device, or IDIFF_CHASE_WAVEFRONT), 3 one-stage sweep (IDIFF_TRIDIAG_ONESTAGE).
+IDIFF_API int idiff_symtridiag_plan(int D) {
+  if (D <= SMALL_D_MAX) return 0;
+  if (option(OPT_TRIDIAG_ONESTAGE)) return 3;
+  return sbr_chase_is_systolic(D) ? 1 : 2;
 }
 
 IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double *offdiag, double *scratch, void *stream) {

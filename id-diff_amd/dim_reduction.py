@@ -30,6 +30,7 @@ from . import _lib, parallel
 from .lightning_data_modules.utils import create_lightning_datamodule
 from .lightning_modules.utils import create_lightning_module
 from .models import utils as mutils
+from .plot_utils import estimate_dim
 
 
 def batching(sample_shape, batchsize):
@@ -71,13 +72,20 @@ class ScoreMatrixBuilder:
         computes it).
 
         Noise: ``noise`` (explicit draws, for parity tests) > ``seed`` (in-kernel Philox stream, the default of the
-        drivers: independent of the launch-set size) > ``generator`` (torch.randn)."""
+        drivers: independent of the launch-set size; for D % 4 != 0 a torch generator keyed by the seed, same property) >
+        ``generator`` (torch.randn, consumed launch set by launch set: the caller owns reproducibility)."""
         _, _, rows = batching(tuple(x.shape), batchsize)
         D = x.numel()
         t = self.eps if t is None else t
         r_lo, r_hi = (0, rows) if row_range is None else row_range
-        if row_range is not None and noise is None and (seed is None or D % 4):
-            raise RuntimeError("a row range needs position-keyed noise: pass `seed` (and D % 4 == 0) or explicit `noise`")
+        if row_range is not None and noise is None and seed is None:
+            raise RuntimeError("a row range needs position-keyed noise: pass `seed` or explicit `noise`")
+        if noise is None and seed is not None and D % 4:
+            # the in-kernel Philox stream writes 16-byte groups (D % 4 == 0).  Other widths draw the point's WHOLE noise
+            # matrix from a generator keyed by the point seed and slice it: still a function of (seed, row, column) only,
+            # whatever the launch-set size, the row range or the number of ranks
+            noise = torch.randn(rows, D, device=self.device, dtype=torch.float32,
+                                generator=torch.Generator(device=self.device).manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF))
         S = torch.empty(r_hi - r_lo, D, device=self.device, dtype=torch.float32)
         step = self.rows_per_launch(rows, D, vector=x.ndim == 1)
         xf = x.reshape(-1).contiguous()
@@ -87,7 +95,7 @@ class ScoreMatrixBuilder:
             mean_unit, std = self.sde.marginal_prob(torch.ones((), device=self.device), vec_t)
             coeff = None if mean_unit.ndim == 0 else mean_unit.reshape(-1).contiguous()
             batch = torch.empty(n, D, device=self.device, dtype=torch.float32)
-            if noise is None and seed is not None and D % 4 == 0:
+            if noise is None and seed is not None:
                 _lib.perturb_randn(xf, std.contiguous(), coeff, batch, n, D, lo, seed)
             else:
                 if noise is not None:
@@ -118,19 +126,50 @@ class SpectrumPipeline:
         # evaluations instead of beside them (+35 ms per point under torch.distributed.run, same kernels, same durations).
         prio = int(os.environ.get("IDIFF_SIDE_STREAM_PRIORITY", "-1"))
         self.side = torch.cuda.Stream(device=device, priority=prio) if overlap else None
-        self.pending = []
+        self.pending = []         # [sv, S or None, pinned failure flag, event after the flag copy]: S is held until the flag is read
         self.deferred = None      # (S, ready event) of the last submitted point, not yet enqueued
+        self.resolved = 0         # spectra that needed a fallback form of the eigensolver (fail-soft, see _reap)
 
     def _launch(self, S, ready):
-        self.side.wait_event(ready)                      # S is complete on the producing stream
-        with torch.cuda.stream(self.side):
+        stream = self.side if self.side is not None else torch.cuda.current_stream()
+        if self.side is not None:
+            self.side.wait_event(ready)                  # S is complete on the producing stream
+        with torch.cuda.stream(stream):
             sv = _lib.spectrum(S, full=True)
-        S.record_stream(self.side)                       # keep S alive until the side stream is done with it
-        self.pending.append(sv)
+            # the eigensolver reports trouble as NaN; one flag per spectrum goes to pinned host memory so that the check
+            # costs no synchronisation: it is read once the event behind the copy has completed
+            flag = torch.empty(1, dtype=torch.bool, pin_memory=True)
+            flag.copy_(torch.isnan(sv).any().reshape(1), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        if self.side is not None:
+            S.record_stream(self.side)                   # keep S alive until the side stream is done with it
+        self.pending.append([sv, S, flag, done])
+
+    def _reap(self, block):
+        """Reads the failure flags of the spectra that have completed (all of them with ``block``).  A flagged spectrum is
+        solved again from its S -- still held for exactly this -- with the eigensolver's fallback forms
+        (``_lib.resolve_failed_spectrum``: wavefront chase, then the one-stage sweep) in this process; only a matrix
+        that defeats all three, or holds non-finite scores, raises."""
+        for entry in self.pending:
+            if entry[1] is None:
+                continue
+            if block:
+                entry[3].synchronize()
+            elif not entry[3].query():
+                break                                    # in stream order: later ones are not done either
+            if bool(entry[2][0]):
+                stream = self.side if self.side is not None else torch.cuda.current_stream()
+                with torch.cuda.stream(stream):
+                    entry[0] = _lib.resolve_failed_spectrum(entry[1], full=True,
+                                                            log=None if parallel.rank_world()[0] == 0 else (lambda msg: None))
+                self.resolved += 1
+            entry[1] = None
 
     def submit(self, S):
+        self._reap(block=False)
         if self.side is None:
-            self.pending.append(_lib.spectrum(S, full=True))
+            self._launch(S, None)
             return
         ready = torch.cuda.Event()
         ready.record()
@@ -139,13 +178,14 @@ class SpectrumPipeline:
             self._launch(*previous)
 
     def results(self):
-        """All submitted spectra, in order; joins the side stream into the current one."""
+        """All submitted spectra, in order, checked; joins the side stream into the current one."""
+        if self.side is not None and self.deferred is not None:
+            self._launch(*self.deferred)
+            self.deferred = None
+        self._reap(block=True)
         if self.side is not None:
-            if self.deferred is not None:
-                self._launch(*self.deferred)
-                self.deferred = None
             torch.cuda.current_stream().wait_stream(self.side)
-        out, self.pending = self.pending, []
+        out, self.pending = [e[0] for e in self.pending], []
         return out
 
 
@@ -156,8 +196,9 @@ def row_sharded_spectrum(S_local, total_rows, ops=None, block_rows=None):
     SURVEY.md 8(f) rank 2 / DESIGN.md 6: two collectives -- all-reduce of the fp64 column sums [D], all-reduce of the
     fp64 centred Gram [D, D] -- then the eigensolve, run redundantly on every rank (cheaper than shipping the result).
     The Gram (75 MB at D = 3072, 1.2 GB at D = 12288: bandwidth-bound on the xGMI ring) goes in blocks of ``block_rows``
-    rows of its upper triangle: the all-reduce of block b is asynchronous and runs while the matrix cores compute
-    block b + 1; the lower triangle is mirrored once at the end.  With one rank this is the same arithmetic as
+    rows of its upper triangle, each packed from its first diagonal tile onwards (0.6 GB in total at D = 12288): the
+    all-reduce of block b is asynchronous and runs while the matrix cores compute block b + 1; the lower triangle is
+    mirrored once at the end.  With one rank this is the same arithmetic as
     ``_lib.spectrum``.  ``ops`` = (column_sums, gram_rows, symmetrize, sym_eigvals) defaults to the HIP stages; the CPU
     process-group test injects plain-torch stand-ins to check the reduction logic without a GPU."""
     col_sums, gram_rows, symmetrize, eigvals = ops if ops is not None else (
@@ -171,15 +212,43 @@ def row_sharded_spectrum(S_local, total_rows, ops=None, block_rows=None):
         block_rows = max(64, ((D // 8 + 63) // 64) * 64)            # ~8 blocks: enough to hide all but the first Gram block
     G = torch.zeros(D, D, dtype=torch.float64, device=S_local.device)
     pending = []
+    grouped = parallel.is_grouped()
     for r0 in range(0, D, block_rows):
         r1 = min(D, r0 + block_rows)
         gram_rows(S_local, mean, G, r0, r1)
-        pending.append(parallel.all_reduce_sum_async(G[r0:r1]))       # rows of a row-major matrix: one contiguous chunk
-    for work in pending:
+        if not grouped:
+            continue
+        # only the columns from the block's first diagonal tile onwards carry data (the rest is mirrored afterwards):
+        # reduce that trapezoid, packed, not whole rows -- about half the bytes of a bandwidth-bound collective
+        c0 = (r0 // 128) * 128
+        staging = G[r0:r1, c0:].contiguous()
+        pending.append((parallel.all_reduce_sum_async(staging), staging, r0, r1, c0))
+    for work, staging, r0, r1, c0 in pending:
         parallel.wait(work)
+        G[r0:r1, c0:].copy_(staging)
     symmetrize(G)
+    keep = G.clone() if ops is None else None                        # the eigensolver overwrites its input
     eig = eigvals(G)
+    if keep is not None and bool(torch.isnan(eig).any()):            # fail soft (every rank takes the same branch: same G)
+        eig = _resolve_failed_eigvals(keep, eigvals)
     return eig.clamp_min(0.0).sqrt().flip(0).to(torch.float32)
+
+
+def _resolve_failed_eigvals(G, eigvals):
+    import warnings
+    if not bool(torch.isfinite(G).all()):
+        raise RuntimeError("the Gram matrix holds non-finite values (NaN / inf score vectors): no spectrum exists")
+    for name, what in _lib._FALLBACKS:
+        prev = _lib.set_option(name, 1)
+        try:
+            eig = eigvals(G.clone())
+        finally:
+            _lib.set_option(name, prev)
+        if not bool(torch.isnan(eig).any()):
+            if parallel.rank_world()[0] == 0:
+                warnings.warn(f"id-diff_amd: the two-stage eigensolver reported a failure; re-solved with {what} ({name})")
+            return eig
+    raise RuntimeError("the eigensolver reported a failure (NaN eigenvalues) in all of its three forms")
 
 
 def checked_spectra(spectra):
@@ -188,8 +257,8 @@ def checked_spectra(spectra):
     the values first reach the host, so this is where that turns into an exception."""
     host = spectra.cpu()
     if bool(torch.isnan(host).any()):
-        raise RuntimeError("the spectrum kernels reported a failure (NaN singular values): non-finite score vectors, or the "
-                           "two-stage eigensolver gave up -- rerun with IDIFF_TRIDIAG_ONESTAGE=1 to use the unblocked sweep")
+        raise RuntimeError("NaN singular values reached the host: a spectrum that did not come through SpectrumPipeline / "
+                           "row_sharded_spectrum (which re-solve a failed eigensolve in-process) reported a failure")
     return host
 
 
@@ -249,7 +318,10 @@ def collect_points(loader, num_datapoints):
     return pts
 
 
-def get_manifold_dimension(config, name=None, return_svd=False):
+def get_manifold_dimension(config, name=None, return_svd=False, return_dims=False):
+    """Drop-in for dim_reduction.py:116-215.  ``return_dims=True`` (not in the reference; needs ``return_svd``) also
+    returns the integer ID of every point, computed by the reference's rule on the rank that owns the point and gathered
+    as int32 in the same collective as the spectra."""
     log_path, log_name = config.logging.log_path, config.logging.log_name
     save_path = os.path.join(log_path, log_name, 'svd')
     rank, world = parallel.rank_world()
@@ -313,12 +385,14 @@ def get_manifold_dimension(config, name=None, return_svd=False):
             local = pipe.results()
     n_sv = points[0][0].numel()              # fixed-width rows for the exchange (a rank without points takes part too)
     local = torch.stack(local) if local else torch.empty(0, n_sv, device=device)
-    spectra = parallel.gather_spectra(local, len(points), n_sv, device)
     # torch.linalg.svd returns min(M, D) values per point (dim_reduction.py:197): a short loader batch gives a shorter list
     keep = [min(batching(tuple(x.shape), b)[2], x.numel()) for x, b in points]
+    # (the rule needs three singular values; -1 marks a point that has fewer)
+    my_dims = [estimate_dim(sv[:keep[p]].tolist()) if keep[p] >= 3 else -1 for sv, p in zip(checked_spectra(local), mine)]
+    spectra, dims = parallel.gather_spectra(local, len(points), n_sv, device, dims=my_dims)
     info = {'singular_values': [s[:k].tolist() for s, k in zip(checked_spectra(spectra), keep)]}
     if return_svd:
-        return info
+        return (info, dims.tolist()) if return_dims else info
     if rank == 0:
         with open(os.path.join(save_path, f'{name}.pkl'), 'wb') as f:
             pickle.dump(info, f)

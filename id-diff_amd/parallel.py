@@ -30,7 +30,8 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # IDIFF_DIST_BACKEND=gloo: several ranks sharing ONE card (tests on a one-GPU box; RCCL wants a GPU per rank)
+            backend = os.environ.get("IDIFF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -48,33 +49,49 @@ def rank_world():
     return 0, 1
 
 
+def is_grouped():
+    """True when a default process group exists -- also at world size 1, where the collectives still go through the
+    backend (a one-rank RCCL communicator on a one-GPU box runs the same code path as the N-GPU legs)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def my_points(num_points, rank, world):
     """Indices of the points this rank owns: round-robin, so results do not depend on the world size."""
     return list(range(rank, num_points, world))
 
 
-def gather_spectra(local, num_points, n_sv, device):
-    """All-gather per-rank spectra into point order.
+def gather_spectra(local, num_points, n_sv, device, dims=None):
+    """All-gather per-rank spectra into point order: ``[num_points, n_sv]`` fp32 on every rank.
 
     ``local``: [len(my_points), n_sv] fp32 on ``device``.  Ranks may own one point fewer than rank 0; rows are
-    padded to ``ceil(num_points / world)`` so a single fixed-size all-gather suffices.
-    """
+    padded to ``ceil(num_points / world)`` so a single fixed-size all-gather suffices.  ``dims`` (optional): this rank's
+    integer IDs, one per local point (``[P/W]`` int32 beside the spectra); they ride in the same
+    collective as one extra column holding the int32 bit patterns, and the call returns ``(spectra, dims)`` with ``dims``
+    an int32 tensor [num_points] in point order.
+
+    Point p = (rank p % world, its step p // world), so the gathered ``[world, per, n]`` block is put into point order by one
+    transposed copy on the device -- no per-rank host loop."""
     rank, world = rank_world()
-    if not (dist.is_available() and dist.is_initialized()):
-        return local
+    grouped = dist.is_available() and dist.is_initialized()
+    if dims is not None:
+        dims = torch.as_tensor(dims, dtype=torch.int32).reshape(-1)
+        if dims.numel() != local.shape[0]:
+            raise ValueError(f"gather_spectra: {dims.numel()} dims for {local.shape[0]} local spectra")
+    if not grouped:
+        return local if dims is None else (local, dims.to(device))
     per = (num_points + world - 1) // world
-    send = torch.zeros(per, n_sv, dtype=torch.float32, device=device)
+    width = n_sv + (1 if dims is not None else 0)
+    send = torch.zeros(per, width, dtype=torch.float32, device=device)
     if local.numel():
-        send[: local.shape[0]] = local
-    recv = torch.empty(world * per, n_sv, dtype=torch.float32, device=device)
+        send[: local.shape[0], :n_sv] = local
+        if dims is not None:
+            send[: local.shape[0], n_sv] = dims.to(device).view(torch.float32)
+    recv = torch.empty(world * per, width, dtype=torch.float32, device=device)
     dist.all_gather_into_tensor(recv, send)
-    recv = recv.view(world, per, n_sv)
-    out = torch.empty(num_points, n_sv, dtype=torch.float32, device=device)
-    for r in range(world):
-        idx = my_points(num_points, r, world)
-        if idx:
-            out[idx] = recv[r, : len(idx)]
-    return out
+    out = recv.view(world, per, width).transpose(0, 1).reshape(per * world, width)[:num_points]
+    if dims is None:
+        return out.contiguous()
+    return out[:, :n_sv].contiguous(), out[:, n_sv].contiguous().view(torch.int32)
 
 
 def my_rows(total_rows, rank, world):

@@ -36,7 +36,10 @@ const char *idiff_source_stamp(void);
 /* Debug / A-B switches, named like the environment variables that initialise them at load time:
  * IDIFF_NO_WINOGRAD (3x3 convs on the implicit GEMM), IDIFF_NO_COLSTATS, IDIFF_NO_PIPE, IDIFF_SCALAR_EPILOGUE,
  * IDIFF_DBUF_ONLY, IDIFF_TRIDIAG_ONESTAGE (per-column Householder instead of the two-stage band reduction),
- * IDIFF_UFD_ROWS.  Returns the previous value, -1 for an unknown name.  No reference counterpart. */
+ * IDIFF_UFD_ROWS, IDIFF_CHASE_WAVEFRONT (bulge chasing one launch per wavefront instead of the persistent systolic kernel),
+ * IDIFF_CHASE_SPIN_LIMIT (polls before a waiting node of the systolic chase gives up; default 2^24), IDIFF_FAKE_CU_COUNT
+ * (CU count used when sizing the systolic chase; tests).  Returns the previous value, -1 for an unknown name.
+ * No reference counterpart. */
 int idiff_set_option(const char *name, int value);
 
 /* ------------------------------------------------------------------ native ops (op/) */
@@ -240,6 +243,11 @@ int64_t idiff_symtridiag_scratch_doubles(int D);
 int idiff_symband_ld(void);
 int idiff_symband_f64(double *G, int D, double *scratch, void *stream);
 int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double *offdiag, double *scratch, void *stream);
+/* Which path idiff_symtridiag_f64 takes for a D x D matrix on the current device: 0 LDS-resident (D <= 128), 1 two-stage
+ * with the single-launch systolic bulge chase, 2 two-stage with the wavefront chase (the systolic kernel's
+ * ceil(D / 32) mutually waiting workgroups exceed HALF of what the device can hold resident -- asked of the
+ * runtime per device -- or IDIFF_CHASE_WAVEFRONT is set), 3 one-stage sweep (IDIFF_TRIDIAG_ONESTAGE). */
+int idiff_symtridiag_plan(int D);
 int idiff_tridiag_eigvals_f64(const double *diag, const double *offdiag, int P, int D, double *eig, void *stream);
 
 #ifdef __cplusplus

@@ -9,9 +9,17 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The GPU box shows every host core (os.cpu_count() = 256) but grants a 16-core share per GPU: the oracle's CPU kernels
+# with 256 threads on 16 cores run many times slower than with 16.  Cap the pools (also of spawned workers, via the env).
+_CORES = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+for _var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_var, str(_CORES))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    import torch
+    torch.set_num_threads(_CORES)
 
 
 def pytest_collection_modifyitems(config, items):

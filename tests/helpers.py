@@ -116,3 +116,78 @@ def replay_conditional_noise(seed, n_levels, n_points, num_batches, batch_shape,
             if level in keep_levels:
                 out[(level, point)] = z.reshape(num_batches * batch_shape[0], *batch_shape[1:])[:rows].clone()
     return out
+
+
+def fake_ml_collections():
+    """Classes pickling like ml_collections 0.1.0's (instance __dict__ with `_fields`, FieldReference with `_value`)
+    and like Lightning's AttributeDict (a dict subclass), under the module names a real checkpoint carries."""
+    import types
+    mods = {}
+    for name in ("ml_collections", "ml_collections.config_dict", "ml_collections.config_dict.config_dict",
+                 "pytorch_lightning", "pytorch_lightning.utilities", "pytorch_lightning.utilities.parsing"):
+        mods[name] = types.ModuleType(name)
+    cd = mods["ml_collections.config_dict.config_dict"]
+
+    class FieldReference:
+        def __init__(self, value):
+            self._value, self._field_type, self._ops, self._required = value, type(value), [], False
+
+    class MLConfigDict:
+        def __init__(self, **fields):
+            self.__dict__["_fields"] = fields
+            self.__dict__["_locked"] = False
+            self.__dict__["_type_safe"] = True
+            self.__dict__["_convert_dict"] = True
+
+    class AttributeDict(dict):
+        pass
+
+    for cls, mod in ((FieldReference, cd), (MLConfigDict, cd), (AttributeDict, mods["pytorch_lightning.utilities.parsing"])):
+        cls.__module__ = mod.__name__
+        cls.__qualname__ = cls.__name__ = {"MLConfigDict": "ConfigDict"}.get(cls.__name__, cls.__name__)
+        setattr(mod, cls.__name__, cls)
+    return mods, MLConfigDict, FieldReference, AttributeDict
+
+
+def to_foreign_config(cfg, MLConfigDict, FieldReference=None):
+    """The local ConfigDict as the ml_collections-shaped stand-in classes (nested), for writing artefacts the way the
+    authors' stack does; with ``FieldReference`` every float leaf is wrapped in one (ml_collections does that for
+    placeholders) so the reader's unwrapping is exercised."""
+    out = {}
+    for k, v in cfg.items():
+        if isinstance(v, ConfigDict):
+            out[k] = to_foreign_config(v, MLConfigDict, FieldReference)
+        elif FieldReference is not None and isinstance(v, float):
+            out[k] = FieldReference(v)
+        else:
+            out[k] = v
+    return MLConfigDict(**out)
+
+
+def write_lightning_artifacts(ckpt_path, score_model_state, cfg, cfg_pkl_path=None):
+    """A checkpoint shaped the way Lightning 1.5 writes the reference's (`state_dict` with `score_model.*` keys,
+    `hyper_parameters` = AttributeDict(config=ml_collections.ConfigDict), optimizer / callback entries) and, optionally,
+    the pickled bare config that `main.py --config x.pkl` reads (/root/reference/main.py:32-34).  The foreign module names
+    exist only while the files are written."""
+    import pickle
+    mods, MLConfigDict, FieldReference, AttributeDict = fake_ml_collections()
+    foreign = to_foreign_config(cfg, MLConfigDict, FieldReference)
+    state = {'score_model.' + k: v.detach().cpu().clone() for k, v in score_model_state.items()}
+    ckpt = {'epoch': 4, 'global_step': 1000, 'pytorch-lightning_version': '1.5.1', 'state_dict': state,
+            'hyper_parameters': AttributeDict(config=foreign), 'callbacks': {}, 'lr_schedulers': [],
+            'optimizer_states': [{'state': {0: {'step': 1000, 'exp_avg': torch.zeros(3)}}, 'param_groups': [{'lr': 2e-4}]}]}
+    saved = {k: sys.modules.get(k) for k in mods}
+    try:
+        sys.modules.update(mods)
+        os.makedirs(os.path.dirname(os.path.abspath(ckpt_path)), exist_ok=True)
+        torch.save(ckpt, ckpt_path)
+        if cfg_pkl_path is not None:
+            with open(cfg_pkl_path, 'wb') as f:
+                pickle.dump(foreign, f)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return ckpt_path

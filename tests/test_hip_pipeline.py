@@ -1,0 +1,398 @@
+"""GPU tests of the assembled pipelines: the authors' artefacts in (Lightning .ckpt, pickled config), spectra / IDs /
+figures out, BASELINE config 5 end to end, the fail-soft eigensolver and the multi-rank control flow on one card."""
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import id_diff_amd
+from helpers import (ncsnpp_config, overrides_from_golden, rel_err, state_dict_from_golden, write_lightning_artifacts)
+from id_diff_amd import _lib, dim_reduction, plot_utils, sde_lib
+from id_diff_amd.configs.config_dict import ConfigDict
+from id_diff_amd.configs.utils import read_config
+from id_diff_amd.models import utils as mutils
+from oracle import dim as odim, models as omodels, sde as osde
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+NET_RTOL = 2e-5
+_T0 = time.time()
+
+
+def _note(msg):
+    """Progress of the long tests on stderr (pytest -s / the captured log): the CPU oracle dominates their run time."""
+    print(f"[{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def _philox_rows(x, sde, t, seed, row0, n):
+    """The draws the in-kernel Philox stream gives rows [row0, row0 + n) of a point (csrc/rng.hip) and the perturbed
+    rows the HIP driver feeds the network, for handing the SAME draws to the oracle."""
+    D = x.numel()
+    vec_t = torch.full((n,), float(t), device=DEV)
+    mean_unit, std = sde.marginal_prob(torch.ones((), device=DEV), vec_t)
+    coeff = None if mean_unit.ndim == 0 else mean_unit.reshape(-1).contiguous()
+    batch, z = torch.empty(n, D, device=DEV), torch.empty(n, D, device=DEV)
+    _lib.perturb_randn(x.reshape(-1).contiguous(), std.contiguous(), coeff, batch, n, D, row0, seed, z_out=z)
+    return batch, z
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 5, assembled
+def test_config5_pipeline_end_to_end_vs_oracle(tmp_path):
+    """`get_manifold_dimension` on configs/.../styleGAN/style_gan_64d_BeatGAN.py (64x64x3 BeatGANs U-Net, 87.5 M
+    parameters, B = 128 -> S 16768 x 12288, svd_points = 3 -> 2 points) from a Lightning-shaped checkpoint:
+    * 64 rows of the device-built S (first and last launch set) against the oracle network on the same Philox draws,
+    * the spectrum of point 0 against an fp64 CPU SVD of the downloaded S at the north star's 1e-4, same integer ID,
+    * the pickle the driver wrote (dim_reduction.py:206-211)."""
+    cfg = read_config('configs/dimension_estimation/extra_experiments/styleGAN/style_gan_64d_BeatGAN.py')
+    cfg.data.data_samples = 160                       # 128 training images: one full loader batch (B = 128)
+    cfg.device = DEV
+    cfg.logging.log_path = str(tmp_path)
+    torch.manual_seed(0)
+    ref_model = omodels.create_model(cfg)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():                             # the zero-initialised out-convs would silence every residual branch
+        for prm in ref_model.parameters():
+            if float(prm.abs().sum()) == 0.0:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.02)
+    ref_model.eval()
+    cfg.model.checkpoint_path = write_lightning_artifacts(str(tmp_path / 'last.ckpt'), ref_model.state_dict(), cfg)
+
+    _note("config 5: oracle model + checkpoint written")
+    dim_reduction.get_manifold_dimension(cfg, name='svd_cfg5')
+    _note("config 5: driver done (2 points)")
+    with open(os.path.join(str(tmp_path), cfg.logging.log_name, 'svd', 'svd_cfg5.pkl'), 'rb') as f:
+        info = pickle.load(f)
+    assert list(info) == ['singular_values'] and len(info['singular_values']) == 2
+    assert all(isinstance(s, list) and len(s) == 12288 and isinstance(s[0], float) for s in info['singular_values'])
+
+    # the same point again, by hand: the driver's data order, weights and per-point seed
+    seed = int(cfg.get('seed', 42))
+    torch.manual_seed(seed)
+    DataModule, pl_module, score_fn, device = dim_reduction.setup_model(cfg)
+    points = dim_reduction.collect_points(DataModule.train_dataloader(), 3)
+    assert len(points) == 2 and points[0][1] == 128
+    x0 = points[0][0].to(DEV)
+    builder = dim_reduction.ScoreMatrixBuilder(score_fn, pl_module.sde, pl_module.sampling_eps, device)
+    with torch.no_grad():
+        S = builder.build(x0, 128, seed=seed + 1000003)
+    assert S.shape == (16768, 12288)
+    sv = _lib.spectrum(S).cpu()
+    np.testing.assert_allclose(sv.numpy(), np.array(info['singular_values'][0], dtype=np.float32), rtol=1e-6)
+
+    _note("config 5: point 0 rebuilt, spectrum equal to the driver's")
+    # rows of S against the oracle network on the same draws
+    sde_c = osde.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
+    score_ref = osde.get_score_fn(sde_c, ref_model)
+    for row0 in (0, 16768 - 32):
+        batch, z = _philox_rows(x0, pl_module.sde, pl_module.sampling_eps, seed + 1000003, row0, 32)
+        t = torch.full((32,), float(pl_module.sampling_eps))
+        mean, std = sde_c.marginal_prob(x0.cpu().unsqueeze(0).repeat(32, 1, 1, 1), t)
+        perturbed = mean + std[:, None, None, None] * z.cpu().view(32, 3, 64, 64)
+        torch.testing.assert_close(batch.cpu().view(32, 3, 64, 64), perturbed, rtol=2e-6, atol=2e-6)
+        with torch.no_grad():
+            ref_rows = score_ref(perturbed, t)
+        assert rel_err(S[row0:row0 + 32].cpu(), ref_rows.reshape(32, -1)) < NET_RTOL
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01          # N(0, 1) draws
+
+    _note("config 5: 64 rows agree with the oracle network; fp64 CPU SVD of 16768 x 12288 ...")
+    # spectrum against the fp64 CPU SVD of the SAME matrix (minutes on the box's 16 cores)
+    ref64 = odim.spectrum_f64(S.cpu()).numpy()
+    _note("config 5: fp64 SVD done")
+    keep = ref64 > 1e-5 * ref64[0]                    # the Gram route holds 1e-4 down to ~2e-6 sigma_max
+    assert keep.sum() > 12000
+    np.testing.assert_allclose(sv.numpy()[keep], ref64[keep], rtol=1e-4)
+    assert float(np.abs(sv.numpy() - ref64).max()) < 1e-6 * ref64[0]
+    assert plot_utils.estimate_dim(sv.tolist()) == odim.estimate_dim(ref64.tolist())
+    assert plot_utils.plot_dims(info)[1][0] == odim.estimate_dim(ref64.tolist())
+
+
+# ------------------------------------------------------------------------------------------ f1: artefacts in, figures out
+def _f1_config(tmp_path, z):
+    cfg = ncsnpp_config(**overrides_from_golden(z))
+    cfg.data.update(ConfigDict(datamodule='image_synthetic', data_samples=200, latent_dim=4, data_seed=0,
+                               split=[0.8, 0.1, 0.1], return_labels=False))
+    cfg.training.lightning_module = 'base'
+    cfg.logging = ConfigDict(log_path=str(tmp_path), log_name='run', svd_points=3, svd_frequency=5, save_svd=True)
+    cfg.dim_estimation = ConfigDict()
+    cfg.device = DEV
+    cfg.seed = 11
+    return cfg
+
+
+def test_lightning_ckpt_to_main_and_callback_on_gpu(golden, tmp_path):
+    """SURVEY 8(f) rank 1 on the GPU, nothing mocked: a Lightning-shaped `.ckpt` of the reference's own nf = 8 NCSN++
+    weights (golden fixture) and a pickled ml_collections-shaped config go through `main.py --mode manifold_dimension`
+    (/root/reference/main.py:17-71) and through `ScoreSpectrumVisualization.on_validation_epoch_end`
+    (lightning_callbacks/callbacks.py:403-432): the restored HIP model reproduces the REFERENCE's score, both entry points
+    give the same spectra, the logged `dim` is the mean of the oracle's IDs of those spectra, two images are logged."""
+    from id_diff_amd import main as cli
+    from id_diff_amd.lightning_callbacks import utils as cutils
+    from id_diff_amd.lightning_modules.utils import create_lightning_module
+    z = golden("ncsnpp_bench_init1.npz")
+    cfg = _f1_config(tmp_path, z)
+    ckpt = str(tmp_path / 'run' / 'checkpoints' / 'best' / 'last.ckpt')      # where the callback looks (callbacks.py:412)
+    cfg_pkl = str(tmp_path / 'config.pkl')
+    write_lightning_artifacts(ckpt, state_dict_from_golden(z), cfg, cfg_pkl)
+
+    # the checkpoint restored into the HIP model gives the reference's score
+    module = create_lightning_module(cfg).load_from_checkpoint(ckpt)
+    module.configure_sde(cfg)
+    module.to(DEV).eval()
+    score_fn = mutils.get_score_fn(module.sde, module.score_model, conditional=False, train=False, continuous=True)
+    y = score_fn(torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV))
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+
+    # CLI: pickled config + --checkpoint_path, pickle out
+    cli.main(['--config', cfg_pkl, '--mode', 'manifold_dimension', '--checkpoint_path', ckpt, '--log_name', 'svd_cli'])
+    with open(os.path.join(str(tmp_path), 'run', 'svd', 'svd_cli.pkl'), 'rb') as f:
+        from_cli = pickle.load(f)
+    assert len(from_cli['singular_values']) == 2 and all(len(s) == 3072 for s in from_cli['singular_values'])
+
+    # callback, un-mocked, both save_svd branches
+    class Experiment:
+        def __init__(self): self.images = []
+        def add_image(self, tag, img, step): self.images.append((tag, img, step))
+
+    class Module:
+        def __init__(self, config, epoch):
+            self.config, self.current_epoch, self.logged = config, epoch, {}
+            self.logger = type("L", (), {})()
+            self.logger.experiment = Experiment()
+        def log(self, key, value, **kw): self.logged[key] = value
+
+    cb = cutils.get_callback_by_name('ScoreSpectrumVisualization')()
+    for save_svd in (True, False):
+        cfg.logging.save_svd = save_svd
+        cfg.model.checkpoint_path = None                  # the callback points the config at last.ckpt itself
+        mod = Module(cfg, 4)
+        cb.on_validation_epoch_end(None, mod)
+        assert cfg.model.checkpoint_path == ckpt
+        tags = [t for t, _, _ in mod.logger.experiment.images]
+        assert tags == ['score specturm', 'dim_distribution']
+        assert all(img.shape[0] == 3 and img.dtype == torch.float32 and step == 4 for _, img, step in mod.logger.experiment.images)
+        oracle_dims = odim.estimate_dims(from_cli, mode='all')
+        assert mod.logged['dim'] == pytest.approx(float(np.mean(oracle_dims)))
+    with open(os.path.join(str(tmp_path), 'run', 'svd', 'svd_4.pkl'), 'rb') as f:
+        from_cb = pickle.load(f)
+    assert from_cb['singular_values'] == from_cli['singular_values']          # same checkpoint, data and seeds
+    quiet = Module(cfg, 2)
+    cb.on_validation_epoch_end(None, quiet)
+    assert not quiet.logger.experiment.images and not quiet.logged
+
+    # and the spectra themselves: point 0 rebuilt by hand against the oracle network + fp64 SVD
+    torch.manual_seed(cfg.seed)
+    DataModule, pl_module, score_fn, device = dim_reduction.setup_model(cfg)
+    points = dim_reduction.collect_points(DataModule.train_dataloader(), 3)
+    x0, B = points[0][0].to(DEV), points[0][1]
+    builder = dim_reduction.ScoreMatrixBuilder(score_fn, pl_module.sde, pl_module.sampling_eps, device)
+    with torch.no_grad():
+        S = builder.build(x0, B, seed=cfg.seed + 1000003)
+    ref_model = omodels.create_model(cfg)
+    ref_model.load_state_dict(state_dict_from_golden(z))
+    ref_model.eval()
+    sde_c = osde.VESDE(0.01, 50, 1000)
+    rows = S.shape[0]
+    batch, zz = _philox_rows(x0, pl_module.sde, pl_module.sampling_eps, cfg.seed + 1000003, 0, rows)
+    t = torch.full((rows,), 1e-5)
+    with torch.no_grad():
+        S_ref = torch.cat([osde.get_score_fn(sde_c, ref_model)(batch[i:i + 560].cpu().view(-1, 3, 32, 32), t[i:i + 560])
+                           for i in range(0, rows, 560)]).reshape(rows, -1)
+    assert rel_err(S.cpu(), S_ref) < NET_RTOL
+    sv = np.array(from_cli['singular_values'][0])
+    ref64 = odim.spectrum_f64(S.cpu()).numpy()
+    keep = ref64 > 1e-5 * ref64[0]
+    np.testing.assert_allclose(sv[keep], ref64[keep], rtol=1e-4)
+    bound = float(torch.linalg.matrix_norm(S.cpu().double() - S_ref.double(), ord=2))
+    assert float(np.abs(sv - odim.spectrum_f64(S_ref).numpy()).max()) <= 1.5 * bound + 1e-6 * ref64[0]
+
+
+def test_return_dims_and_every_rank_rule(tmp_path):
+    """`return_dims=True`: the int32 IDs that ride in the exchange equal the rule applied to the returned spectra."""
+    cfg = read_config('configs/dimension_estimation/paper/euclidean_data/ksphere/10dim.py')
+    cfg.model.name = 'ksphere_exact'
+    cfg.data.data_samples = 2000
+    cfg.device = DEV
+    cfg.logging.log_path = str(tmp_path)
+    svd, dims = dim_reduction.get_manifold_dimension(cfg, return_svd=True, return_dims=True)
+    assert dims == odim.estimate_dims(svd) == [10] * 4
+
+
+# ------------------------------------------------------------------------------------------ fail-soft eigensolver
+def _cliff_matrix(M, D, k, seed):
+    S = torch.randn(M, D, generator=torch.Generator().manual_seed(seed)) + 0.5
+    S[:, D - k:] *= 0.02
+    return S
+
+
+def test_stalled_chase_is_resolved_in_process():
+    """IDIFF_CHASE_SPIN_LIMIT = 1 makes every node of the systolic chase give up at its first long wait (what a device
+    that cannot keep all nodes resident would do after 2^24 polls): the plain call reports NaN, never a wrong spectrum;
+    `resolve_failed_spectrum` and `SpectrumPipeline` (with and without the side stream) solve the same matrix again with the
+    wavefront chase in this process and match the oracle."""
+    S_cpu = _cliff_matrix(1400, 1024, 37, 21)
+    S = S_cpu.to(DEV)
+    ref = odim.spectrum_f64(S_cpu).numpy()
+    good = _lib.spectrum(S).cpu().numpy()
+    np.testing.assert_allclose(good, ref, rtol=1e-4)
+    assert _lib.symtridiag_plan(1024) == 1
+    prev = _lib.set_option("IDIFF_CHASE_SPIN_LIMIT", 1)
+    try:
+        bad = _lib.spectrum(S)
+        assert bool(torch.isnan(bad).all())
+        with pytest.warns(UserWarning, match="IDIFF_CHASE_WAVEFRONT"):
+            fixed = _lib.resolve_failed_spectrum(S)
+        np.testing.assert_allclose(fixed.cpu().numpy(), ref, rtol=1e-4)
+        for overlap in (True, False):
+            pipe = dim_reduction.SpectrumPipeline(torch.device(DEV), overlap=overlap)
+            with pytest.warns(UserWarning, match="re-solved"):
+                pipe.submit(S)
+                pipe.submit(S * 2.0)
+                out = pipe.results()
+            assert pipe.resolved == 2 and len(out) == 2
+            np.testing.assert_allclose(out[0].cpu().numpy(), ref, rtol=1e-4)
+            np.testing.assert_allclose(out[1].cpu().numpy(), 2.0 * ref, rtol=1e-4)
+            assert plot_utils.estimate_dim(out[0].tolist()) == odim.estimate_dim(ref.tolist()) == 37
+    finally:
+        _lib.set_option("IDIFF_CHASE_SPIN_LIMIT", int(prev))
+    # a healthy pipeline resolves nothing, and non-finite scores are an error, not a fallback
+    pipe = dim_reduction.SpectrumPipeline(torch.device(DEV))
+    pipe.submit(S)
+    assert np.array_equal(pipe.results()[0].cpu().numpy(), good) and pipe.resolved == 0
+    S_nan = S.clone()
+    S_nan[5, 7] = float("nan")
+    pipe.submit(S_nan)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        pipe.results()
+
+
+def test_chase_form_follows_what_the_device_can_hold():
+    """The systolic chase needs all ceil(D / 32) workgroups resident at once; the limit is asked of the runtime per device
+    (occupancy x CU count, halved).  With a faked CU count the same matrices take the wavefront chase, same spectrum."""
+    assert _lib.symtridiag_plan(100) == 0
+    assert _lib.symtridiag_plan(3072) == 1 and _lib.symtridiag_plan(12288) == 1     # configs 3/4 and 5 on a whole MI355X
+    props = torch.cuda.get_device_properties(0)
+    per_cu = None
+    prev = _lib.set_option("IDIFF_FAKE_CU_COUNT", 8)
+    try:
+        # limit = per_cu * 8 / 2 nodes of 32 columns: find it from the plan and check it is a sane occupancy (1..8 per CU)
+        flips = [D for D in range(160, 2049, 32) if _lib.symtridiag_plan(D) == 2]
+        assert flips, "a device of 8 CUs cannot hold 64 nodes"
+        per_cu = (flips[0] - 32) // 32 * 2 // 8
+        assert 1 <= per_cu <= 8
+        assert _lib.symtridiag_plan(flips[0] - 32) == 1 and _lib.symtridiag_plan(3072) == 2
+        S_cpu = _cliff_matrix(1400, 1024, 37, 22)
+        assert _lib.symtridiag_plan(1024) == 2
+        sv = _lib.spectrum(S_cpu.to(DEV)).cpu().numpy()
+    finally:
+        _lib.set_option("IDIFF_FAKE_CU_COUNT", int(prev))
+    np.testing.assert_allclose(sv, odim.spectrum_f64(S_cpu).numpy(), rtol=1e-4)
+    assert _lib.symtridiag_plan(32 * per_cu * props.multi_processor_count // 2) == 1
+    assert _lib.symtridiag_plan(32 * per_cu * props.multi_processor_count // 2 + 64) == 2
+    prev = _lib.set_option("IDIFF_CHASE_WAVEFRONT", 1)
+    try:
+        assert _lib.symtridiag_plan(3072) == 2
+    finally:
+        _lib.set_option("IDIFF_CHASE_WAVEFRONT", int(prev))
+
+
+def test_eigenvalues_are_trimmed_like_the_singular_values():
+    S = torch.randn(40, 100, generator=torch.Generator().manual_seed(2)).to(DEV)
+    sv, eig = _lib.spectrum(S, return_eig=True)
+    assert sv.shape == (40,) and eig.shape == (40,)
+    torch.testing.assert_close(sv.double(), eig.clamp_min(0).sqrt().flip(0), rtol=1e-6, atol=1e-6)
+    sv, eig = _lib.spectrum(S, return_eig=True, full=True)
+    assert sv.shape == (100,) and eig.shape == (100,)
+
+
+def test_seeded_noise_for_widths_that_are_not_multiples_of_four():
+    """D % 4 != 0 cannot use the in-kernel Philox stream; with a seed the draws are still a function of (seed, row,
+    column) only: launch-set size and row range do not matter, another seed gives other draws."""
+    sde = sde_lib.VESDE(0.01, 4, 1000)
+    score_fn = lambda x, t: x * 3.0 - 1.0
+    x = torch.linspace(-1, 1, 101, device=DEV)
+    mats = []
+    for inflight in (None, 7, 64):
+        b = dim_reduction.ScoreMatrixBuilder(score_fn, sde, 1e-5, torch.device(DEV), inflight_rows=inflight)
+        mats.append(b.build(x, 50, seed=5))                       # ambient 1 -> 4 batches, extra 1 -> 151 rows
+    assert mats[0].shape == (151, 101) and all(torch.equal(m, mats[0]) for m in mats[1:])
+    part = b.build(x, 50, seed=5, row_range=(40, 97))
+    assert torch.equal(part, mats[0][40:97])
+    assert not torch.equal(b.build(x, 50, seed=6), mats[0])
+    z = (mats[0] + 1.0) / 3.0 - x                                  # = std * noise
+    assert abs(float(z.mean())) < 0.05 * 0.01 and abs(float(z.std()) / 0.01 - 1.0) < 0.05
+
+
+# ------------------------------------------------------------------------------------------ multi-rank control flow on one card
+def _bench_two_ranks_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      IDIFF_DIST_BACKEND="gloo")     # two processes on the one card: RCCL wants a GPU per rank
+    import bench
+    line = bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    q.put((rank, line))
+
+
+def test_bench_main_two_ranks_real_workload_one_gpu():
+    """bench.main() with the REAL config-3 workload at world size 2 (two processes sharing this card, gloo moving the
+    device tensors): barrier / timed region / exchange of spectra and int32 IDs / all-reduce-MAX of the time / rank-0-only
+    instrumented pass and JSON line, all with GPU tensors."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_two_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[1] is None
+    line = got[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak" and line["config"]["process_group"] == "gloo"
+    assert line["value"] == pytest.approx(2 * 4480 / (line["ms_per_step"] * 1e-3), rel=1e-6)
+    assert len(line["id_estimates_all_ranks"]) == 2 and line["id_estimates_all_ranks"][0] == line["id_estimates"][0]
+    assert line["roofline"] is not None and line["roofline"]["kernel"].startswith("winograd_kernel")
+    assert 0.3 < line["roofline"]["frac"] < 1.0 and line["svd_wall_clock_ms_per_point"] > 0
+
+
+def _rows_rccl_worker(port, q):
+    """ONE rank with a real RCCL communicator: the row-sharded spectrum's staged, asynchronous all-reduces go through
+    RCCL's stream semantics (the collective runs on the communicator's stream, `wait` joins it into the compute stream)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    import id_diff_amd  # noqa: F401
+    from id_diff_amd import dim_reduction as dr, parallel
+    from oracle import dim as od
+    parallel.init_from_env()
+    backend = dist.get_backend()
+    S_cpu = _cliff_matrix(900, 384, 20, 23)
+    sv = dr.row_sharded_spectrum(S_cpu.to("cuda"), 900, block_rows=64)        # six staged trapezoids in flight
+    err = float(np.abs(sv.cpu().numpy() / od.spectrum_f64(S_cpu).numpy() - 1.0).max())
+    local = sv.unsqueeze(0)
+    gathered, dims = parallel.gather_spectra(local, 1, 384, torch.device("cuda"), dims=[20])
+    q.put((backend, err, bool(torch.equal(gathered, local)), dims.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_spectrum_and_exchange_on_one_rank_rccl():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rows_rccl_worker, args=(39500 + (os.getpid() % 2000), q))
+    p.start()
+    backend, err, same, dims = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert backend == "nccl" and err < 1e-4 and same and dims == [20]

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import id_diff_amd
-from helpers import beatgans_config, ddpm_config, fcn_config, ncsnpp_config
+from helpers import beatgans_config, ddpm_config, fake_ml_collections, fcn_config, ncsnpp_config
 from id_diff_amd import dim_reduction, parallel, plot_utils, sde_lib
 from id_diff_amd.configs.config_dict import ConfigDict
 from id_diff_amd.configs.utils import read_config
@@ -241,37 +241,6 @@ def test_image_folder_datamodule(tmp_path):
         dutils.create_lightning_datamodule(cfg).setup()
 
 
-def _fake_ml_collections():
-    """Classes pickling like ml_collections 0.1.0's (instance __dict__ with `_fields`, FieldReference with `_value`)
-    and like Lightning's AttributeDict (a dict subclass), under the module names a real checkpoint carries."""
-    import types
-    mods = {}
-    for name in ("ml_collections", "ml_collections.config_dict", "ml_collections.config_dict.config_dict",
-                 "pytorch_lightning", "pytorch_lightning.utilities", "pytorch_lightning.utilities.parsing"):
-        mods[name] = types.ModuleType(name)
-    cd = mods["ml_collections.config_dict.config_dict"]
-
-    class FieldReference:
-        def __init__(self, value):
-            self._value, self._field_type, self._ops, self._required = value, type(value), [], False
-
-    class MLConfigDict:
-        def __init__(self, **fields):
-            self.__dict__["_fields"] = fields
-            self.__dict__["_locked"] = False
-            self.__dict__["_type_safe"] = True
-            self.__dict__["_convert_dict"] = True
-
-    class AttributeDict(dict):
-        pass
-
-    for cls, mod in ((FieldReference, cd), (MLConfigDict, cd), (AttributeDict, mods["pytorch_lightning.utilities.parsing"])):
-        cls.__module__ = mod.__name__
-        cls.__qualname__ = cls.__name__ = {"MLConfigDict": "ConfigDict"}.get(cls.__name__, cls.__name__)
-        setattr(mod, cls.__name__, cls)
-    return mods, MLConfigDict, FieldReference, AttributeDict
-
-
 def test_lightning_checkpoint_round_trip(tmp_path, monkeypatch):
     """A checkpoint shaped the way Lightning writes the reference's (BaseSdeGenerativeModel.py:17 save_hyperparameters:
     `score_model.*` keys + a pickled ml_collections.ConfigDict) loads with strict=True although neither ml_collections nor
@@ -280,7 +249,7 @@ def test_lightning_checkpoint_round_trip(tmp_path, monkeypatch):
     from id_diff_amd.lightning_modules import checkpoint_io
     from id_diff_amd.lightning_modules.utils import create_lightning_module
     from id_diff_amd.models import utils as mutils
-    mods, MLConfigDict, FieldReference, AttributeDict = _fake_ml_collections()
+    mods, MLConfigDict, FieldReference, AttributeDict = fake_ml_collections()
     cfg = fcn_config(hidden_nodes=32, hidden_layers=2)
     cfg.training.lightning_module = 'base'
     torch.manual_seed(3)

@@ -22,6 +22,9 @@ def _worker(rank, world, port, num_points, n_sv, q):
     local = torch.stack([torch.arange(n_sv, dtype=torch.float32) + 100.0 * p for p in mine]) if mine \
         else torch.empty(0, n_sv)
     out = parallel.gather_spectra(local, num_points, n_sv, torch.device("cpu"))
+    # the same exchange with the per-point integer IDs riding along as int32 bit patterns
+    out2, dims = parallel.gather_spectra(local, num_points, n_sv, torch.device("cpu"), dims=[7 * p + 3 for p in mine])
+    assert torch.equal(out, out2) and dims.dtype == torch.int32 and dims.tolist() == [7 * p + 3 for p in range(num_points)]
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -151,5 +154,6 @@ def test_bench_main_two_ranks_gloo(capfd):
     assert line["config"]["process_group"] == "gloo" and line["config"]["rows_per_point"] == 12
     assert line["value"] == pytest.approx(2 * 3 * 12 / (line["ms_per_step"] * 3e-3), rel=1e-6)
     assert line["id_estimates"] == [2, 2, 2]          # rank 0's three timed points: the cliff 30 -> 2 leaves two small values
+    assert line["id_estimates_all_ranks"] == [2] * 6  # every rank's IDs, computed where the spectrum lives, one collective
     printed = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
     assert len(printed) == 1 and json.loads(printed[0])["metric"] == line["metric"]
