@@ -14,7 +14,8 @@ Passes, in order:
   1. warm-up (W points), then the TIMED region (K points, no instrumentation)            -> value, ms_per_step
   2. the same K points again with HIP events around the instrumented launches (rank 0)   -> roofline, roofline.kernels
   3. the spectrum stages of one point, alone on the device                                -> svd_wall_clock_ms_per_point
-  4. cpu_baseline: the oracle on this box's host cores, bounded sample (rank 0, N = 1)
+  4. extra.cfg2 / extra.cfg5: KSphere + fcn and 64x64 BeatGANs side measurements (rank 0, N = 1, seconds each)
+  5. cpu_baseline: the oracle on this box's host cores, bounded sample (rank 0, N = 1)
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -200,11 +201,11 @@ def roofline_report(probe):
             "kernels": kernels}
 
 
-def spectrum_stage_report(rows, D, dev):
+def spectrum_stage_report(rows, D, dev, reps=3):
     """The spectrum of one point alone on the device, stage by stage (events on the launch stream)."""
     S = torch.randn(rows, D, device=dev)
 
-    def timed(fn, reps=3):
+    def timed(fn, reps=reps):
         fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -226,7 +227,7 @@ def spectrum_stage_report(rows, D, dev):
     stages = [
         {"kernel": "gram_big_kernel + mirror pass (fp64 centred Gram, upper-triangular 128x128 tiles, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": rows * D * D / (gram_ms * 1e-3) / 1e12,
          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rows * D * D / (gram_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms": gram_ms},
-        {"kernel": "band reduction, stage 1 of the eigensolver (11 launches per 32-column panel; latency-bound at D = 3072)", "bound": "hbm",
+        {"kernel": "band reduction, stage 1 of the eigensolver (launches per 32-column panel: see DESIGN 4.2; latency-bound at D = 3072)", "bound": "hbm",
          "achieved": 24.0 * m2 / (band_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": 24.0 * m2 / (band_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": band_ms},
         {"kernel": "systolic bulge chasing + Sturm bisection (one persistent launch; a chain of 2D dependent steps)", "bound": "latency",
@@ -235,12 +236,111 @@ def spectrum_stage_report(rows, D, dev):
     return whole, stages
 
 
+LDS_PEAK_GBS = 150000.0      # MI355X_MICROARCH.md, LDS: ~150 TB/s aggregate for ds_read_b64 / b128 with every CU streaming
+
+
+def _events_ms(fn, reps=3):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def extra_cfg2(dev):
+    """BASELINE config 2 (north_star: "throughput on synthetic KSphere"): the 50-sphere in R^100, random-weight fcn 2048 x 5,
+    B = 500 -> S 1501 x 100 per point.  (i) the drop-in driver end to end on P = 512 points (points batched per launch set,
+    batched spectrum kernel), (ii) 4096 batched spectra of 1501 x 100, (iii) the LDS-resident tridiagonalisation alone."""
+    cfg = read_config('configs/dimension_estimation/paper/euclidean_data/ksphere/50dim.py')
+    cfg.model.allow_random_init = True
+    cfg.device = str(dev)
+    cfg.data.data_samples = 8000
+    cfg.dim_estimation.num_datapoints = 513                       # the reference's loop stops one short: 512 points
+    dim_reduction.get_manifold_dimension(cfg, return_svd=True)    # first call: data / model set-up, allocator warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    svd = dim_reduction.get_manifold_dimension(cfg, return_svd=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    P = len(svd['singular_values'])
+    M, D, NP = 1501, 100, 4096
+    S = torch.randn(NP, M, D, device=dev)
+    spectra_ms = _events_ms(lambda: _lib.spectrum(S))
+    mean = torch.empty(NP, D, dtype=torch.float64, device=dev)
+    scratch = torch.empty(NP * 32 * D, dtype=torch.float64, device=dev)
+    G = torch.empty(NP, D, D, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    lib = _lib.lib()
+    lib.idiff_colmean_f64(S.data_ptr(), NP, M, D, mean.data_ptr(), scratch.data_ptr(), st)
+    gram_ms = _events_ms(lambda: lib.idiff_centered_gram_f64(S.data_ptr(), mean.data_ptr(), NP, M, D, G.data_ptr(), st))
+    diag, offd = torch.empty(NP, D, dtype=torch.float64, device=dev), torch.empty(NP, D, dtype=torch.float64, device=dev)
+    G2 = G.clone()
+    clone_ms = _events_ms(lambda: G2.copy_(G))
+
+    def tri():
+        G2.copy_(G)                                               # the kernel overwrites its input
+        lib.idiff_symtridiag_f64(G2.data_ptr(), NP, D, diag.data_ptr(), offd.data_ptr(), None, st)
+    tri_ms = _events_ms(tri) - clone_ms
+    # Householder step k on a trailing block of n = D - k - 1: symv reads n^2 doubles, the rank-2 update reads and writes
+    # them: 24 n^2 bytes of LDS traffic -> ~8 D^3 bytes per matrix; HBM: the 8 D^2-byte matrix once
+    lds_bytes = NP * 24.0 * sum((D - k - 1) ** 2 for k in range(D - 2))
+    del S, G, G2, scratch
+    return {"workload": "KSphere 50-sphere in R^100, random-weight fcn 2048x5, VE-SDE t=1e-5, B=500 -> S 1501x100 per point",
+            "points": P, "driver_seconds": dt, "evals_per_s_end_to_end": P * M / dt,
+            "id_estimates_min_max": [int(min(plot_utils.plot_dims(svd)[1])), int(max(plot_utils.plot_dims(svd)[1]))],
+            "batched_spectra": {"matrices": NP, "shape": [M, D], "ms": spectra_ms},
+            "kernels": [
+                {"kernel": "gram_kernel (fp64 centred Gram, 64x64 tiles, 4096 matrices per launch)", "bound": "mfma",
+                 "achieved": NP * M * D * D / (gram_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": NP * M * D * D / (gram_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms": gram_ms,
+                 "hbm_gbs": 4.0 * NP * M * D / (gram_ms * 1e-3) / 1e9},
+                {"kernel": "tridiag_small_kernel (one workgroup per 100x100 matrix, Householder in LDS)", "bound": "lds",
+                 "achieved": lds_bytes / (tri_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                 "frac": lds_bytes / (tri_ms * 1e-3) / 1e9 / LDS_PEAK_GBS, "ms": tri_ms,
+                 "hbm_gbs": 8.0 * NP * D * D / (tri_ms * 1e-3) / 1e9}]}
+
+
+def extra_cfg5(dev):
+    """BASELINE config 5 on one GPU: the 64x64x3 BeatGANs U-Net (87.5 M parameters, random weights with the zero-initialised
+    convs randomised) score evaluations, and the spectrum of one 16768 x 12288 score matrix, stage by stage."""
+    cfg = read_config('configs/dimension_estimation/extra_experiments/styleGAN/style_gan_64d_BeatGAN.py')
+    torch.manual_seed(0)
+    model = mutils.create_model(cfg)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for prm in model.parameters():
+            if float(prm.abs().sum()) == 0.0:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.02)
+    model = model.to(dev).eval()
+    sde, eps = sde_lib.configure_sde(cfg)
+    score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
+    rows_launch = (2240 * 3072) // (3 * 64 * 64)                  # the driver's launch-set size for this sample size (560)
+    x = torch.rand(rows_launch, 3, 64, 64, device=dev)
+    t = torch.full((rows_launch,), float(eps), device=dev)
+    with torch.no_grad():
+        fwd_ms = _events_ms(lambda: score_fn(x, t), reps=2)
+        del model, score_fn, x
+        torch.cuda.empty_cache()
+        rows, D = dim_reduction.batching((3, 64, 64), cfg.training.batch_size)[2], 3 * 64 * 64
+        whole_ms, stages = spectrum_stage_report(rows, D, dev, reps=1)
+    evals = rows_launch / (fwd_ms * 1e-3)
+    return {"workload": "StyleGAN-64d-shaped 64x64x3, BeatGANsUNetModel ch128 mult(1,1,2,3,4), VE-SDE t=1e-5, B=128 -> S 16768x12288",
+            "score_evals_per_s": evals, "rows_per_launch": rows_launch, "ms_per_launch_set": fwd_ms,
+            "model_tflops_direct_conv_equivalent": evals * 37.43e9 / 1e12,
+            "svd_wall_clock_ms_per_point": whole_ms,
+            "evals_per_s_one_point_no_overlap": rows / (rows / evals + whole_ms * 1e-3),
+            "kernels": stages}
+
+
 def cpu_baseline(cfg, rows_per_point, D, S_gpu):
     """the oracle (CPU restatement of the reference path) on this box's host cores, bounded sample.
 
     score_fn both under no_grad and with autograd enabled (the reference never disables it, dim_reduction.py:183);
     ``torch.linalg.svd`` with full matrices exactly as dim_reduction.py:197 and ``svdvals`` as the fair floor, both on
-    the S the GPU path consumed for its last timed point; median of 5 after one warm-up each."""
+    the S the GPU path consumed for its last timed point; medians after one warm-up each."""
     from oracle import models as omodels, sde as osde
     # the GPU box exposes every host core (os.cpu_count() = 256) but grants a 16-core share per GPU:
     # oversubscribing the share makes the CPU run arbitrarily slow, so use the share
@@ -255,10 +355,10 @@ def cpu_baseline(cfg, rows_per_point, D, S_gpu):
     model = omodels.create_model(cfg)
     score_fn = osde.get_score_fn(osde.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales), model)
 
-    def median_rate(n, grad):
+    def median_rate(n, grad, reps):
         x, t = torch.rand(n, 3, 32, 32), torch.full((n,), 1e-5)
         times = []
-        for rep in range(6):
+        for rep in range(reps + 1):
             t0 = time.perf_counter()
             if grad:
                 score_fn(x, t).detach()
@@ -270,8 +370,10 @@ def cpu_baseline(cfg, rows_per_point, D, S_gpu):
                   file=sys.stderr, flush=True)
         return n / statistics.median(times[1:])
 
-    nograd = median_rate(16, False)
-    withgrad = median_rate(8, True)
+    # the reference evaluates B = 128 rows per call (dim_reduction.py:167-183): time that batch shape
+    B = int(cfg.training.batch_size)
+    nograd = median_rate(B, False, 2)
+    withgrad = median_rate(B, True, 2)
     S = S_gpu.cpu()
     c = S - S.mean(0, keepdim=True)
 
@@ -289,8 +391,9 @@ def cpu_baseline(cfg, rows_per_point, D, S_gpu):
     as_reference = rows_per_point / (rows_per_point / withgrad + svd_full)
     floor = rows_per_point / (rows_per_point / nograd + svd_vals)
     return {"value": as_reference, "unit": "score-vector evals/s", "cores": cores, "cpu_model": model_name, "kind": "port",
-            "sample": f"oracle NCSN++ score_fn, median of 5 after 1 warm-up: autograd on (as the reference runs, dim_reduction.py:183) "
-                      f"{withgrad:.2f} evals/s on batches of 8, no_grad {nograd:.2f} evals/s on batches of 16; torch.linalg.svd "
+            "sample": f"oracle NCSN++ score_fn on batches of B = {B} rows (the reference's batch shape), median of 2 after 1 warm-up: "
+                      f"autograd on (as the reference runs, dim_reduction.py:183) {withgrad:.2f} evals/s, no_grad {nograd:.2f} "
+                      f"evals/s; torch.linalg.svd "
                       f"(full matrices, dim_reduction.py:197) {svd_full:.2f} s and svdvals {svd_vals:.2f} s, median of 3, on the "
                       f"{rows_per_point}x{D} S of the last timed GPU point; per-point rates extrapolated",
             "score_evals_per_s_autograd": withgrad, "score_evals_per_s_no_grad": nograd, "svd_full_s": svd_full,
@@ -370,6 +473,7 @@ def main(argv=None, workload_factory=Workload):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run each point's spectrum on the main stream")
     ap.add_argument("--no-probe", action="store_true", help="skip the instrumented second pass (roofline = null)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config-2 / config-5 side measurements (extra = null)")
     ap.add_argument("--device", default=None, help="(tests) 'cpu' with a stand-in workload")
     args = ap.parse_args(argv)
 
@@ -426,6 +530,14 @@ def main(argv=None, workload_factory=Workload):
         if dev.type == "cuda":
             line["svd_wall_clock_ms_per_point"] = svd_ms
             line["roofline"] = roofline
+            if world == 1 and not args.no_extras:
+                # the other workloads north_star names, each bounded to a few seconds; not part of `value`
+                last_S, work.last_S = work.last_S, None
+                del work.model, work.builder, work.pipe
+                torch.cuda.empty_cache()
+                with torch.no_grad():
+                    line["extra"] = {"cfg2": extra_cfg2(dev), "cfg5": extra_cfg5(dev)}
+                work.last_S = last_S
             if world == 1 and not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(work.cfg, rows, D, work.last_S)
         print(json.dumps(line))

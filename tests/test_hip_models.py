@@ -322,6 +322,19 @@ def test_driver_row_sharded_matches_point_sharded(tmp_path):
     for rank in (0, 1):
         np.testing.assert_allclose(np.array(got[rank]), np.array(ref['singular_values']), rtol=2e-5, atol=1e-5)
         assert plot_utils.plot_dims({'singular_values': got[rank]})[1] == [10] * 4
+    # not only the HIP path against itself: point 0's score matrix rebuilt here (driver's data order and per-point seed)
+    # and handed to the oracle's CPU SVD -- the row-sharded spectrum holds 1e-4 against it, and the oracle's ID is 10 too
+    torch.manual_seed(int(cfg.get('seed', 42)))
+    DataModule, pl_module, score_fn, device = dim_reduction.setup_model(cfg)
+    points = dim_reduction.collect_points(DataModule.train_dataloader(), dim_reduction._num_datapoints(cfg))
+    builder = dim_reduction.ScoreMatrixBuilder(score_fn, pl_module.sde, pl_module.sampling_eps, device)
+    S0 = builder.build(points[0][0].to(DEV), points[0][1], seed=int(cfg.get('seed', 42)) + 1000003).cpu()
+    ref32, ref64 = odim.spectrum(S0), odim.spectrum_f64(S0)
+    for rank in (0, 1):
+        sv0 = np.array(got[rank][0])
+        np.testing.assert_allclose(sv0, ref32.numpy(), rtol=1e-4)
+        np.testing.assert_allclose(sv0, ref64.numpy(), rtol=1e-4)
+    assert odim.estimate_dim(ref32.tolist()) == 10
 
 
 def test_winograd_and_implicit_gemm_paths_agree_on_the_spectrum():

@@ -321,9 +321,11 @@ def _rows_gpu_worker(rank, world, port, q):
     import id_diff_amd  # noqa: F401
     from id_diff_amd import _lib as lib, dim_reduction, parallel, sde_lib
     from id_diff_amd.models import utils as mutils
+    from id_diff_amd.plot_utils import estimate_dim as plot_utils_dim
     from helpers import fcn_config
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     torch.cuda.set_device(0)
+    torch.set_num_threads(8)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # two processes on the one card: gloo moves
     dev = torch.device("cuda:0")                                           # the device tensors, RCCL needs a GPU per rank
     cfg = fcn_config()
@@ -342,14 +344,29 @@ def _rows_gpu_worker(rank, world, port, q):
         S_full = builder.build(x, bs, seed=77)
         ok_rows = bool(torch.equal(S_full[lo:hi], S_local))
         ref = lib.spectrum(S_full)
-    q.put((rank, ok_rows, float((sv - ref).abs().max() / ref.abs().max())))
+        # ... and against the ORACLE (fp32 CPU SVD as the reference path, and its fp64 yardstick) of the full matrix
+        from oracle import dim as od
+        ref32, ref64 = od.spectrum(S_full.cpu()), od.spectrum_f64(S_full.cpu())
+        keep = ref64 > 2e-5 * ref64[0]
+        err32 = float(((sv.cpu() - ref32).abs() / ref32)[keep].max())
+        err64 = float(((sv.cpu().double() - ref64).abs() / ref64)[keep].max())
+        same_id = plot_utils_dim(sv.tolist()) == od.estimate_dim(ref32.tolist())
+        # a wider matrix (D = 384: six row blocks, packed trapezoids of the upper triangle in flight), same seed on both ranks
+        g = torch.Generator().manual_seed(19)
+        T_cpu = torch.randn(900, 384, generator=g) * torch.linspace(0.05, 2.0, 384) + 0.4
+        a, b = parallel.my_rows(900, rank, world)
+        sv_t = dim_reduction.row_sharded_spectrum(T_cpu[a:b].contiguous().to(dev), 900, block_rows=64)
+        t64 = od.spectrum_f64(T_cpu)
+        err_t = float(((sv_t.cpu().double() - t64).abs() / t64).max())
+    q.put((rank, ok_rows, float((sv - ref).abs().max() / ref.abs().max()), err32, err64, same_id, err_t))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_row_sharded_pipeline_two_processes_one_gpu():
     """Two ranks (two processes on this card, gloo moving the device tensors) each evaluate half of the rows of one
-    point's score matrix; the all-reduced spectrum equals the single-rank one and the rows do not depend on the split."""
+    point's score matrix; the all-reduced spectrum equals the single-rank one, the rows do not depend on the split, and the
+    spectrum holds the north star's 1e-4 against the oracle's CPU SVD of the full matrix (same integer ID)."""
     import os
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -362,6 +379,8 @@ def test_row_sharded_pipeline_two_processes_one_gpu():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, ok_rows, err in got:
+    for rank, ok_rows, err, err32, err64, same_id, err_t in got:
         assert ok_rows, rank
         assert err < 5e-6, (rank, err)
+        assert err32 < 1e-4 and err64 < 1e-4 and same_id, (rank, err32, err64, same_id)
+        assert err_t < 1e-4, (rank, err_t)
