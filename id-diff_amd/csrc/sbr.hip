@@ -217,6 +217,17 @@ __device__ __forceinline__ void lu_nopivot(double (*Bm)[BW + 1], double (*bc)[BW
   wave_lds_sync();
 }
 
+// k2: R1 = chol(sum Gpart)
+__global__ void __launch_bounds__(256) panel_chol1_kernel(const double *__restrict__ Gpart, int nchunk, double *__restrict__ R1) {
+  __shared__ double M[BW][BW + 1];
+  __shared__ double dsc[BW];
+  __shared__ double bc[2][BW];
+  reduce_partials(Gpart, nchunk, M, true);
+  if (threadIdx.x < 64) cholesky_upper(M, dsc, bc);
+  __syncthreads();
+  for (int e = threadIdx.x; e < BW * BW; e += blockDim.x) R1[e] = M[e / BW][e % BW];
+}
+
 // x <- x R^-1 for one row x (forward substitution over the columns of the upper-triangular R held in LDS).
 // Right-looking: as soon as x[j] is final it is taken out of every later column, so the 31 - j updates of a step are
 // independent of each other and only one multiply-add per column sits on the dependency chain (the left-looking loop
@@ -232,27 +243,20 @@ __device__ __forceinline__ void row_solve_upper(double *x, const double (*R)[BW 
   }
 }
 
-// k2: R1 = chol(sum Gpart), formed by EVERY workgroup for itself (a 32 x 32 factorisation by one wave: the same ~10 us
-// whether one workgroup does it and the others wait for the next launch, or all do it at once -- one launch less on the
-// panel's critical path); Q_chunk = P_chunk R1^-1 (one thread per row), stored; Gpart2[chunk] = Q_chunk^T Q_chunk
-__global__ void __launch_bounds__(256) panel_q_kernel(PanelGeom g, const double *__restrict__ Gpart, double *__restrict__ Q,
+// k3: Q_chunk = P_chunk R1^-1 (one thread per row), stored; Gpart2[chunk] = Q_chunk^T Q_chunk
+__global__ void __launch_bounds__(256) panel_q_kernel(PanelGeom g, const double *__restrict__ R1, double *__restrict__ Q,
                                                       double *__restrict__ Gpart2) {
   __shared__ double R[BW][BW + 1];
-  __shared__ double dsc[BW];
-  __shared__ double bc[2][BW];
   const int chunk = blockIdx.x, tid = threadIdx.x;
+  for (int e = tid; e < BW * BW; e += 256) R[e / BW][e % BW] = R1[e];
+  __syncthreads();
   const int r0 = chunk * g.chunk_rows, r1 = min(g.m, r0 + g.chunk_rows);
   const int row = r0 + tid;
-  double x[BW];
-  if (row < r1) {                                   // chunk_rows <= 256: one row per thread; requested before the reduction
+  if (row < r1) {                                   // chunk_rows <= 256: one row per thread
+    double x[BW];
     const double *p = g.A + (int64_t)(g.lo + row) * g.D + g.j0;
 #pragma unroll
     for (int j = 0; j < BW; ++j) x[j] = p[j];
-  }
-  reduce_partials(Gpart, g.nchunk, R, true);
-  if (tid < 64) cholesky_upper(R, dsc, bc);
-  __syncthreads();
-  if (row < r1) {
     row_solve_upper(x, R);
     double *q = Q + (int64_t)row * BW;
 #pragma unroll
@@ -267,63 +271,75 @@ __global__ void __launch_bounds__(256) panel_q_kernel(PanelGeom g, const double 
   store_tile_partial(Gpart2 + (int64_t)chunk * BW * BW, i0, j0, acc);
 }
 
-// k4 (every workgroup for itself, as k2): R2 = chol(sum Gpart2); Q1_top = Q_top R2^-1; S' = -sign(diag Q1_top); LU (no
-// pivoting) of I - Q1_top S' = V_top U'.  k5: V rows.  Rows < BW are V_top (unit lower); rows >= BW:
-// v = ((q R2^-1) * (-S')) U'^-1.  Then partials of V^T V and V^T P.  Workgroup 0 keeps V_top for k10 (the R block).
-__global__ void __launch_bounds__(256) panel_v_kernel(PanelGeom g, const double *__restrict__ Gpart2, const double *__restrict__ Q,
-                                                      double *__restrict__ Vtop, double *__restrict__ V,
-                                                      double *__restrict__ VtVpart, double *__restrict__ VtPpart) {
-  __shared__ double Ra[BW][BW + 1];
+// k4: R2 = chol(sum Gpart2); Q1_top = Q_top R2^-1; S' = -sign(diag Q1_top); LU (no pivoting) of I - Q1_top S' = V_top U'.
+// Outputs (all BW x BW): R2, U' (upper), Vtop (unit lower), sgn[BW] = S'.
+__global__ void __launch_bounds__(256) panel_hr_kernel(const double *__restrict__ Gpart2, int nchunk, const double *__restrict__ Q,
+                                                      double *__restrict__ R2out, double *__restrict__ Uout,
+                                                      double *__restrict__ Vtop, double *__restrict__ sgn) {
+  __shared__ double M[BW][BW + 1];
   __shared__ double Bm[BW][BW + 1];
-  __shared__ double sg[BW];
+  __shared__ double dsc[BW];
   __shared__ double bc[2][BW];
-  const int chunk = blockIdx.x, tid = threadIdx.x;
-  const int r0 = chunk * g.chunk_rows, r1 = min(g.m, r0 + g.chunk_rows);
-  const int row = r0 + tid;
-  double x[BW];
-  if (row < r1 && row >= BW) {
-#pragma unroll
-    for (int j = 0; j < BW; ++j) x[j] = Q[(int64_t)row * BW + j];
-  }
-  reduce_partials(Gpart2, g.nchunk, Ra, true);
-  if (tid < 64) cholesky_upper(Ra, sg, bc);
+  const int tid = threadIdx.x;
+  reduce_partials(Gpart2, nchunk, M, true);
+  if (tid < 64) cholesky_upper(M, dsc, bc);
   __syncthreads();
+  for (int e = tid; e < BW * BW; e += blockDim.x) R2out[e] = M[e / BW][e % BW];
   // Q1_top rows
   if (tid < BW) {
-    double y[BW];
+    double x[BW];
 #pragma unroll
-    for (int j = 0; j < BW; ++j) y[j] = Q[(int64_t)tid * BW + j];
-    row_solve_upper(y, Ra);
+    for (int j = 0; j < BW; ++j) x[j] = Q[(int64_t)tid * BW + j];
+    row_solve_upper(x, M);
 #pragma unroll
-    for (int j = 0; j < BW; ++j) Bm[tid][j] = y[j];
+    for (int j = 0; j < BW; ++j) Bm[tid][j] = x[j];
   }
   __syncthreads();
-  if (tid < BW) sg[tid] = Bm[tid][tid] >= 0.0 ? -1.0 : 1.0;      // S'
+  if (tid < BW) dsc[tid] = Bm[tid][tid] >= 0.0 ? -1.0 : 1.0;      // S'
   __syncthreads();
   for (int e = tid; e < BW * BW; e += blockDim.x) {
     const int i = e / BW, j = e % BW;
-    Bm[i][j] = (i == j ? 1.0 : 0.0) - Bm[i][j] * sg[j];
+    Bm[i][j] = (i == j ? 1.0 : 0.0) - Bm[i][j] * dsc[j];
   }
   __syncthreads();
   // LU without pivoting (diagonal entries start at 1 + |q_ii| >= 1; Ballard et al., "Reconstructing Householder vectors
-  // from TSQR": the multipliers stay bounded by 1 for an orthonormal Q1): U' on and above the diagonal of Bm, V_top below
+  // from TSQR": the multipliers stay bounded by 1 for an orthonormal Q1)
   if (tid < 64) lu_nopivot(Bm, bc);
   __syncthreads();
-  if (chunk == 0) {
-    for (int e = tid; e < BW * BW; e += blockDim.x) {
-      const int i = e / BW, j = e % BW;
-      Vtop[e] = i > j ? Bm[i][j] : (i == j ? 1.0 : 0.0);
-    }
+  for (int e = tid; e < BW * BW; e += blockDim.x) {
+    const int i = e / BW, j = e % BW;
+    Uout[e] = i <= j ? Bm[i][j] : 0.0;
+    Vtop[e] = i > j ? Bm[i][j] : (i == j ? 1.0 : 0.0);
   }
+  if (tid < BW) sgn[tid] = dsc[tid];
+}
+
+// k5: V rows.  Rows < BW come from Vtop; rows >= BW: v = ((q R2^-1) * (-S')) U'^-1.  Then partials of V^T V and V^T P.
+__global__ void __launch_bounds__(256) panel_v_kernel(PanelGeom g, const double *__restrict__ Q, const double *__restrict__ R2,
+                                                      const double *__restrict__ U, const double *__restrict__ Vtop,
+                                                      const double *__restrict__ sgn, double *__restrict__ V,
+                                                      double *__restrict__ VtVpart, double *__restrict__ VtPpart) {
+  __shared__ double Ra[BW][BW + 1];
+  __shared__ double Ub[BW][BW + 1];
+  __shared__ double sg[BW];
+  const int chunk = blockIdx.x, tid = threadIdx.x;
+  for (int e = tid; e < BW * BW; e += 256) { Ra[e / BW][e % BW] = R2[e]; Ub[e / BW][e % BW] = U[e]; }
+  if (tid < BW) sg[tid] = sgn[tid];
+  __syncthreads();
+  const int r0 = chunk * g.chunk_rows, r1 = min(g.m, r0 + g.chunk_rows);
+  const int row = r0 + tid;
   if (row < r1) {
+    double x[BW];
     if (row < BW) {
 #pragma unroll
-      for (int j = 0; j < BW; ++j) x[j] = row > j ? Bm[row][j] : (row == j ? 1.0 : 0.0);
+      for (int j = 0; j < BW; ++j) x[j] = Vtop[row * BW + j];
     } else {
+#pragma unroll
+      for (int j = 0; j < BW; ++j) x[j] = Q[(int64_t)row * BW + j];
       row_solve_upper(x, Ra);
 #pragma unroll
       for (int j = 0; j < BW; ++j) x[j] *= -sg[j];
-      row_solve_upper(x, Bm);            // the solver reads R[j][k] for k >= j only: the strict lower part (V_top) is not touched
+      row_solve_upper(x, Ub);
     }
     double *v = V + (int64_t)row * BW;
 #pragma unroll
@@ -339,6 +355,52 @@ __global__ void __launch_bounds__(256) panel_v_kernel(PanelGeom g, const double 
   gram_tile(V, BW, i0, P, g.D, j0, r0, r1, acc2);
   store_tile_partial(VtVpart + (int64_t)chunk * BW * BW, i0, j0, acc);
   store_tile_partial(VtPpart + (int64_t)chunk * BW * BW, i0, j0, acc2);
+}
+
+// k6: Tinv = striu(V^T V) + diag(V^T V) / 2 (upper triangular; T itself is never formed: every use is a triangular solve);
+//     C = T^T (V^T P) = Tinv^-T (V^T P);  the panel's surviving block R = P_top - V_top C goes back into A (upper triangle,
+//     mirrored), C is kept for the residual check of k10.
+__global__ void __launch_bounds__(256) panel_t_kernel(PanelGeom g, const double *__restrict__ VtVpart, const double *__restrict__ VtPpart,
+                                                     const double *__restrict__ Vtop, double *__restrict__ Tinv, double *__restrict__ C) {
+  __shared__ double M[BW][BW + 1];
+  __shared__ double W[BW][BW + 1];
+  const int tid = threadIdx.x;
+  reduce_partials(VtVpart, g.nchunk, M, true);
+  for (int e = tid; e < BW * BW; e += blockDim.x) {
+    const int i = e / BW, j = e % BW;
+    const double t = i < j ? M[i][j] : (i == j ? 0.5 * M[i][i] : 0.0);
+    Tinv[e] = t;
+  }
+  __syncthreads();
+  for (int e = tid; e < BW * BW; e += blockDim.x) { const int i = e / BW, j = e % BW; M[i][j] = i < j ? M[i][j] : (i == j ? 0.5 * M[i][i] : 0.0); }
+  reduce_partials(VtPpart, g.nchunk, W, false);
+  // C = Tinv^-T W: column c of C solves Tinv^T x = W[:, c] (forward substitution, Tinv^T lower); thread c owns column c
+  if (tid < BW) {          // Tinv^T x = w has the recurrence of x Tinv = w^T: the row solver on a register copy
+    double x[BW];
+#pragma unroll
+    for (int i = 0; i < BW; ++i) x[i] = W[i][tid];
+    row_solve_upper(x, M);
+#pragma unroll
+    for (int i = 0; i < BW; ++i) W[i][tid] = x[i];
+  }
+  __syncthreads();
+  for (int e = tid; e < BW * BW; e += blockDim.x) C[e] = W[e / BW][e % BW];
+  // R = P_top - V_top C, upper triangle kept (what is below is rounding noise of an exact annihilation)
+  for (int e = tid; e < BW * BW; e += blockDim.x) {
+    const int i = e / BW, j = e % BW;
+    double r = 0.0;
+    if (i <= j) {
+      r = g.A[(int64_t)(g.lo + i) * g.D + g.j0 + j];
+      for (int k = 0; k <= i; ++k) r -= Vtop[i * BW + k] * W[k][j];      // V_top is unit lower triangular
+    }
+    M[i][j] = r;
+  }
+  __syncthreads();
+  for (int e = tid; e < BW * BW; e += blockDim.x) {
+    const int i = e / BW, j = e % BW;
+    g.A[(int64_t)(g.lo + i) * g.D + g.j0 + j] = M[i][j];
+    g.A[(int64_t)(g.j0 + j) * g.D + g.lo + i] = M[i][j];
+  }
 }
 
 // k7: Ypart[ks][m][BW] = A'[:, ks-th column slice] V[slice]; workgroup = 128 rows x BW columns x one slice of KSPLIT_COLS
@@ -428,83 +490,59 @@ __global__ void __launch_bounds__(256) trailing_yk_kernel(PanelGeom g, const dou
   store_tile_partial(Kpart + (int64_t)chunk * BW * BW, i0, j0, acc);
 }
 
-// k6 + k9 + k10, one launch; the BW x BW parts are formed by EVERY workgroup for itself (see k2):
-//   k6  Tinv = striu(V^T V) + diag(V^T V) / 2 (upper triangular; T itself is never formed: every use is a triangular
-//       solve); C = T^T (V^T P) = Tinv^-T (V^T P); workgroup 0 puts the panel's surviving block R = P_top - V_top C back
-//       into A (upper triangle, mirrored);
-//   k9  W2 = -(1/2) T^T K T = -(1/2) Tinv^-T K Tinv^-1 with K = sum Kpart (symmetric);
-//   k10 Z = Y Tinv^-1 + V W2 (one thread per row); rows >= BW of the panel are checked (|| P_low - V_low C ||^2 is what
-//       the annihilation left behind, accumulated into *resid2) and zeroed, together with their mirror.
-__global__ void __launch_bounds__(256) trailing_z_kernel(PanelGeom g, const double *__restrict__ VtVpart, const double *__restrict__ VtPpart,
-                                                         const double *__restrict__ Kpart, const double *__restrict__ Vtop,
-                                                         const double *__restrict__ Y, const double *__restrict__ V,
-                                                         double *__restrict__ Z, double *__restrict__ resid2) {
+// k9: W2 = -(1/2) T^T K T = -(1/2) Tinv^-T K Tinv^-1 with K = sum Kpart (symmetric)
+__global__ void __launch_bounds__(256) trailing_w2_kernel(const double *__restrict__ Kpart, int nchunk, const double *__restrict__ Tinv,
+                                                         double *__restrict__ W2) {
+  __shared__ double K[BW][BW + 1];
+  __shared__ double Ti[BW][BW + 1];
+  const int tid = threadIdx.x;
+  reduce_partials(Kpart, nchunk, K, false);
+  for (int e = tid; e < BW * BW; e += blockDim.x) Ti[e / BW][e % BW] = Tinv[e];
+  __syncthreads();
+  // symmetrise K (V^T A' V of a symmetric A' up to rounding)
+  for (int e = tid; e < BW * BW; e += blockDim.x) { const int i = e / BW, j = e % BW; if (i < j) { const double s = 0.5 * (K[i][j] + K[j][i]); K[i][j] = s; K[j][i] = s; } }
+  __syncthreads();
+  // rows: K <- K Tinv^-1 (thread i owns row i)
+  if (tid < BW) {
+    double x[BW];
+#pragma unroll
+    for (int j = 0; j < BW; ++j) x[j] = K[tid][j];
+    row_solve_upper(x, Ti);
+#pragma unroll
+    for (int j = 0; j < BW; ++j) K[tid][j] = x[j];
+  }
+  __syncthreads();
+  // columns: K <- Tinv^-T K (thread c owns column c; Tinv^T is lower triangular)
+  if (tid < BW) {
+    double x[BW];
+#pragma unroll
+    for (int i = 0; i < BW; ++i) x[i] = K[i][tid];
+    row_solve_upper(x, Ti);
+#pragma unroll
+    for (int i = 0; i < BW; ++i) K[i][tid] = x[i];
+  }
+  __syncthreads();
+  for (int e = tid; e < BW * BW; e += blockDim.x) W2[e] = -0.5 * K[e / BW][e % BW];
+}
+
+// k10: Z = Y Tinv^-1 + V W2 (one thread per row); rows >= BW of the panel are checked (|| P_low - V_low C ||^2 is what
+// the annihilation left behind, accumulated into *resid2) and zeroed, together with their mirror.
+__global__ void __launch_bounds__(256) trailing_z_kernel(PanelGeom g, const double *__restrict__ Y, const double *__restrict__ V,
+                                                         const double *__restrict__ Tinv, const double *__restrict__ W2,
+                                                         const double *__restrict__ C, double *__restrict__ Z, double *__restrict__ resid2) {
   __shared__ double Ti[BW][BW + 1];
   __shared__ double Wm[BW][BW + 1];
   __shared__ double Cm[BW][BW + 1];
   __shared__ double red[4];
   const int chunk = blockIdx.x, tid = threadIdx.x;
+  for (int e = tid; e < BW * BW; e += 256) { Ti[e / BW][e % BW] = Tinv[e]; Wm[e / BW][e % BW] = W2[e]; Cm[e / BW][e % BW] = C[e]; }
+  __syncthreads();
+  double res = 0.0;
   const int row = chunk * g.chunk_rows + tid;
-  const bool mine = tid < g.chunk_rows && row < g.m;
-  double x[BW], v[BW];
-  if (mine) {                                                   // requested before the small factorisations
+  if (tid < g.chunk_rows && row < g.m) {
+    double x[BW], v[BW];
 #pragma unroll
     for (int j = 0; j < BW; ++j) { x[j] = Y[(int64_t)row * BW + j]; v[j] = V[(int64_t)row * BW + j]; }
-  }
-  // ---- k6
-  reduce_partials(VtVpart, g.nchunk, Ti, true);
-  for (int e = tid; e < BW * BW; e += blockDim.x) { const int i = e / BW, j = e % BW; const double t = Ti[i][j]; Ti[i][j] = i < j ? t : (i == j ? 0.5 * t : 0.0); }
-  reduce_partials(VtPpart, g.nchunk, Cm, false);                // (its barrier also publishes Ti)
-  // C = Tinv^-T W: column c of C solves Tinv^T x = W[:, c] (forward substitution, Tinv^T lower); thread c owns column c
-  if (tid < BW) {          // Tinv^T x = w has the recurrence of x Tinv = w^T: the row solver on a register copy
-    double c[BW];
-#pragma unroll
-    for (int i = 0; i < BW; ++i) c[i] = Cm[i][tid];
-    row_solve_upper(c, Ti);
-#pragma unroll
-    for (int i = 0; i < BW; ++i) Cm[i][tid] = c[i];
-  }
-  // ---- k9
-  reduce_partials(Kpart, g.nchunk, Wm, false);                  // (its barrier also publishes Cm)
-  // symmetrise K (V^T A' V of a symmetric A' up to rounding)
-  for (int e = tid; e < BW * BW; e += blockDim.x) { const int i = e / BW, j = e % BW; if (i < j) { const double s = 0.5 * (Wm[i][j] + Wm[j][i]); Wm[i][j] = s; Wm[j][i] = s; } }
-  __syncthreads();
-  if (chunk == 0) {
-    // R = P_top - V_top C, upper triangle kept (what is below is rounding noise of an exact annihilation)
-    for (int e = tid; e < BW * BW; e += blockDim.x) {
-      const int i = e / BW, j = e % BW;
-      double r = 0.0;
-      if (i <= j) {
-        r = g.A[(int64_t)(g.lo + i) * g.D + g.j0 + j];
-        for (int k = 0; k <= i; ++k) r -= Vtop[i * BW + k] * Cm[k][j];      // V_top is unit lower triangular
-      }
-      g.A[(int64_t)(g.lo + i) * g.D + g.j0 + j] = r;
-      g.A[(int64_t)(g.j0 + j) * g.D + g.lo + i] = r;
-    }
-  }
-  // rows: K <- K Tinv^-1 (thread i owns row i)
-  if (tid < BW) {
-    double k[BW];
-#pragma unroll
-    for (int j = 0; j < BW; ++j) k[j] = Wm[tid][j];
-    row_solve_upper(k, Ti);
-#pragma unroll
-    for (int j = 0; j < BW; ++j) Wm[tid][j] = k[j];
-  }
-  __syncthreads();
-  // columns: K <- Tinv^-T K (thread c owns column c; Tinv^T is lower triangular)
-  if (tid < BW) {
-    double k[BW];
-#pragma unroll
-    for (int i = 0; i < BW; ++i) k[i] = Wm[i][tid];
-    row_solve_upper(k, Ti);
-#pragma unroll
-    for (int i = 0; i < BW; ++i) Wm[i][tid] = -0.5 * k[i];
-  }
-  __syncthreads();
-  // ---- k10
-  double res = 0.0;
-  if (mine) {
     row_solve_upper(x, Ti);
 #pragma unroll
     for (int j = 0; j < BW; ++j) {
@@ -876,7 +914,7 @@ __device__ __forceinline__ bool msg_recv(const unsigned long long *box, double *
       const unsigned long long u = __hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((unsigned)(u >> 32) == tag) { reinterpret_cast<unsigned *>(dst)[i] = (unsigned)u; return false; }
       __builtin_amdgcn_s_sleep(1);                            // (polling without it measured the same)
-      if ((++spins & 255) == 0) {
+      if ((++spins & 255) == 0 || spin_limit < 256) {          // (a tiny limit is a test forcing the abort path: checked at every poll)
         if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
         if (spins > spin_limit) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
       }
@@ -1126,8 +1164,8 @@ int64_t sbr_scratch_doubles(int D) {
          + (int64_t)D * (BW + 1)              // carried reflectors of stage 2
          + 4 * m * BW                         // Q, V, Y, Z
          + nks * m * BW                       // Ypart
-         + 5 * nchunk * BW * BW               // Gram partials (G, G2, VtV, VtP, K)
-         + 8 * BW * BW + BW + 16;             // Vtop, spare | spare | scalars
+         + 4 * nchunk * BW * BW               // Gram partials (G / G2 share, VtV, VtP, K)
+         + 8 * BW * BW + BW + 16;             // R1, R2, U, Vtop, Tinv, C, W2, spare | sgn | scalars
 }
 
 // Stage 1: G (D x D, both triangles, overwritten) -> compact lower band AB = scratch[0 .. D * LDB) (column-major band:
@@ -1140,16 +1178,26 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
   const int64_t nchunk_max = (D + CHUNK - 1) / CHUNK, nks_max = (D + KSPLIT_COLS - 1) / KSPLIT_COLS;
   double *Ypart = Z + (int64_t)D * BW;
   double *Gp = Ypart + nks_max * D * BW;
-  double *Gp2 = Gp + nchunk_max * BW * BW;     // (its own buffer: a workgroup of k3 may write it while another still sums Gp)
-  double *VtVp = Gp2 + nchunk_max * BW * BW, *VtPp = VtVp + nchunk_max * BW * BW, *Kp = VtPp + nchunk_max * BW * BW;
-  double *Vtop = Kp + nchunk_max * BW * BW;
-  double *sgn = Vtop + 8 * BW * BW;
+  double *VtVp = Gp + nchunk_max * BW * BW, *VtPp = VtVp + nchunk_max * BW * BW, *Kp = VtPp + nchunk_max * BW * BW;
+  double *R1 = Kp + nchunk_max * BW * BW;
+  double *R2 = R1 + BW * BW, *U = R2 + BW * BW, *Vtop = U + BW * BW, *Tinv = Vtop + BW * BW, *C = Tinv + BW * BW,
+         *W2 = C + BW * BW;
+  double *sgn = W2 + 2 * BW * BW;
   double *scal = sgn + BW;             // [0] = residual^2, [1] = ||G||_F^2
 
   hipError_t e = hipMemsetAsync(scal, 0, 2 * sizeof(double), st);
   if (e != hipSuccess) { set_error("sbr: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
   hipLaunchKernelGGL(fro2_kernel, dim3(512), dim3(256), 0, st, G, (int64_t)D * D, scal + 1);
 
+  // IDIFF_SBR_SYNC (debugging): wait for every launch and say which one it was -- a fault then names its kernel
+  const bool dbg = option(OPT_SBR_SYNC);
+  auto after = [&](const char *what, int j) {
+    if (!dbg) return;
+    const hipError_t err = hipStreamSynchronize(st);
+    fprintf(stderr, "[sbr] D=%d j0=%d %s: %s\n", D, j, what, hipGetErrorString(err));
+    fflush(stderr);
+  };
+  after("fro2", 0);
   int j0 = 0;
   while (D - j0 > CORNER) {
     PanelGeom g;
@@ -1162,13 +1210,28 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     const int krange = ceil_div(ceil_div(g.m, nks), KSPLIT_COLS) * KSPLIT_COLS;
     nks = ceil_div(g.m, krange);
     hipLaunchKernelGGL(panel_gram_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp);
-    hipLaunchKernelGGL(panel_q_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp, Q, Gp2);
-    hipLaunchKernelGGL(panel_v_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp2, Q, Vtop, V, VtVp, VtPp);
+    after("panel_gram_kernel", j0);
+    hipLaunchKernelGGL(panel_chol1_kernel, dim3(1), dim3(256), 0, st, Gp, g.nchunk, R1);
+    after("panel_chol1_kernel", j0);
+    hipLaunchKernelGGL(panel_q_kernel, dim3(g.nchunk), dim3(256), 0, st, g, R1, Q, Gp);
+    after("panel_q_kernel", j0);
+    hipLaunchKernelGGL(panel_hr_kernel, dim3(1), dim3(256), 0, st, Gp, g.nchunk, Q, R2, U, Vtop, sgn);
+    after("panel_hr_kernel", j0);
+    hipLaunchKernelGGL(panel_v_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Q, R2, U, Vtop, sgn, V, VtVp, VtPp);
+    after("panel_v_kernel", j0);
+    hipLaunchKernelGGL(panel_t_kernel, dim3(1), dim3(256), 0, st, g, VtVp, VtPp, Vtop, Tinv, C);
+    after("panel_t_kernel", j0);
     hipLaunchKernelGGL(trailing_y_kernel, dim3(rbs, nks), dim3(256), 0, st, g, V, Ypart, krange);
+    after("trailing_y_kernel", j0);
     hipLaunchKernelGGL(trailing_yk_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Ypart, nks, V, Y, Kp);
-    hipLaunchKernelGGL(trailing_z_kernel, dim3(g.nchunk), dim3(256), 0, st, g, VtVp, VtPp, Kp, Vtop, Y, V, Z, scal);
+    after("trailing_yk_kernel", j0);
+    hipLaunchKernelGGL(trailing_w2_kernel, dim3(1), dim3(256), 0, st, Kp, g.nchunk, Tinv, W2);
+    after("trailing_w2_kernel", j0);
+    hipLaunchKernelGGL(trailing_z_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Y, V, Tinv, W2, C, Z, scal);
+    after("trailing_z_kernel", j0);
     const int tiles = ceil_div(g.m, 64);
     hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, g, V, Z);
+    after("trailing_update_kernel", j0);
     j0 += BW;
   }
   {
@@ -1179,6 +1242,7 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     if (int rc = set_dynamic_lds_once(guard, &fn, 1, (int)(((size_t)CORNER * (CORNER + 1) + 2 * CORNER + 8) * sizeof(double)), "sbr corner"))
       return rc;
     if (n > BW + 1) hipLaunchKernelGGL(corner_kernel, dim3(1), dim3(256), lds, st, G, D, j0);
+    after("corner_kernel", j0);
   }
   hipLaunchKernelGGL(extract_band_kernel, dim3((unsigned)ceil_div64((int64_t)(D + PAD) * LDB, 256)), dim3(256), 0, st, G, D, AB);
   return launch_status("sbr_to_band");
