@@ -408,14 +408,22 @@ __global__ void __launch_bounds__(256) panel_t_kernel(PanelGeom g, const double 
 // as two 16-row MFMA tiles x two 16-column tiles.  A lane fetches four consecutive k of each of its two rows (32 bytes
 // each) and spends them on four MFMAs per tile.
 constexpr int YROWS = 128;
-__global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const double *__restrict__ V, double *__restrict__ Ypart, int krange) {
+__global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const double *__restrict__ V, double *__restrict__ Ypart, int krange,
+                                                         int off /* lo & 63, or -1: both triangles of A' are valid */) {
   __shared__ double Vs[KSPLIT_COLS][BW];
   const int rb = blockIdx.x, ks = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fl = lane & 15, fk = lane >> 4;
   const int k_lo = ks * krange, k_hi = min(g.m, k_lo + krange);
   const int row0 = rb * YROWS + wave * 32 + fl, row1 = row0 + 16;           // local rows of A'
-  const double *ar0 = g.A + (int64_t)(g.lo + min(row0, g.m - 1)) * g.D + g.lo;
-  const double *ar1 = g.A + (int64_t)(g.lo + min(row1, g.m - 1)) * g.D + g.lo;
+  const int r0c = min(row0, g.m - 1), r1c = min(row1, g.m - 1);
+  const double *Ap = g.A + (int64_t)g.lo * g.D + g.lo;
+  const double *ar0 = Ap + (int64_t)r0c * g.D;
+  const double *ar1 = Ap + (int64_t)r1c * g.D;
+  // Only the tiles of the absolute 64-grid at or below the diagonal are kept up to date (k11s).  A 16 x 16 block whose
+  // column tile lies to the right of its row tile is read as the transpose of its mirror image: lane (fl, fk) then takes
+  // A'[column][row fl] -- for a fixed column the sixteen lanes of a row group read 128 contiguous bytes.
+  const int t0 = off < 0 ? 0x7fffffff : (rb * YROWS + wave * 32 + off) >> 6;          // tile rows of the wave's two row groups
+  const int t1 = off < 0 ? 0x7fffffff : (rb * YROWS + wave * 32 + 16 + off) >> 6;
   doublex4 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -435,11 +443,13 @@ __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const doub
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int kb = c + 16 * h + 4 * fk;
+        const int tc = (c + 16 * h + off) >> 6;          // tile column of this group of sixteen columns (uniform)
+        const bool up0 = tc > t0, up1 = tc > t1;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int k = min(kb + u, g.m - 1);        // columns beyond the slice meet zero rows of Vs
-          a0[h][u] = ar0[k];
-          a1[h][u] = ar1[k];
+          a0[h][u] = up0 ? Ap[(int64_t)k * g.D + r0c] : ar0[k];
+          a1[h][u] = up1 ? Ap[(int64_t)k * g.D + r1c] : ar1[k];
         }
       }
 #pragma unroll
@@ -642,6 +652,85 @@ __global__ void __launch_bounds__(256) trailing_update_kernel(PanelGeom g, const
       }
 }
 
+
+// ---------------------------------------------------------------------------------------------- stage 1: lower-triangle form
+// From here on only the LOWER triangle of the trailing block A' is kept up to date, at the granularity of an ABSOLUTE
+// grid of 64 x 64 tiles (tile index = matrix index >> 6, so a tile is the same set of elements for every panel although
+// the trailing block starts 32 further each time): tiles below the diagonal and the diagonal tiles (both halves) are
+// valid, tiles above it are stale.  trailing_update then reads and writes half the bytes (k11s); Y = A' V (k7) fetches a
+// 16 x 16 block above the diagonal as the transpose of its mirror image.
+//
+// k11s: A' -= V Z^T + Z V^T on the tiles of the absolute 64-grid at or below the diagonal (wave = 32 x 32 = 2 x 2 MFMA
+// tiles, K = 2 BW).  Diagonal tiles write their lower half and its mirror, so they stay valid in both halves.
+__global__ void __launch_bounds__(256) trailing_update_lower_kernel(PanelGeom g, int off, const double *__restrict__ V,
+                                                                    const double *__restrict__ Z) {
+  // triangular launch: block b -> (ti, tj), tj <= ti
+  const int b = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+  while (ti * (ti + 1) / 2 > b) --ti;
+  const int tj = b - ti * (ti + 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fl = lane & 15, fk = lane >> 4;
+  const int wi = ti * 64 + (wave >> 1) * 32 - off, wj = tj * 64 + (wave & 1) * 32 - off;      // local indices (may start at -32)
+  doublex4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = (doublex4){0.0, 0.0, 0.0, 0.0};
+  double *Ap = g.A + (int64_t)g.lo * g.D + g.lo;
+  double cold[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = wi + a * 16 + fk + 4 * r, gj = wj + c * 16 + fl;
+        cold[a][c][r] = (gi >= 0 && gj >= 0 && gi < g.m && gj < g.m) ? Ap[(int64_t)gi * g.D + gj] : 0.0;
+      }
+  // acc += Z_i V_j^T + V_i Z_j^T, in this order for every tile (the mirror of a diagonal tile is written, not recomputed)
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const double *Ai = pass == 0 ? Z : V, *Bj = pass == 0 ? V : Z;
+#pragma unroll
+    for (int kc = 0; kc < BW; kc += 16) {
+      double av[2][4], bv[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ri = min(max(wi + q * 16 + fl, 0), g.m - 1), rj = min(max(wj + q * 16 + fl, 0), g.m - 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[q][u] = Ai[(int64_t)ri * BW + kc + 4 * fk + u];
+          bv[q][u] = Bj[(int64_t)rj * BW + kc + 4 * fk + u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[a][c] = mfma(av[a][u], bv[c][u], acc[a][c]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = wi + a * 16 + fk + 4 * r, gj = wj + c * 16 + fl;
+        if (gi >= 0 && gj >= 0 && gi < g.m && gj < g.m) {
+          if (ti != tj) {
+            Ap[(int64_t)gi * g.D + gj] = cold[a][c][r] - acc[a][c][r];
+          } else if (gi >= gj) {
+            const double val = cold[a][c][r] - acc[a][c][r];
+            Ap[(int64_t)gi * g.D + gj] = val;
+            Ap[(int64_t)gj * g.D + gi] = val;
+          }
+        }
+      }
+}
+
 // ---------------------------------------------------------------------------------------------- stage 1: corner in LDS
 // The trailing n x n block (n <= CORNER) is brought to half-bandwidth BW by plain Householder reflections, one
 // workgroup, the block in LDS (pitch n + 1): column c keeps rows <= c + BW.
@@ -657,7 +746,11 @@ __global__ void __launch_bounds__(256) corner_kernel(double *__restrict__ A, int
   extern __shared__ double sm[];
   const int n = D - j0, pitch = n + 1, tid = threadIdx.x;
   double *C = sm, *v = sm + n * pitch, *w = v + n, *red = w + n;
-  for (int e = tid; e < n * n; e += 256) C[(e / n) * pitch + e % n] = A[(int64_t)(j0 + e / n) * D + j0 + e % n];
+  // (only the lower triangle of the trailing block is kept up to date: the upper half is its mirror)
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e % n, hi = max(i, j), lo2 = min(i, j);
+    C[i * pitch + j] = A[(int64_t)(j0 + hi) * D + j0 + lo2];
+  }
   __syncthreads();
   for (int c = 0; c + BW + 1 < n; ++c) {
     const int base = c + BW, len = n - base;            // reflector acts on local rows/cols [base, n)
@@ -1198,6 +1291,8 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     fflush(stderr);
   };
   after("fro2", 0);
+  // IDIFF_SBR_FULL (A/B): the round-2 form that keeps both triangles of the trailing block up to date
+  const bool full = option(OPT_SBR_FULL);
   int j0 = 0;
   while (D - j0 > CORNER) {
     PanelGeom g;
@@ -1221,7 +1316,8 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     after("panel_v_kernel", j0);
     hipLaunchKernelGGL(panel_t_kernel, dim3(1), dim3(256), 0, st, g, VtVp, VtPp, Vtop, Tinv, C);
     after("panel_t_kernel", j0);
-    hipLaunchKernelGGL(trailing_y_kernel, dim3(rbs, nks), dim3(256), 0, st, g, V, Ypart, krange);
+    const int off = g.lo & 63;                           // the trailing block starts `off` into its first tile of the absolute grid
+    hipLaunchKernelGGL(trailing_y_kernel, dim3(rbs, nks), dim3(256), 0, st, g, V, Ypart, krange, full ? -1 : off);
     after("trailing_y_kernel", j0);
     hipLaunchKernelGGL(trailing_yk_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Ypart, nks, V, Y, Kp);
     after("trailing_yk_kernel", j0);
@@ -1230,7 +1326,12 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     hipLaunchKernelGGL(trailing_z_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Y, V, Tinv, W2, C, Z, scal);
     after("trailing_z_kernel", j0);
     const int tiles = ceil_div(g.m, 64);
-    hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, g, V, Z);
+    if (full) {
+      hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, g, V, Z);
+    } else {
+      const int nt = ceil_div(g.m + off, 64);
+      hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, g, off, V, Z);
+    }
     after("trailing_update_kernel", j0);
     j0 += BW;
   }
