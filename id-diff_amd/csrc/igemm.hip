@@ -284,7 +284,35 @@ int launch_cfg(IgemmParams &p, int batch, hipStream_t st) {
 // Requires 16-byte aligned K-contiguous operands, slices < 4 GiB and (conv) Cin % 32 == 0; everything else
 // takes the general kernel above.
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr uint32_t OOB = 0xFFFFFFFFu;
+
+// ---- split-precision products (SPLIT): every fp32 operand element is cut EXACTLY into three bf16 pieces of 8 mantissa bits
+// each, x = x1 + x2 + x3 (truncation: x1 = the top 16 bits of x, r = x - x1 is exact, x2 = the top 16 bits of r, x3 = r - x2 is
+// exact and has at most 8 significant bits), and a product a b is formed as the six partial products of weight >= 2^-16,
+//     a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1        (smallest first),
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  What is left out (a2 b3 + a3 b2 + a3 b3) is below 2^-23 |a b|: the
+// size of the rounding of ONE fp32 product.  Measured on [2.3 M x 128] x [128 x 128] against an fp64 contraction of the same
+// fp32 inputs (scripts/bf16x6_probe.hip): 1.7e-7 relative for this form, 2.0e-7 for the k-ordered fp32 fma chain of
+// v_mfma_f32_32x32x2_f32 -- the split form is not a reduced-precision mode.  The bf16 matrix core retires a 32x32x16 block in
+// 32 cycles where the fp32 one needs 8 x 64 for the same k extent: six of them are 2.7x cheaper, and unlike the fp32 MFMA they
+// run beside the vector ALU, which is where the splitting (about 5 instructions per element) goes.
+constexpr int SP = BK + 8;            // bf16 elements per LDS row of a split plane: 80 bytes, 16-byte aligned, conflict-free b128 reads
+
+__device__ __forceinline__ void split4(const float4 v, uint2 &p1, uint2 &p2, uint2 &p3) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  uint32_t t1[4], t2[4], t3[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    t1[e] = __float_as_uint(x[e]) & 0xffff0000u;
+    const float r1 = x[e] - __uint_as_float(t1[e]);
+    t2[e] = __float_as_uint(r1) & 0xffff0000u;
+    t3[e] = __float_as_uint(r1 - __uint_as_float(t2[e]));
+  }
+  p1 = make_uint2((t1[0] >> 16) | t1[1], (t1[2] >> 16) | t1[3]);
+  p2 = make_uint2((t2[0] >> 16) | t2[1], (t2[2] >> 16) | t2[3]);
+  p3 = make_uint2((t3[0] >> 16) | (t3[1] & 0xffff0000u), (t3[2] >> 16) | (t3[3] & 0xffff0000u));
+}
 bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
@@ -292,9 +320,10 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t b
   return __builtin_bit_cast(float4, v);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF>
-__global__ void __launch_bounds__(WARPS_M *WARPS_N * 64, DBUF ? 2 : 4)
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF, bool SPLIT>
+__global__ void __launch_bounds__(WARPS_M *WARPS_N * 64, (DBUF || SPLIT) ? 2 : 4)
 igemm_pipe_kernel(const IgemmParams p) {
+  static_assert(!(SPLIT && DBUF), "the split form uses one LDS buffer");
   constexpr int T = WARPS_M * WARPS_N * 64;
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -305,6 +334,9 @@ igemm_pipe_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *As = lds;
   float *Bs = lds + (DBUF ? 2 : 1) * BM * LDS_PITCH;
+  // SPLIT: three bf16 planes per operand and buffer, [buffer][plane][row][SP]
+  unsigned short *As16 = reinterpret_cast<unsigned short *>(lds);
+  unsigned short *Bs16 = As16 + (DBUF ? 2 : 1) * 3 * BM * SP;
 
   const int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
@@ -400,15 +432,13 @@ igemm_pipe_kernel(const IgemmParams p) {
       if (++f_kx == p.KW) { f_kx = 0; ++f_ky; }
       if (f_tap == ntaps) { f_tap = 0; f_kx = 0; f_ky = 0; f_c0 += BK; }
     } else {
-      if (p.K1 > 0 && f_kt * BK >= p.K1) {   // wave-uniform: second source, same row offsets
-        const uint32_t koff = (uint32_t)(f_kt * BK - p.K1) * 4u;
+      // wave-uniform choice of the source (columns K1.. live in the second matrix, same row offsets): a select of the
+      // descriptor, not a branch -- the k-tile body stays one basic block, which the interleaving below needs
+      const bool second = p.K1 > 0 && f_kt * BK >= p.K1;
+      const __amdgpu_buffer_rsrc_t rS = second ? rA2 : rA;
+      const uint32_t koff = (uint32_t)(f_kt * BK - (second ? p.K1 : 0)) * 4u;
 #pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) a_reg[i] = buf_load4(rA2, (a_mask[i] && kok) ? a_base[i] + koff : OOB);
-      } else {
-        const uint32_t koff = (uint32_t)f_kt * (BK * 4u);
-#pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) a_reg[i] = buf_load4(rA, (a_mask[i] && kok) ? a_base[i] + koff : OOB);
-      }
+      for (int i = 0; i < A_PER_T; ++i) a_reg[i] = buf_load4(rS, (a_mask[i] && kok) ? a_base[i] + koff : OOB);
     }
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) b_reg[i] = buf_load4(rB, (b_ok[i] && kok) ? b_base[i] + koffb : OOB);
@@ -416,6 +446,28 @@ igemm_pipe_kernel(const IgemmParams p) {
   };
 
   auto stage = [&](int buf) {
+    if (SPLIT) {
+      unsigned short *a_dst = As16 + buf * 3 * BM * SP, *b_dst = Bs16 + buf * 3 * BN * SP;
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) {
+        uint2 q1, q2, q3;
+        split4(a_reg[i], q1, q2, q3);
+        unsigned short *d = a_dst + (row_base + i * ROW_STEP) * SP + kc;
+        *reinterpret_cast<uint2 *>(d) = q1;
+        *reinterpret_cast<uint2 *>(d + BM * SP) = q2;
+        *reinterpret_cast<uint2 *>(d + 2 * BM * SP) = q3;
+      }
+#pragma unroll
+      for (int i = 0; i < B_PER_T; ++i) {
+        uint2 q1, q2, q3;
+        split4(b_reg[i], q1, q2, q3);
+        unsigned short *d = b_dst + (row_base + i * ROW_STEP) * SP + kc;
+        *reinterpret_cast<uint2 *>(d) = q1;
+        *reinterpret_cast<uint2 *>(d + BN * SP) = q2;
+        *reinterpret_cast<uint2 *>(d + 2 * BN * SP) = q3;
+      }
+      return;
+    }
     float *a_dst = As + buf * BM * LDS_PITCH;
     float *b_dst = Bs + buf * BN * LDS_PITCH;
 #pragma unroll
@@ -438,14 +490,48 @@ igemm_pipe_kernel(const IgemmParams p) {
 
   auto ktile = [&](int kt, auto first) {
     const int buf = DBUF ? (kt & 1) : 0;
-    if (DBUF) {
+    if (DBUF && !SPLIT) {
       if (kt + 1 < nkt) stage(buf ^ 1);   // tile kt+1: loaded one iteration ago
       if (kt + 2 < nkt) fetch();          // tile kt+2: lands while this tile's 64 MFMAs run
+    }
+    if (SPLIT) {
+      // lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8 h + e] and B[k = 8 h + e][column r], e = 0 .. 7
+      const unsigned short *a16 = As16 + buf * 3 * BM * SP + (wm0 + frag_row) * SP + (lane >> 5) * 8;
+      const unsigned short *b16 = Bs16 + buf * 3 * BN * SP + (wn0 + frag_row) * SP + (lane >> 5) * 8;
+      bf16x8 af[BK / 16][TM][3], bf[BK / 16][TN][3];
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) af[s][i][q] = *reinterpret_cast<const bf16x8 *>(a16 + (q * BM + i * 32) * SP + s * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bf[s][j][q] = *reinterpret_cast<const bf16x8 *>(b16 + (q * BN + j * 32) * SP + s * 16);
+      }
+      // the six partial products, smallest first
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (decltype(first)::value && s == 0 && t == 0) {
+                const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i][PA[t]], bf[s][j][PB[t]], zero, 0, 0, 0);
+              } else {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i][PA[t]], bf[s][j][PB[t]], acc[i][j], 0, 0, 0);
+              }
+            }
     }
     const float *a_src = As + buf * BM * LDS_PITCH + (wm0 + frag_row) * LDS_PITCH + frag_k;
     const float *b_src = Bs + buf * BN * LDS_PITCH + (wn0 + frag_row) * LDS_PITCH + frag_k;
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
+    for (int g = 0; g < (SPLIT ? 0 : BK / 8); ++g) {
       float4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a_src + i * 32 * LDS_PITCH + g * 8);
@@ -715,12 +801,16 @@ igemm_pipe_kernel(const IgemmParams p) {
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF = true>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF = true, bool SPLIT = false>
 int launch_pipe(IgemmParams &p, int batch, hipStream_t st) {
   p.tiles_m = idiff::ceil_div(p.M, BM);
   p.tiles_n = idiff::ceil_div(p.N, BN);
-  constexpr size_t lds_bytes = (size_t)(DBUF ? 2 : 1) * (BM + BN) * LDS_PITCH * sizeof(float);
-  auto kern = igemm_pipe_kernel<BM, BN, WARPS_M, WARPS_N, CONV, DBUF>;
+  constexpr size_t stage_bytes = SPLIT ? (size_t)(DBUF ? 2 : 1) * (BM + BN) * 3 * SP * sizeof(unsigned short)
+                                       : (size_t)(DBUF ? 2 : 1) * (BM + BN) * LDS_PITCH * sizeof(float);
+  // (the epilogue turns the accumulators through one 32 x WTN fp32 patch per wave in the same memory)
+  constexpr size_t patch_bytes = (size_t)WARPS_M * WARPS_N * 32 * (BN / WARPS_N) * sizeof(float);
+  constexpr size_t lds_bytes = stage_bytes > patch_bytes ? stage_bytes : patch_bytes;
+  auto kern = igemm_pipe_kernel<BM, BN, WARPS_M, WARPS_N, CONV, DBUF, SPLIT>;
   if (lds_bytes > 64 * 1024) {
     static idiff::AttrGuard guard;                 // one per template instantiation, one bit per device
     const void *fn = reinterpret_cast<const void *>(kern);
@@ -757,6 +847,18 @@ int pipe_tile_rows(int M, int N, int batch) {
 template <bool CONV>
 int dispatch_pipe(IgemmParams &p, int batch, hipStream_t st) {
   const int64_t wg_big = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 128) * batch;
+  if (!idiff::option(idiff::OPT_NO_SPLIT)) {
+    // split-precision products on the bf16 matrix cores (see split4): single LDS buffer (60 KB at 128 x 128: two workgroups
+    // per CU), the same tile choice as below.  (A double-buffered form with the splitting of tile t + 1 interleaved between
+    // the matrix instructions of tile t by sched_group_barrier was built and measured: 118-128 TFLOP/s against 140-180 for
+    // this one -- at 32 k per tile a 128 x 128 workgroup asks the L2 for 32 KB per 1600 matrix-pipe cycles, which is what
+    // bounds it, not the instruction mix.)
+    if (p.N > 64 && wg_big >= 256) return launch_pipe<128, 128, 2, 2, CONV, false, true>(p, batch, st);
+    if (p.N <= 32 && p.M >= 4096) return launch_pipe<128, 32, 4, 1, CONV, false, true>(p, batch, st);
+    const int64_t wg_mid_s = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 64) * batch;
+    if (wg_mid_s >= 256 || p.M >= 4096) return launch_pipe<128, 64, 2, 2, CONV, false, true>(p, batch, st);
+    return launch_pipe<64, 64, 2, 2, CONV, false, true>(p, batch, st);
+  }
   // >= 4 workgroups per CU available: single LDS buffer, 128 registers, four resident workgroups per CU
   // (measured 135-142 TFLOP/s vs 124-135 for the double-buffered two-workgroup form)
   if (p.N > 64 && wg_big >= 1024 && !idiff::option(idiff::OPT_DBUF_ONLY)) return launch_pipe<128, 128, 2, 2, CONV, false>(p, batch, st);
