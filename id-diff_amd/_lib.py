@@ -45,6 +45,10 @@ _SIGNATURES = {
     "idiff_winograd_pack_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "idiff_conv2d_winograd_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 5 + [ctypes.POINTER(Epilogue), c_p]),
     "idiff_conv2d_winograd_colstats_split": (c_i, [c_i] * 5),
+    "idiff_conv2d_winograd_split_ok": (c_i, [c_i] * 5),
+    "idiff_winograd_split_weight_floats": (c_i64, [c_i, c_i]),
+    "idiff_winograd_pack_split_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    "idiff_conv2d_winograd_split_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 5 + [ctypes.POINTER(Epilogue), c_p]),
     "idiff_groupnorm_finalize_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "idiff_groupnorm_nsplit": (c_i, [c_i, c_i, c_i]),
     "idiff_groupnorm_stats_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
@@ -262,11 +266,17 @@ def conv2d_winograd_ok(B, H, W, Cin, Cout):
     return bool(lib().idiff_conv2d_winograd_ok(B, H, W, Cin, Cout))
 
 
-def winograd_pack(wt, Cin, Cout):
-    """wt [Cout, 3, 3, Cin] (the direct kernel's panel) -> the transformed filter bank of idiff_conv2d_winograd_f32."""
+def winograd_pack(wt, Cin, Cout, B_hint=None):
+    """wt [Cout, 3, 3, Cin] (the direct kernel's panel) -> the transformed filter bank of idiff_conv2d_winograd_f32, or --
+    when ``B_hint = (B, H, W)`` names a geometry the split-precision kernel serves -- of idiff_conv2d_winograd_split_f32."""
     _dev(wt, "wt")
     if wt.numel() != Cout * 9 * Cin:
         raise RuntimeError(f"winograd_pack: expected {Cout}x3x3x{Cin} weights, got {tuple(wt.shape)}")
+    if B_hint is not None and lib().idiff_conv2d_winograd_split_ok(*B_hint, Cin, Cout):
+        # the split-precision bank (three bf16 per weight); conv2d_winograd tells the two apart by their size
+        u = torch.empty(lib().idiff_winograd_split_weight_floats(Cin, Cout), device=wt.device, dtype=torch.float32)
+        _check(lib().idiff_winograd_pack_split_f32(wt.data_ptr(), u.data_ptr(), Cin, Cout, _stream()), "idiff_winograd_pack_split_f32")
+        return u
     u = torch.empty(lib().idiff_winograd_weight_floats(Cin, Cout), device=wt.device, dtype=torch.float32)
     _check(lib().idiff_winograd_pack_f32(wt.data_ptr(), u.data_ptr(), Cin, Cout, _stream()), "idiff_winograd_pack_f32")
     return u
@@ -274,6 +284,10 @@ def winograd_pack(wt, Cin, Cout):
 
 def conv2d_winograd(x, u, out, B, H, W, Cin, Cout, epilogue=None):
     ep = ctypes.byref(epilogue) if epilogue is not None else None
+    if u.numel() == 24 * Cin * Cout:        # a split-precision bank (winograd_pack with a geometry hint)
+        _check(lib().idiff_conv2d_winograd_split_f32(x.data_ptr(), u.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, ep, _stream()),
+               "idiff_conv2d_winograd_split_f32")
+        return out
     _check(lib().idiff_conv2d_winograd_f32(x.data_ptr(), u.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, ep, _stream()),
            "idiff_conv2d_winograd_f32")
     return out

@@ -97,168 +97,10 @@ __device__ __forceinline__ void split_tile(const WinoParams &p, int T, int &img,
   }
 }
 
-// PEEL: step 0 is peeled and its MFMAs take C = 0 as an inline constant, so no accumulator is initialised (1-3 % on the
-// large maps); launches of only a few rounds of workgroups (the 4x4 maps) measured 7 % faster with the plain loop.
-template <bool PEEL>
-__global__ void __launch_bounds__(THREADS, 2)   // two waves per SIMD (256 VGPRs): two 256-thread workgroups per CU
-winograd_kernel(const WinoParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-#ifdef IDIFF_WINO_STAMP   // diagnostic build only (scripts/wino_clock.py): the clock the chip holds inside this kernel
-  const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-
-  const int nwg = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  }
-  // groups of `ngroup` output-channel tiles: inside a group tile_n is innermost (the workgroups of an XCD share the input
-  // patches of a run of tile_m and stream only ngroup filter slabs), the groups follow one another
-  const int per_group = p.tiles_m * p.ngroup;
-  const int grp = bid / per_group, in_grp = bid - grp * per_group;
-  const int tile_n = grp * p.ngroup + in_grp % p.ngroup, tile_m = in_grp / p.ngroup;
-  const int tile0 = tile_m * WG_TILES, n0 = tile_n * WG_COUT;
-  const int tid = threadIdx.x, lane = tid & 63;
-  // the wave index in an SGPR: roles, operand halves and buffer descriptors stay provably wave-uniform (no waterfall
-  // loops around the buffer loads, scalar branches)
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = wave & 3, tb = wave >> 2;   // transform-domain row, 32-tile half
-
-  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
-
-  // ---------------------------------------------------------------- loader state
-  const bool early = wave < NWAVES / 2;    // waves w and w+4 share a SIMD: one transforms while the other feeds the matrix pipe
-  uint32_t v_src[4], u_src[4];
-  int v_dst;
-  float sgn;
-  {
-    const int r = tid & 3, q = (tid >> 2) & 1, tl = tid >> 3;
-    const int T = tile0 + tl;
-    const bool tv = T < p.total_tiles;
-    const int TT = tv ? T : 0;
-    int img, ty, tx;
-    split_tile(p, TT, img, ty, tx);
-    const int y = 2 * ty - 1 + r, x0 = 2 * tx - 1;
-    const bool yok = tv && y >= 0 && y < p.H;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int xx = x0 + j;
-      v_src[j] = (yok && xx >= 0 && xx < p.W) ? (uint32_t)(((img * p.H + y) * p.W + xx) * p.Cin + q * 4) * 4u : INVALID_PIXEL;
-    }
-    v_dst = r * V_SLOT + tl * KC + 4 * (q ^ ((tl >> 3) & 1));
-    sgn = (r == 1) ? 1.f : -1.f;
-    // U fragments go straight from the slab to the MFMA operand registers of the lane that uses them (32 channels x 32
-    // bytes contiguous per half wave): no LDS round trip for the filter bank
-    const int fr_ = lane & 31, fh_ = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) u_src[j] = (uint32_t)(((4 * j + wi) * 64 + fr_) * 32 + 16 * (fh_ ^ ((fr_ >> 3) & 1)));
-  }
-
-  float4 ldv[4], bfr[4][2];
-  const int nsteps = p.Cin / KC;
-  int f_step = 0;
-  // the per-step offsets are wave-uniform: they ride in the buffer instruction's scalar offset (not part of the range
-  // check of a raw buffer, so an out-of-range pixel stays out of range) instead of costing a VALU add per load
-  auto fetch = [&]() {
-    const int choff = f_step * (KC * 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ldv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)v_src[j], choff, 0));
-    ++f_step;
-  };
-
-  auto stage = [&](int buf) {
-    float *Vd = lds + buf * STAGE_FLOATS + v_dst;
-    float4 c[4];
-    c[0] = f4sub(ldv[0], ldv[2]); c[1] = f4add(ldv[1], ldv[2]); c[2] = f4sub(ldv[2], ldv[1]); c[3] = f4sub(ldv[1], ldv[3]);
-    // c += sgn * quad_perm[2,2,1,1](c), the permute folded into the fma's DPP operand (hipcc keeps v_mov_b32_dpp + v_fmac
-    // apart).  s_nop 1: a VALU write of a VGPR needs two wait states before a DPP read of it, and the hazard
-    // recogniser does not look inside inline asm.
-#define IDIFF_QFMA(x) "v_fmac_f32_dpp " x ", " x ", %16 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    asm volatile("s_nop 1\n" IDIFF_QFMA("%0") IDIFF_QFMA("%1") IDIFF_QFMA("%2") IDIFF_QFMA("%3") IDIFF_QFMA("%4") IDIFF_QFMA("%5")
-                 IDIFF_QFMA("%6") IDIFF_QFMA("%7") IDIFF_QFMA("%8") IDIFF_QFMA("%9") IDIFF_QFMA("%10") IDIFF_QFMA("%11")
-                 IDIFF_QFMA("%12") IDIFF_QFMA("%13") IDIFF_QFMA("%14") IDIFF_QFMA("%15")
-                 : "+v"(c[0].x), "+v"(c[0].y), "+v"(c[0].z), "+v"(c[0].w), "+v"(c[1].x), "+v"(c[1].y), "+v"(c[1].z), "+v"(c[1].w),
-                   "+v"(c[2].x), "+v"(c[2].y), "+v"(c[2].z), "+v"(c[2].w), "+v"(c[3].x), "+v"(c[3].y), "+v"(c[3].z), "+v"(c[3].w)
-                 : "v"(sgn));
-#undef IDIFF_QFMA
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(Vd + j * 4 * V_SLOT) = c[j];
-  };
-
-  floatx16 acc[8];   // [j][channel half]; PEEL: first written by the MFMAs of step 0 (the 2 x 128 v_mov_b32 of an explicit
-                     // initialisation were 11 % of a wave's non-MFMA VALU work)
-
-  const int fr = lane & 31, fh = lane >> 5;
-  const int frag = fr * KC + 4 * (fh ^ ((fr >> 3) & 1));
-  const int a_frag = wi * V_SLOT + tb * 32 * KC + frag;       // slot of position (wi, j): 4j + wi
-
-  auto load_b = [&](int j, int step) {
-    const int slab = (step * p.tiles_n + tile_n) * (OPER_FLOATS * 4);
-    bfr[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[j], slab, 0));
-    bfr[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[j] + 32 * 32, slab, 0));
-  };
-  auto compute = [&](int buf, int j0, int s, auto first) {
-    const float *S = lds + buf * STAGE_FLOATS;
-#pragma unroll
-    for (int j = j0; j < j0 + 2; ++j) {
-      const float4 a = *reinterpret_cast<const float4 *>(S + a_frag + 4 * j * V_SLOT);
-      const float4 b0 = bfr[j][0], b1 = bfr[j][1];
-      if constexpr (decltype(first)::value) {
-        const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, zero, 0, 0, 0);
-        acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, zero, 0, 0, 0);
-      } else {
-        acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[2 * j], 0, 0, 0);
-        acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[2 * j + 1], 0, 0, 0);
-      }
-      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[2 * j], 0, 0, 0);
-      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[2 * j + 1], 0, 0, 0);
-      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[2 * j], 0, 0, 0);
-      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[2 * j + 1], 0, 0, 0);
-      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[2 * j], 0, 0, 0);
-      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[2 * j + 1], 0, 0, 0);
-      // the registers are free once these MFMAs have read them; the last step re-requests its own slab (clamped, not
-      // skipped: no branch per position, and the scalar offset of a raw buffer is not range-checked, so it must stay valid)
-      load_b(j, min(s + 1, nsteps - 1));
-    }
-  };
-  auto step = [&](int s, auto first) {
-    const int buf = s & 1;
-    if (early) {
-      if (s + 1 < nsteps) stage(buf ^ 1);   // loaded one step ago
-      if (s + 2 < nsteps) fetch();
-    }
-    compute(buf, 0, s, first);
-    __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of the two halves from being hoisted together
-    compute(buf, 2, s, first);
-    if (!early) {
-      if (s + 1 < nsteps) stage(buf ^ 1);
-      if (s + 2 < nsteps) fetch();
-    }
-    __syncthreads();
-  };
-
-#pragma unroll
-  for (int j = 0; j < 4; ++j) load_b(j, 0);
-  fetch();
-  stage(0);
-  if (nsteps > 1) fetch();
-  __syncthreads();
-
-  if constexpr (PEEL) {
-    step(0, std::true_type());
-    for (int s = 1; s < nsteps; ++s) step(s, std::false_type());
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    for (int s = 0; s < nsteps; ++s) step(s, std::false_type());
-  }
-
-  // ---------------------------------------------------------------- tail
+// ---------------------------------------------------------------- tail (shared by the fp32 and the split-precision kernel)
+// acc[2 j + h] = M at position (wi, j) for this wave's 32 tiles x cout half h, in the 32x32 accumulator layout.
+__device__ __forceinline__ void wino_tail(const WinoParams &p, floatx16 (&acc)[8], float *lds, const int tile0, const int n0,
+                                          const int tile_m, const int tid, const int lane, const int wave, const int wi, const int tb) {
   // This thread finishes 4 channels (n .. n+3) of tiles 2g and 2g+1: output pixels (2ty + a, 2tx + b).  Everything here
   // is VALU work that no MFMA hides (a wave's non-MFMA VALU instructions were split about evenly between the K loop and
   // prologue + tail at Cin = 256), so the tail is written to issue as few of them as it can: 32-bit byte offsets into
@@ -428,7 +270,173 @@ winograd_kernel(const WinoParams p) {
       dst[0] = a; dst[1] = b;
     }
   }
+}
+
+// PEEL: step 0 is peeled and its MFMAs take C = 0 as an inline constant, so no accumulator is initialised (1-3 % on the
+// large maps); launches of only a few rounds of workgroups (the 4x4 maps) measured 7 % faster with the plain loop.
+template <bool PEEL>
+__global__ void __launch_bounds__(THREADS, 2)   // two waves per SIMD (256 VGPRs): two 256-thread workgroups per CU
+winograd_kernel(const WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef IDIFF_WINO_STAMP   // diagnostic build only (scripts/wino_clock.py): the clock the chip holds inside this kernel
+  const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  // groups of `ngroup` output-channel tiles: inside a group tile_n is innermost (the workgroups of an XCD share the input
+  // patches of a run of tile_m and stream only ngroup filter slabs), the groups follow one another
+  const int per_group = p.tiles_m * p.ngroup;
+  const int grp = bid / per_group, in_grp = bid - grp * per_group;
+  const int tile_n = grp * p.ngroup + in_grp % p.ngroup, tile_m = in_grp / p.ngroup;
+  const int tile0 = tile_m * WG_TILES, n0 = tile_n * WG_COUT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index in an SGPR: roles, operand halves and buffer descriptors stay provably wave-uniform (no waterfall
+  // loops around the buffer loads, scalar branches)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave & 3, tb = wave >> 2;   // transform-domain row, 32-tile half
+
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
+
+  // ---------------------------------------------------------------- loader state
+  const bool early = wave < NWAVES / 2;    // waves w and w+4 share a SIMD: one transforms while the other feeds the matrix pipe
+  uint32_t v_src[4], u_src[4];
+  int v_dst;
+  float sgn;
+  {
+    const int r = tid & 3, q = (tid >> 2) & 1, tl = tid >> 3;
+    const int T = tile0 + tl;
+    const bool tv = T < p.total_tiles;
+    const int TT = tv ? T : 0;
+    int img, ty, tx;
+    split_tile(p, TT, img, ty, tx);
+    const int y = 2 * ty - 1 + r, x0 = 2 * tx - 1;
+    const bool yok = tv && y >= 0 && y < p.H;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xx = x0 + j;
+      v_src[j] = (yok && xx >= 0 && xx < p.W) ? (uint32_t)(((img * p.H + y) * p.W + xx) * p.Cin + q * 4) * 4u : INVALID_PIXEL;
+    }
+    v_dst = r * V_SLOT + tl * KC + 4 * (q ^ ((tl >> 3) & 1));
+    sgn = (r == 1) ? 1.f : -1.f;
+    // U fragments go straight from the slab to the MFMA operand registers of the lane that uses them (32 channels x 32
+    // bytes contiguous per half wave): no LDS round trip for the filter bank
+    const int fr_ = lane & 31, fh_ = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u_src[j] = (uint32_t)(((4 * j + wi) * 64 + fr_) * 32 + 16 * (fh_ ^ ((fr_ >> 3) & 1)));
+  }
+
+  float4 ldv[4], bfr[4][2];
+  const int nsteps = p.Cin / KC;
+  int f_step = 0;
+  // the per-step offsets are wave-uniform: they ride in the buffer instruction's scalar offset (not part of the range
+  // check of a raw buffer, so an out-of-range pixel stays out of range) instead of costing a VALU add per load
+  auto fetch = [&]() {
+    const int choff = f_step * (KC * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ldv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)v_src[j], choff, 0));
+    ++f_step;
+  };
+
+  auto stage = [&](int buf) {
+    float *Vd = lds + buf * STAGE_FLOATS + v_dst;
+    float4 c[4];
+    c[0] = f4sub(ldv[0], ldv[2]); c[1] = f4add(ldv[1], ldv[2]); c[2] = f4sub(ldv[2], ldv[1]); c[3] = f4sub(ldv[1], ldv[3]);
+    // c += sgn * quad_perm[2,2,1,1](c), the permute folded into the fma's DPP operand (hipcc keeps v_mov_b32_dpp + v_fmac
+    // apart).  s_nop 1: a VALU write of a VGPR needs two wait states before a DPP read of it, and the hazard
+    // recogniser does not look inside inline asm.
+#define IDIFF_QFMA(x) "v_fmac_f32_dpp " x ", " x ", %16 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    asm volatile("s_nop 1\n" IDIFF_QFMA("%0") IDIFF_QFMA("%1") IDIFF_QFMA("%2") IDIFF_QFMA("%3") IDIFF_QFMA("%4") IDIFF_QFMA("%5")
+                 IDIFF_QFMA("%6") IDIFF_QFMA("%7") IDIFF_QFMA("%8") IDIFF_QFMA("%9") IDIFF_QFMA("%10") IDIFF_QFMA("%11")
+                 IDIFF_QFMA("%12") IDIFF_QFMA("%13") IDIFF_QFMA("%14") IDIFF_QFMA("%15")
+                 : "+v"(c[0].x), "+v"(c[0].y), "+v"(c[0].z), "+v"(c[0].w), "+v"(c[1].x), "+v"(c[1].y), "+v"(c[1].z), "+v"(c[1].w),
+                   "+v"(c[2].x), "+v"(c[2].y), "+v"(c[2].z), "+v"(c[2].w), "+v"(c[3].x), "+v"(c[3].y), "+v"(c[3].z), "+v"(c[3].w)
+                 : "v"(sgn));
+#undef IDIFF_QFMA
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(Vd + j * 4 * V_SLOT) = c[j];
+  };
+
+  floatx16 acc[8];   // [j][channel half]; PEEL: first written by the MFMAs of step 0 (the 2 x 128 v_mov_b32 of an explicit
+                     // initialisation were 11 % of a wave's non-MFMA VALU work)
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int frag = fr * KC + 4 * (fh ^ ((fr >> 3) & 1));
+  const int a_frag = wi * V_SLOT + tb * 32 * KC + frag;       // slot of position (wi, j): 4j + wi
+
+  auto load_b = [&](int j, int step) {
+    const int slab = (step * p.tiles_n + tile_n) * (OPER_FLOATS * 4);
+    bfr[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[j], slab, 0));
+    bfr[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[j] + 32 * 32, slab, 0));
+  };
+  auto compute = [&](int buf, int j0, int s, auto first) {
+    const float *S = lds + buf * STAGE_FLOATS;
+#pragma unroll
+    for (int j = j0; j < j0 + 2; ++j) {
+      const float4 a = *reinterpret_cast<const float4 *>(S + a_frag + 4 * j * V_SLOT);
+      const float4 b0 = bfr[j][0], b1 = bfr[j][1];
+      if constexpr (decltype(first)::value) {
+        const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, zero, 0, 0, 0);
+        acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, zero, 0, 0, 0);
+      } else {
+        acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[2 * j], 0, 0, 0);
+        acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[2 * j + 1], 0, 0, 0);
+      }
+      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[2 * j], 0, 0, 0);
+      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[2 * j + 1], 0, 0, 0);
+      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[2 * j], 0, 0, 0);
+      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[2 * j + 1], 0, 0, 0);
+      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[2 * j], 0, 0, 0);
+      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[2 * j + 1], 0, 0, 0);
+      // the registers are free once these MFMAs have read them; the last step re-requests its own slab (clamped, not
+      // skipped: no branch per position, and the scalar offset of a raw buffer is not range-checked, so it must stay valid)
+      load_b(j, min(s + 1, nsteps - 1));
+    }
+  };
+  auto step = [&](int s, auto first) {
+    const int buf = s & 1;
+    if (early) {
+      if (s + 1 < nsteps) stage(buf ^ 1);   // loaded one step ago
+      if (s + 2 < nsteps) fetch();
+    }
+    compute(buf, 0, s, first);
+    __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of the two halves from being hoisted together
+    compute(buf, 2, s, first);
+    if (!early) {
+      if (s + 1 < nsteps) stage(buf ^ 1);
+      if (s + 2 < nsteps) fetch();
+    }
+    __syncthreads();
+  };
+
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load_b(j, 0);
+  fetch();
+  stage(0);
+  if (nsteps > 1) fetch();
+  __syncthreads();
+
+  if constexpr (PEEL) {
+    step(0, std::true_type());
+    for (int s = 1; s < nsteps; ++s) step(s, std::false_type());
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int s = 0; s < nsteps; ++s) step(s, std::false_type());
+  }
+
+  wino_tail(p, acc, lds, tile0, n0, tile_m, tid, lane, wave, wi, tb);
 #ifdef IDIFF_WINO_STAMP
+  const idiff_epilogue &ep = p.ep;
+  const bool has_ep = p.has_ep != 0;
   if (has_ep && ep.colstats && tid == 0) {
     // shader-clock ticks and 100 MHz ticks of this workgroup's lifetime, in a buffer nothing else reads
     uint64_t *st = reinterpret_cast<uint64_t *>(ep.colstats) + 2 * (int64_t)blockIdx.x;
@@ -436,6 +444,248 @@ winograd_kernel(const WinoParams p) {
     st[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Split-precision form: the same algorithm with the 16 position-wise contractions M_p = V_p U_p^T on the bf16 matrix cores.
+// Every fp32 operand element is cut EXACTLY into three bf16 pieces (8 + 8 + 8 mantissa bits, x = x1 + x2 + x3) and a product
+// is the six partial products of weight >= 2^-16, fp32 accumulation: what is left out is < 2^-23 |a b| per product, one fp32
+// rounding (igemm.hip, split4; measured 1.7e-7 against 2.0e-7 for the fp32 MFMA chain).  v_mfma_f32_32x32x16_bf16 retires
+// 16 channels in 32 cycles where the fp32 form needs 8 x 64: six of them are 2.7x cheaper, and they leave the vector ALU
+// free for the transforms and the splitting.
+//   * U is split once, in idiff_winograd_pack_split_f32: per 16-channel step, output tile, position and piece a block of
+//     [64 cout][16 cin] bf16 (32 bytes per output channel: the fragment of lane half 0, then that of lane half 1).
+//   * V stays fp32 in LDS, in the layout of the fp32 kernel: a 16-channel step is two of its 8-channel stages.  Lane
+//     (tile fr, half fh) reads the eight channels of stage fh for its tile (two 16-byte reads, the conflict-free one first:
+//     lane half 1 therefore gets its two quads in the opposite order, and the packed U matches) and splits them in
+//     registers: each V element is consumed by exactly one wave, so splitting on the reading side costs the same vector
+//     work as on the writing side and keeps the LDS traffic at 4 bytes per element.
+//   * one wave per SIMD (4 waves, 133 KB of LDS: two double-buffered stages; 128 accumulators + 96 registers of U
+//     fragments per wave do not fit two waves per SIMD), so everything that is not an MFMA -- ~180 instructions of
+//     splitting, 96 of input transform, 8 + 8 LDS, 32 memory instructions per 48 MFMAs -- has to issue in the shadow of
+//     the wave's own matrix instructions: the step body is one basic block (loads beyond the last step are clamped or out of
+//     range, nothing is conditional) and the scheduler is told the interleaving (sched_group_barrier).
+//   STATUS (round 3, measured): parity as the fp32 kernel (tests/test_hip_ops.py, both forms at 3e-6 against an fp64
+//   convolution), speed 0.8x of it -- 178-230 TFLOP/s direct-equivalent against 225-270.  PMC on [2240,16,16,256]->256: the
+//   matrix pipe is busy 24.6k of a wave's 104k cycles (65.5k of 82k per SIMD slot in the fp32 kernel), 5870 vector
+//   instructions per wave against 2600, 49k cycles waiting to issue: with ONE wave per SIMD nothing covers a wait, and the
+//   compiler's schedule leaves vector blocks of 25-45 instructions between clusters of matrix instructions.  Not used
+//   unless IDIFF_WINO_SPLIT=1; what it would take (two waves per SIMD: 64 tiles / 8 waves with U fetched a step ahead does
+//   not fit 256 registers; a 32-channel output tile does) is in DESIGN.md 7.3.
+constexpr int SPLIT_KC = 16;
+constexpr size_t SPLIT_LDS_BYTES = sizeof(float) * (size_t)(4 * STAGE_FLOATS > TAIL_FLOATS ? 4 * STAGE_FLOATS : TAIL_FLOATS);   // 133 KB
+constexpr int SPLIT_POS_BYTES = 3 * 64 * SPLIT_KC * 2;          // one position of one slab: 3 pieces x [64 cout][16 cin] bf16
+constexpr int SPLIT_SLAB_BYTES = NPOS * SPLIT_POS_BYTES;        // 98304
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float4 lo, const float4 hi, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
+  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uintx4 q1, q2, q3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t t1[2], t2[2], t3[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      t1[e] = __float_as_uint(x[2 * j + e]) & 0xffff0000u;
+      const float r1 = x[2 * j + e] - __uint_as_float(t1[e]);
+      t2[e] = __float_as_uint(r1) & 0xffff0000u;
+      t3[e] = __float_as_uint(r1 - __uint_as_float(t2[e]));
+    }
+    q1[j] = (t1[0] >> 16) | t1[1];
+    q2[j] = (t2[0] >> 16) | t2[1];
+    q3[j] = (t3[0] >> 16) | (t3[1] & 0xffff0000u);
+  }
+  p1 = __builtin_bit_cast(bf16x8, q1); p2 = __builtin_bit_cast(bf16x8, q2); p3 = __builtin_bit_cast(bf16x8, q3);
+}
+
+__global__ void __launch_bounds__(THREADS, 1)
+winograd_split_kernel(const WinoParams p) {
+  static_assert(WG_TILES == 32, "the split kernel is written for 4 waves of 32 tiles");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int per_group = p.tiles_m * p.ngroup;
+  const int grp = bid / per_group, in_grp = bid - grp * per_group;
+  const int tile_n = grp * p.ngroup + in_grp % p.ngroup, tile_m = in_grp / p.ngroup;
+  const int tile0 = tile_m * WG_TILES, n0 = tile_n * WG_COUT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave & 3, tb = 0;
+
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
+
+  // ---------------------------------------------------------------- loader state (as the fp32 kernel: thread = row r of the
+  // 4x4 patch of one (tile, 4-channel quad) unit; here it serves quad q of BOTH 8-channel stages of a step)
+  uint32_t v_src[4], u_src[4];
+  int v_dst;
+  float sgn;
+  {
+    const int r = tid & 3, q = (tid >> 2) & 1, tl = tid >> 3;
+    const int T = tile0 + tl;
+    const bool tv = T < p.total_tiles;
+    const int TT = tv ? T : 0;
+    int img, ty, tx;
+    split_tile(p, TT, img, ty, tx);
+    const int y = 2 * ty - 1 + r, x0 = 2 * tx - 1;
+    const bool yok = tv && y >= 0 && y < p.H;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xx = x0 + j;
+      v_src[j] = (yok && xx >= 0 && xx < p.W) ? (uint32_t)(((img * p.H + y) * p.W + xx) * p.Cin + q * 4) * 4u : INVALID_PIXEL;
+    }
+    v_dst = r * V_SLOT + tl * KC + 4 * (q ^ ((tl >> 3) & 1));
+    sgn = (r == 1) ? 1.f : -1.f;
+    const int fr_ = lane & 31, fh_ = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u_src[j] = (uint32_t)((4 * j + wi) * SPLIT_POS_BYTES + fr_ * (SPLIT_KC * 2) + 16 * fh_);
+  }
+
+  float4 ldv[2][4];
+  uintx4 bfr[4][2][3];              // [position j][cout half][piece]
+  const int nsteps = p.Cin / SPLIT_KC;
+  int f_step = 0;
+  auto fetch = [&]() {
+    // Unconditional (no branch in the step body).  Beyond the last step the LAST step is fetched again -- never consumed;
+    // the scalar offset of a raw buffer load is not range-checked, so it must not run past the tensor.
+    const int choff = min(f_step, nsteps - 1) * (SPLIT_KC * 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ldv[h][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)v_src[j], choff + h * (KC * 4), 0));
+    ++f_step;
+  };
+  // c += sgn * quad_perm[2,2,1,1](c): the row mixing of the input transform.  Written with the DPP move builtin (two
+  // instructions per value where the fp32 kernel's inline asm has one fused v_fmac_f32_dpp): an asm block is a wall for the
+  // scheduler, and this kernel needs the transform interleaved with the matrix instructions.
+  auto qmix = [&](float v) -> float {
+    const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x5A /* quad_perm:[2,2,1,1] */, 0xf, 0xf, true);
+    return fmaf(sgn, __int_as_float(m), v);
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float *Vd = lds + (buf * 2 + h) * STAGE_FLOATS + v_dst;
+      float4 c[4];
+      c[0] = f4sub(ldv[h][0], ldv[h][2]); c[1] = f4add(ldv[h][1], ldv[h][2]); c[2] = f4sub(ldv[h][2], ldv[h][1]); c[3] = f4sub(ldv[h][1], ldv[h][3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c[j] = make_float4(qmix(c[j].x), qmix(c[j].y), qmix(c[j].z), qmix(c[j].w));
+        *reinterpret_cast<float4 *>(Vd + j * 4 * V_SLOT) = c[j];
+      }
+    }
+  };
+
+  floatx16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5, sw = (fr >> 3) & 1;
+  // stage fh, row fr; first the half the fp32 kernel's lane would read (conflict-free), then the other one
+  const int a_first = fh * STAGE_FLOATS + wi * V_SLOT + fr * KC + 4 * (fh ^ sw);
+  const int a_second = fh * STAGE_FLOATS + wi * V_SLOT + fr * KC + 4 * (fh ^ sw ^ 1);
+
+  auto load_b = [&](int j, int step) {
+    const int slab = (step * p.tiles_n + tile_n) * SPLIT_SLAB_BYTES;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        bfr[j][hb][q] = __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[j] + q * (64 * SPLIT_KC * 2) + hb * (32 * SPLIT_KC * 2), slab, 0);
+  };
+
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load_b(j, 0);
+  fetch();
+  stage(0);
+  fetch();
+  __syncthreads();
+
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // the six partial products, smallest first
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    const float *S = lds + buf * 2 * STAGE_FLOATS;
+    float4 alo[4], ahi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      alo[j] = *reinterpret_cast<const float4 *>(S + a_first + 4 * j * V_SLOT);
+      ahi[j] = *reinterpret_cast<const float4 *>(S + a_second + 4 * j * V_SLOT);
+    }
+    // the next step's input: transform + LDS writes of the values fetched one step ago, then the fetch for the step after
+    stage(buf ^ 1);
+    fetch();
+    const int snext = min(s + 1, nsteps - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x8 a[3];
+      split8(alo[j], ahi[j], a[0], a[1], a[2]);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+          acc[2 * j + hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]], __builtin_bit_cast(bf16x8, bfr[j][hb][PB[t]]), acc[2 * j + hb], 0, 0, 0);
+      load_b(j, snext);
+    }
+    // 48 MFMAs; ~5 vector instructions fit in the shadow of each
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      if (k % 6 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // 8 LDS writes
+      if (k % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // 32 memory reads (24 of U, 8 of x)
+    }
+    __syncthreads();
+  }
+  wino_tail(p, acc, lds, tile0, n0, tile_m, tid, lane, wave, wi, tb);
+}
+
+// U = G g G^T (fp64, rounded once to fp32 exactly as idiff_winograd_pack_f32 does), then cut into the three bf16 pieces and
+// laid out for winograd_split_kernel: [Cin / 16][Cout / 64][16 positions][3 pieces][64 cout][16 cin], where the 16 channels
+// of a row are the eight of lane half 0 (channels 0 .. 7 of the step) followed by the eight of lane half 1 in ITS reading
+// order (channels 12 .. 15, then 8 .. 11).
+__global__ void winograd_pack_split_kernel(const float *wt, unsigned short *u, int Cin, int Cout) {
+  const int64_t total = (int64_t)Cin * Cout;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cin = (int)(idx % Cin), cout = (int)(idx / Cin);
+    double g[3][3];
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)wt[((int64_t)cout * 9 + ky * 3 + kx) * Cin + cin];
+    double gg[4][3];   // G g
+    for (int kx = 0; kx < 3; ++kx) {
+      gg[0][kx] = g[0][kx];
+      gg[1][kx] = 0.5 * (g[0][kx] + g[1][kx] + g[2][kx]);
+      gg[2][kx] = 0.5 * (g[0][kx] - g[1][kx] + g[2][kx]);
+      gg[3][kx] = g[2][kx];
+    }
+    const int s = cin / SPLIT_KC, c16 = cin % SPLIT_KC, nt = cout / WG_COUT, co = cout % WG_COUT;
+    const int half = c16 >> 3, e = c16 & 7;
+    const int pos_in_row = half * 8 + (half ? ((e >> 2) ^ 1) * 4 + (e & 3) : e);
+    unsigned short *dst = u + ((int64_t)(s * (Cout / WG_COUT) + nt) * NPOS * 3 * 64 + co) * SPLIT_KC + pos_in_row;
+    for (int i = 0; i < 4; ++i) {
+      const double r0 = gg[i][0], r1 = gg[i][1], r2 = gg[i][2];
+      const double v[4] = {r0, 0.5 * (r0 + r1 + r2), 0.5 * (r0 - r1 + r2), r2};
+      const double sign = i == 3 ? -1.0 : 1.0;     // the kernel's input transform produces row 3 negated
+      for (int j = 0; j < 4; ++j) {
+        const float x = (float)(sign * v[j]);
+        const uint32_t t1 = __float_as_uint(x) & 0xffff0000u;
+        const float r1f = x - __uint_as_float(t1);
+        const uint32_t t2 = __float_as_uint(r1f) & 0xffff0000u;
+        const uint32_t t3 = __float_as_uint(r1f - __uint_as_float(t2));
+        unsigned short *d = dst + (int64_t)(j * 4 + i) * 3 * 64 * SPLIT_KC;
+        d[0] = (unsigned short)(t1 >> 16);
+        d[64 * SPLIT_KC] = (unsigned short)(t2 >> 16);
+        d[2 * 64 * SPLIT_KC] = (unsigned short)(t3 >> 16);
+      }
+    }
+  }
 }
 
 // U = G g G^T in fp64, rounded once; g[ky][kx] = wt[cout][ky][kx][cin] (the K-contiguous panel of the direct kernel).
@@ -492,6 +742,28 @@ IDIFF_API int idiff_conv2d_winograd_colstats_split(int B, int H, int W, int Cin,
 
 IDIFF_API int64_t idiff_winograd_weight_floats(int Cin, int Cout) { return (int64_t)16 * Cin * Cout; }
 
+// The split-precision form (winograd_split_kernel): Cin % 16 == 0 on top of the fp32 kernel's conditions.  OPT-IN
+// (IDIFF_WINO_SPLIT): correct to the same bars, but measured 0.8x the fp32 kernel on the NCSN++ layers.
+IDIFF_API int idiff_conv2d_winograd_split_ok(int B, int H, int W, int Cin, int Cout) {
+  if (!idiff::option(idiff::OPT_WINO_SPLIT) || idiff::option(idiff::OPT_NO_SPLIT) || idiff::option(idiff::OPT_NO_WINOGRAD)) return 0;
+  if (!geometry_ok(B, H, W, Cin, Cout) || Cin % SPLIT_KC) return 0;
+  if ((int64_t)24 * Cin * Cout * 4 >= X_LIMIT) return 0;
+  return 1;
+}
+
+IDIFF_API int64_t idiff_winograd_split_weight_floats(int Cin, int Cout) { return (int64_t)24 * Cin * Cout; }   // 3 bf16 per weight
+
+IDIFF_API int idiff_winograd_pack_split_f32(const float *wt, float *u, int Cin, int Cout, void *stream) {
+  using namespace idiff;
+  if (Cin <= 0 || Cout <= 0 || Cin % SPLIT_KC || Cout % WG_COUT)
+    return fail("winograd_pack_split: Cin must be a multiple of %d and Cout of %d (got %d, %d)", SPLIT_KC, WG_COUT, Cin, Cout);
+  if (!wt || !u) return fail("winograd_pack_split: null pointer");
+  const int64_t total = (int64_t)Cin * Cout;
+  hipLaunchKernelGGL(winograd_pack_split_kernel, dim3(streaming_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, wt,
+                     reinterpret_cast<unsigned short *>(u), Cin, Cout);
+  return launch_status("winograd_pack_split");
+}
+
 IDIFF_API int idiff_winograd_pack_f32(const float *wt, float *u, int Cin, int Cout, void *stream) {
   using namespace idiff;
   if (Cin <= 0 || Cout <= 0 || Cin % KC || Cout % WG_COUT)
@@ -502,8 +774,23 @@ IDIFF_API int idiff_winograd_pack_f32(const float *wt, float *u, int Cin, int Co
   return launch_status("winograd_pack");
 }
 
+namespace {
+int conv2d_winograd_impl(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
+                         const idiff_epilogue *ep, void *stream, bool split);
+}
 IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
                                         const idiff_epilogue *ep, void *stream) {
+  return conv2d_winograd_impl(x, u, out, B, H, W, Cin, Cout, ep, stream, false);
+}
+// u: the bank of idiff_winograd_pack_split_f32
+IDIFF_API int idiff_conv2d_winograd_split_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
+                                              const idiff_epilogue *ep, void *stream) {
+  if (Cin % SPLIT_KC) return idiff::fail("conv2d_winograd_split: Cin must be a multiple of %d (got %d)", SPLIT_KC, Cin);
+  return conv2d_winograd_impl(x, u, out, B, H, W, Cin, Cout, ep, stream, true);
+}
+namespace {
+int conv2d_winograd_impl(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
+                         const idiff_epilogue *ep, void *stream, bool split) {
   using namespace idiff;
   if (B == 0) return 0;
   if (!geometry_ok(B, H, W, Cin, Cout))
@@ -532,9 +819,9 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
       if (hi.residual) hi.residual += m_lo * ep->ld_residual;
       if (hi.rowscale) hi.rowscale += g0;
     }
-    int rc = idiff_conv2d_winograd_f32(x, u, out, b_lo, H, W, Cin, Cout, ep ? &lo : nullptr, stream);
+    int rc = conv2d_winograd_impl(x, u, out, b_lo, H, W, Cin, Cout, ep ? &lo : nullptr, stream, split);
     if (rc) return rc;
-    return idiff_conv2d_winograd_f32(x + m_lo * Cin, u, out + m_lo * Cout, B - b_lo, H, W, Cin, Cout, ep ? &hi : nullptr, stream);
+    return conv2d_winograd_impl(x + m_lo * Cin, u, out + m_lo * Cout, B - b_lo, H, W, Cin, Cout, ep ? &hi : nullptr, stream, split);
   }
   WinoParams p = {};
   p.x = x; p.u = u; p.out = out; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
@@ -550,7 +837,7 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
     const int want = option_value(OPT_WINO_NGROUP);
     p.ngroup = (want > 0 && p.tiles_n % want == 0) ? want : ((p.tiles_n > 2 && p.tiles_n % 2 == 0) ? 2 : p.tiles_n);
   }
-  p.x_bytes = (uint32_t)x_bytes; p.u_bytes = (uint32_t)((int64_t)16 * Cin * Cout * 4);
+  p.x_bytes = (uint32_t)x_bytes; p.u_bytes = (uint32_t)((int64_t)(split ? 24 : 16) * Cin * Cout * 4);
   p.out_bytes = (uint32_t)out_bytes; p.res_bytes = (uint32_t)res_bytes;
   if (ep) {
     p.ep = *ep; p.has_ep = 1;
@@ -567,9 +854,17 @@ IDIFF_API int idiff_conv2d_winograd_f32(const float *x, const float *u, float *o
     if (int rc = set_dynamic_lds_once(guard, fns, 2, (int)LDS_BYTES, "conv2d_winograd")) return rc;
   }
   const int nwg = p.tiles_m * p.tiles_n;
+  if (split) {
+    static AttrGuard sguard;
+    const void *fn = reinterpret_cast<const void *>(winograd_split_kernel);
+    if (int rc = set_dynamic_lds_once(sguard, &fn, 1, (int)SPLIT_LDS_BYTES, "conv2d_winograd_split")) return rc;
+    hipLaunchKernelGGL(winograd_split_kernel, dim3(nwg), dim3(THREADS), SPLIT_LDS_BYTES, (hipStream_t)stream, p);
+    return launch_status("conv2d_winograd_split");
+  }
   if (nwg >= PEEL_MIN_WORKGROUPS)
     hipLaunchKernelGGL(winograd_kernel<true>, dim3(nwg), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL(winograd_kernel<false>, dim3(nwg), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, p);
   return launch_status("conv2d_winograd");
 }
+}  // namespace

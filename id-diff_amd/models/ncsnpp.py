@@ -375,7 +375,7 @@ class NCSNpp(HipScoreModel):
             # Winograd F(2x2, 3x3): 2.25x fewer MFMA flops; the transformed filter bank is cached beside the panel
             bank = self._packed.setdefault("wino", {})
             if id(wt) not in bank:
-                bank[id(wt)] = (wt, _lib.winograd_pack(wt, cin, cout))
+                bank[id(wt)] = (wt, _lib.winograd_pack(wt, cin, cout, B_hint=(B, x.H, x.W)))
             if stats:
                 ns = _lib.conv2d_winograd_colstats_split(B, x.H, x.W, cin, cout)
                 if ns > 0:

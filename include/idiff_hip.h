@@ -38,8 +38,11 @@ const char *idiff_source_stamp(void);
  * IDIFF_DBUF_ONLY, IDIFF_TRIDIAG_ONESTAGE (per-column Householder instead of the two-stage band reduction),
  * IDIFF_UFD_ROWS, IDIFF_CHASE_WAVEFRONT (bulge chasing one launch per wavefront instead of the persistent systolic kernel),
  * IDIFF_CHASE_SPIN_LIMIT (polls before a waiting node of the systolic chase gives up; default 2^24), IDIFF_FAKE_CU_COUNT
- * (CU count used when sizing the systolic chase; tests).  Returns the previous value, -1 for an unknown name.
- * No reference counterpart. */
+ * (CU count used when sizing the systolic chase; tests), IDIFF_SBR_SYNC (band reduction waits for and names every launch on
+ * stderr: a fault then names its kernel), IDIFF_SBR_FULL (band reduction keeps both triangles up to date, the round-2 form),
+ * IDIFF_NO_SPLIT (contractions of idiff_gemm_f32 / idiff_conv2d_nhwc_f32 on the fp32 matrix cores instead of the
+ * split-precision products described there), IDIFF_WINO_SPLIT (opt-in: the split-precision Winograd kernel).
+ * Returns the previous value, -1 for an unknown name.  No reference counterpart. */
 int idiff_set_option(const char *name, int value);
 
 /* ------------------------------------------------------------------ native ops (op/) */
@@ -61,7 +64,7 @@ int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, int major, i
 int idiff_fused_bias_act_f32(const float *x, const float *b, const float *ref, float *out, int64_t n,
                              int step_b, int size_b, int act, int grad, float alpha, float scale, void *stream);
 
-/* ------------------------------------------------------------------ dense contractions (fp32 MFMA) */
+/* ------------------------------------------------------------------ dense contractions (fp32 in, fp32 out) */
 
 /* Activation codes shared by the epilogues below. */
 #define IDIFF_ACT_NONE 0
@@ -96,7 +99,12 @@ typedef struct idiff_epilogue {
 
 /* Batched C[b] = epilogue(A[b] (M x K, row-major, lda) * Bt[b]^T (Bt is N x K, row-major, ldb)).
  * Replaces torch.nn.Linear (models/fcn.py:18-28), NIN / 1x1 conv contractions (models/layers.py:555-564),
- * and the two attention einsums of models/layerspp.py:82-86.  Exact fp32 (v_mfma_f32_32x32x2_f32).
+ * and the two attention einsums of models/layerspp.py:82-86.  fp32 operands and results.  Arithmetic of the fast path
+ * (16-byte aligned K-contiguous operands below 4 GiB): every operand element is cut EXACTLY into three bf16 pieces
+ * (8 + 8 + 8 mantissa bits) and a product is formed as the six partial products of weight >= 2^-16 on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; what is left out is < 2^-23 of the product, the size of one fp32
+ * rounding (1.7e-7 against an fp64 contraction where the k-ordered fp32 fma chain of v_mfma_f32_32x32x2_f32 gives
+ * 2.0e-7).  IDIFF_NO_SPLIT selects that fp32 chain; operands the fast path does not take always use it.
  * batch strides are in elements; a stride of 0 broadcasts that operand.  The epilogue pointers are
  * shared by all batch entries. */
 int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt, int64_t ldb, int64_t strideB,
@@ -143,6 +151,19 @@ int idiff_winograd_pack_f32(const float *wt, float *u, int Cin, int Cout, void *
 int idiff_conv2d_winograd_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
                               const idiff_epilogue *ep, void *stream);
 int idiff_conv2d_winograd_colstats_split(int B, int H, int W, int Cin, int Cout);
+/* Split-precision form of the same convolution: the 16 position-wise contractions run on the bf16 matrix cores with every
+ * fp32 operand cut exactly into three bf16 pieces and six of the nine partial products kept (fp32 accumulation; what is
+ * dropped is < 2^-23 of a product, one fp32 rounding -- the result meets the same parity bars as the fp32 form).
+ *   idiff_conv2d_winograd_split_ok       1 when served: the fp32 form's conditions, Cin % 16 == 0, and IDIFF_WINO_SPLIT set
+ *                                        (opt-in: measured slower than the fp32 form on the NCSN++ layers).
+ *   idiff_winograd_split_weight_floats   size of its filter bank (24 * Cin * Cout floats: three bf16 per transformed weight).
+ *   idiff_winograd_pack_split_f32        wt [Cout, 3, 3, Cin] -> that bank, once per layer.
+ *   idiff_conv2d_winograd_split_f32      as idiff_conv2d_winograd_f32 with that bank (same epilogue, same colstats split). */
+int idiff_conv2d_winograd_split_ok(int B, int H, int W, int Cin, int Cout);
+int64_t idiff_winograd_split_weight_floats(int Cin, int Cout);
+int idiff_winograd_pack_split_f32(const float *wt, float *u, int Cin, int Cout, void *stream);
+int idiff_conv2d_winograd_split_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
+                                    const idiff_epilogue *ep, void *stream);
 
 /* ------------------------------------------------------------------ normalisation / pointwise (HBM-bound) */
 

@@ -1,4 +1,4 @@
-"""One Winograd conv shape, a few launches (for rocprofv3 --pmc runs): wino_one.py H Cin Cout [B]."""
+"""One Winograd conv shape, a few launches (for rocprofv3 --pmc runs): wino_one.py H Cin Cout [B] [split]."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,8 @@ B = int(sys.argv[4]) if len(sys.argv) > 4 else 2240
 dev = torch.device("cuda:0")
 x = torch.randn(B, H * H, Cin, device=dev)
 w = torch.randn(Cout, 3, 3, Cin, device=dev) / (9 * Cin) ** 0.5
-u = _lib.winograd_pack(w, Cin, Cout)
+split = len(sys.argv) > 5 and sys.argv[5] == 'split'
+u = _lib.winograd_pack(w, Cin, Cout, B_hint=(B, H, H) if split else None)
 o = torch.empty(B, H * H, Cout, device=dev)
 ep = _lib.make_epilogue(bias=torch.randn(Cout, device=dev))
 for _ in range(4):

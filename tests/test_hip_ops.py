@@ -234,11 +234,17 @@ def test_conv2d_narrow_head_vs_cpu(B, H, W, Cout):
     assert rel_err(out.cpu(), direct.double().cpu()) < 2e-6
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 32, 32, 128, 128), (5, 16, 16, 256, 64), (7, 8, 8, 64, 128),
-                                              (9, 4, 4, 32, 64), (2, 6, 10, 8, 64), (1, 2, 2, 16, 64), (33, 4, 4, 8, 64)])
-def test_conv2d_winograd_vs_cpu(B, H, W, Cin, Cout):
+                                              (9, 4, 4, 32, 64), (2, 6, 10, 8, 64), (1, 2, 2, 16, 64), (33, 4, 4, 8, 64),
+                                              (2, 16, 16, 512, 256), (130, 2, 2, 48, 64)])
+def test_conv2d_winograd_vs_cpu(B, H, W, Cin, Cout, split):
     """F(2x2, 3x3) conv against the fp64 CPU convolution, with every epilogue term (per-sample bias, activation,
-    residual, scales); tile counts that do not fill a workgroup, maps smaller than a workgroup's 64 tiles."""
+    residual, scales); tile counts that do not fill a workgroup, maps smaller than a workgroup's 64 tiles.  Both forms of
+    the position-wise contractions -- fp32 matrix cores, and operands cut exactly into three bf16 pieces with six partial
+    products on the bf16 matrix cores -- are held to the same 3e-6."""
+    if split and Cin % 16:
+        pytest.skip("the split-precision kernel takes 16 channels per step")
     g = torch.Generator().manual_seed(B * H + Cin)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
@@ -249,7 +255,12 @@ def test_conv2d_winograd_vs_cpu(B, H, W, Cin, Cout):
     assert _lib.conv2d_winograd_ok(B, H, W, Cin, Cout)
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     wt = w.permute(0, 2, 3, 1).contiguous().to(DEV)
-    u = _lib.winograd_pack(wt, Cin, Cout)
+    prev = _lib.set_option("IDIFF_WINO_SPLIT", 1)          # the split-precision Winograd kernel is opt-in
+    try:
+        u = _lib.winograd_pack(wt, Cin, Cout, B_hint=(B, H, W) if split else None)
+    finally:
+        _lib.set_option("IDIFF_WINO_SPLIT", int(prev))
+    assert u.numel() == (24 if split else 16) * Cin * Cout
     out = torch.empty(B, H, W, Cout, device=DEV)
     _lib.conv2d_winograd(xd, u, out, B, H, W, Cin, Cout, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
@@ -341,8 +352,9 @@ def test_conv2d_winograd_rejects_what_it_cannot_take():
         _lib.conv2d_winograd(x, torch.zeros(16 * 32 * 64, device=DEV), torch.zeros(2, 7, 8, 64, device=DEV), 2, 7, 8, 32, 64)
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "split"])
 @pytest.mark.parametrize("B,H,Cin,Cout", [(3, 32, 64, 128), (6, 16, 128, 64), (5, 8, 64, 128), (11, 4, 32, 64), (64, 4, 8, 64)])
-def test_winograd_colstats_feed_groupnorm(B, H, Cin, Cout):
+def test_winograd_colstats_feed_groupnorm(B, H, Cin, Cout, split):
     """Column sums from the conv epilogue = a statistics pass over its output; maps of 8x8 and 4x4 (several whole samples per
     workgroup, one slot per sample) with sample counts that leave the last workgroup partly empty."""
     g = torch.Generator().manual_seed(B)
@@ -353,7 +365,15 @@ def test_winograd_colstats_feed_groupnorm(B, H, Cin, Cout):
     assert ns == max(1, H * H // 128)                   # 32 output tiles (of 2x2 pixels) per workgroup
     cs = torch.empty(B * ns * Cout * 2, device=DEV, dtype=torch.float64)
     out = torch.empty(B, H * H, Cout, device=DEV)
-    _lib.conv2d_winograd(x, _lib.winograd_pack(w, Cin, Cout), out, B, H, H, Cin, Cout,
+    if split and Cin % 16:
+        pytest.skip("the split-precision kernel takes 16 channels per step")
+    prev = _lib.set_option("IDIFF_WINO_SPLIT", 1)
+    try:
+        u = _lib.winograd_pack(w, Cin, Cout, B_hint=(B, H, H) if split else None)
+    finally:
+        _lib.set_option("IDIFF_WINO_SPLIT", int(prev))
+    assert u.numel() == (24 if split else 16) * Cin * Cout
+    _lib.conv2d_winograd(x, u, out, B, H, H, Cin, Cout,
                          epilogue=_lib.make_epilogue(bias=bias, act="silu", rows_per_group=H * H, colstats=cs))
     G = 32
     st_a, st_b = torch.empty(B * G * 2, device=DEV), torch.empty(B * G * 2, device=DEV)
