@@ -232,9 +232,28 @@ upfirdn2d_planes_rowslide(const float *__restrict__ x, const float *__restrict__
   const int plane0 = blockIdx.x * ppb;
   const int nplanes = min(ppb, p.major - plane0);
   const float *src = x + (int64_t)plane0 * psz;
-  for (int i = tid; i < nplanes * psz; i += 256) {
-    const int q = i / psz, r = i - q * psz, iy = r / p.in_w, ix = r - iy * p.in_w;
-    pl[q * lpsz + iy * pitch + ix] = src[i];
+  if ((p.in_w & 3) == 0 && ((((uintptr_t)src) & 15) == 0)) {
+    // 16-byte loads (the planes of a workgroup are one contiguous run; a row is a whole number of float4), and the
+    // (plane, row, column) of an element by one division per thread and running sums instead of two divisions per element:
+    // the fill was a third of this kernel's time on 16 x 16 planes
+    const int row4 = p.in_w >> 2, n4 = (nplanes * psz) >> 2;
+    int i4 = tid;
+    int rowi = i4 / row4, c4 = i4 - rowi * row4;          // global row index over the workgroup's planes, float4 column
+    int q = rowi / p.in_h, iy = rowi - q * p.in_h;
+    const int drow = 256 / row4, dc4 = 256 - drow * row4;  // what 256 float4 further means in (rows, columns)
+    for (; i4 < n4; i4 += 256) {
+      const float4 v = reinterpret_cast<const float4 *>(src)[i4];
+      float *d = pl + q * lpsz + iy * pitch + 4 * c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      c4 += dc4; iy += drow;
+      if (c4 >= row4) { c4 -= row4; ++iy; }
+      while (iy >= p.in_h) { iy -= p.in_h; ++q; }
+    }
+  } else {
+    for (int i = tid; i < nplanes * psz; i += 256) {
+      const int q = i / psz, r = i - q * psz, iy = r / p.in_w, ix = r - iy * p.in_w;
+      pl[q * lpsz + iy * pitch + ix] = src[i];
+    }
   }
   __syncthreads();
   const int q = tid / p.out_h, oy = tid - q * p.out_h;

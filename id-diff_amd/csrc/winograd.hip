@@ -98,9 +98,15 @@ __device__ __forceinline__ void split_tile(const WinoParams &p, int T, int &img,
 }
 
 // ---------------------------------------------------------------- tail (shared by the fp32 and the split-precision kernel)
-// acc[2 j + h] = M at position (wi, j) for this wave's 32 tiles x cout half h, in the 32x32 accumulator layout.
-__device__ __forceinline__ void wino_tail(const WinoParams &p, floatx16 (&acc)[8], float *lds, const int tile0, const int n0,
+// MODE 0 (fp32 kernel, 4 waves): acc[2 j + h] = M at position (wi, j) for this wave's 32 tiles x cout half h, in the 32x32
+//   accumulator layout.
+// MODE 1 (split kernel, 8 waves): wave (wi, jh) holds only positions j = 2 jh, 2 jh + 1: acc[2 jj + h].  The waves of
+//   jh = 1 park their share of z_ib in LDS, the waves of jh = 0 add theirs on top, and waves 0 .. 3 (tid < THREADS) finish as
+//   in mode 0; the other four only keep the barriers company.
+template <int MODE>
+__device__ __forceinline__ void wino_tail(const WinoParams &p, const floatx16 *acc, float *lds, const int tile0, const int n0,
                                           const int tile_m, const int tid, const int lane, const int wave, const int wi, const int tb) {
+  const bool active = MODE == 0 || tid < THREADS;     // wave-uniform
   // This thread finishes 4 channels (n .. n+3) of tiles 2g and 2g+1: output pixels (2ty + a, 2tx + b).  Everything here
   // is VALU work that no MFMA hides (a wave's non-MFMA VALU instructions were split about evenly between the K loop and
   // prologue + tail at Cin = 256), so the tail is written to issue as few of them as it can: 32-bit byte offsets into
@@ -130,7 +136,7 @@ __device__ __forceinline__ void wino_tail(const WinoParams &p, floatx16 (&acc)[8
   uint32_t ooff[2];            // its byte offset (+ this thread's channels), INVALID_PIXEL beyond the last tile
   float4 badd[2], res[2][4];
   float sc[2];
-  {
+  if (active) {
     int T = tile0 + 2 * g, img, ty, tx;
     split_tile(p, T, img, ty, tx);
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -160,19 +166,47 @@ __device__ __forceinline__ void wino_tail(const WinoParams &p, floatx16 (&acc)[8
   // z_ib for this wave's row i: z_i0 = m_i0 + m_i1 + m_i2, z_i1 = m_i1 - m_i2 - m_i3 -> LDS [i][tile][b][cout]
   {
     float *zp = lds + ((wi * WG_TILES + tb * 32 + 4 * (lane >> 5)) * 2) * 64 + (lane & 31);
+    if (MODE == 0) {
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch)
+      for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const float m0 = acc[ch][reg], m1 = acc[2 + ch][reg], m2 = acc[4 + ch][reg], m3 = acc[6 + ch][reg];
-        const int trow = (reg & 3) + 8 * (reg >> 2);        // + 4 * (lane >> 5): row of the 32x32 accumulator tile
-        zp[(trow * 2) * 64 + ch * 32] = m0 + m1 + m2;
-        zp[(trow * 2 + 1) * 64 + ch * 32] = m1 - m2 - m3;
+        for (int reg = 0; reg < 16; ++reg) {
+          const float m0 = acc[ch][reg], m1 = acc[2 + ch][reg], m2 = acc[4 + ch][reg], m3 = acc[6 + ch][reg];
+          const int trow = (reg & 3) + 8 * (reg >> 2);        // + 4 * (lane >> 5): row of the 32x32 accumulator tile
+          zp[(trow * 2) * 64 + ch * 32] = m0 + m1 + m2;
+          zp[(trow * 2 + 1) * 64 + ch * 32] = m1 - m2 - m3;
+        }
+    } else {
+      const bool second = wave >= 4;                           // jh = 1: positions (wi, 2), (wi, 3)
+      if (second) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const float m2 = acc[ch][reg], m3 = acc[2 + ch][reg];
+            const int trow = (reg & 3) + 8 * (reg >> 2);
+            zp[(trow * 2) * 64 + ch * 32] = m2;
+            zp[(trow * 2 + 1) * 64 + ch * 32] = -m2 - m3;
+          }
       }
+      __syncthreads();
+      if (!second) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const float m0 = acc[ch][reg], m1 = acc[2 + ch][reg];
+            const int trow = (reg & 3) + 8 * (reg >> 2);
+            zp[(trow * 2) * 64 + ch * 32] = (m0 + m1) + zp[(trow * 2) * 64 + ch * 32];
+            zp[(trow * 2 + 1) * 64 + ch * 32] = m1 + zp[(trow * 2 + 1) * 64 + ch * 32];
+          }
+      }
+    }
   }
   __syncthreads();
 
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (active) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -222,6 +256,7 @@ __device__ __forceinline__ void wino_tail(const WinoParams &p, floatx16 (&acc)[8
       }
     }
   }
+  }
   if (want_stats && p.tiles_per_img < WG_TILES) {
     // Maps smaller than a workgroup (8x8: 16 tiles, 4x4: 4 tiles per sample): the workgroup holds WG_TILES / tiles_per_img
     // whole samples and writes one slot per (sample, channel), layout [B][1][Cout][2].  A thread's two tiles lie in one
@@ -229,14 +264,16 @@ __device__ __forceinline__ void wino_tail(const WinoParams &p, floatx16 (&acc)[8
     // 64 x samples threads add up the tile pairs of their sample in a fixed order.
     __syncthreads();                                          // every z has been read: the area is free again
     double *red = reinterpret_cast<double *>(lds);           // [16 tile pairs][64 channels][2]
+    if (active) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      red[((g * WG_COUT) + 4 * cq + e) * 2] = s1[e];
-      red[((g * WG_COUT) + 4 * cq + e) * 2 + 1] = s2[e];
+      for (int e = 0; e < 4; ++e) {
+        red[((g * WG_COUT) + 4 * cq + e) * 2] = s1[e];
+        red[((g * WG_COUT) + 4 * cq + e) * 2 + 1] = s2[e];
+      }
     }
     __syncthreads();
     const int pairs = p.tiles_per_img >> 1, samples = WG_TILES / p.tiles_per_img;
-    for (int o = tid; o < samples * WG_COUT; o += THREADS) {
+    for (int o = active ? tid : samples * WG_COUT; o < samples * WG_COUT; o += THREADS) {
       const int smp = o / WG_COUT, ch = o - smp * WG_COUT;
       const int64_t img = (int64_t)tile_m * samples + smp;
       if (img >= p.B) continue;
@@ -254,7 +291,7 @@ __device__ __forceinline__ void wino_tail(const WinoParams &p, floatx16 (&acc)[8
     }
     __syncthreads();                                          // every z has been read: the area is free again
     double *red = reinterpret_cast<double *>(lds);           // [NWAVES][64][2]
-    if (lane < 16) {
+    if (lane < 16 && active) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         red[((wave * WG_COUT) + 4 * cq + e) * 2] = s1[e];
@@ -433,7 +470,7 @@ winograd_kernel(const WinoParams p) {
     for (int s = 0; s < nsteps; ++s) step(s, std::false_type());
   }
 
-  wino_tail(p, acc, lds, tile0, n0, tile_m, tid, lane, wave, wi, tb);
+  wino_tail<0>(p, acc, lds, tile0, n0, tile_m, tid, lane, wave, wi, tb);
 #ifdef IDIFF_WINO_STAMP
   const idiff_epilogue &ep = p.ep;
   const bool has_ep = p.has_ep != 0;
@@ -460,20 +497,14 @@ winograd_kernel(const WinoParams p) {
 //     lane half 1 therefore gets its two quads in the opposite order, and the packed U matches) and splits them in
 //     registers: each V element is consumed by exactly one wave, so splitting on the reading side costs the same vector
 //     work as on the writing side and keeps the LDS traffic at 4 bytes per element.
-//   * one wave per SIMD (4 waves, 133 KB of LDS: two double-buffered stages; 128 accumulators + 96 registers of U
-//     fragments per wave do not fit two waves per SIMD), so everything that is not an MFMA -- ~180 instructions of
-//     splitting, 96 of input transform, 8 + 8 LDS, 32 memory instructions per 48 MFMAs -- has to issue in the shadow of
-//     the wave's own matrix instructions: the step body is one basic block (loads beyond the last step are clamped or out of
-//     range, nothing is conditional) and the scheduler is told the interleaving (sched_group_barrier).
-//   STATUS (round 3, measured): parity as the fp32 kernel (tests/test_hip_ops.py, both forms at 3e-6 against an fp64
-//   convolution), speed 0.8x of it -- 178-230 TFLOP/s direct-equivalent against 225-270.  PMC on [2240,16,16,256]->256: the
-//   matrix pipe is busy 24.6k of a wave's 104k cycles (65.5k of 82k per SIMD slot in the fp32 kernel), 5870 vector
-//   instructions per wave against 2600, 49k cycles waiting to issue: with ONE wave per SIMD nothing covers a wait, and the
-//   compiler's schedule leaves vector blocks of 25-45 instructions between clusters of matrix instructions.  Not used
-//   unless IDIFF_WINO_SPLIT=1; what it would take (two waves per SIMD: 64 tiles / 8 waves with U fetched a step ahead does
-//   not fit 256 registers; a 32-channel output tile does) is in DESIGN.md 7.3.
+//   * 8 waves = 4 rows of the transform domain x 2 pairs of positions, 32 tiles x 64 output channels per workgroup, one
+//     workgroup per CU: a wave holds 2 positions x 2 channel halves (64 accumulators) and its 12 U fragments a step ahead
+//     (48 registers), which fits TWO waves per SIMD (256 registers each) -- with one wave per SIMD (the first version: 4
+//     waves x 4 positions, 128 accumulators + 96 registers of U) nothing covered a wait and the kernel ran at 0.8x of the
+//     fp32 one, its matrix pipe busy 24 % of the time.  One LDS stage of V: fragments go to registers, a barrier, then
+//     the stage is rewritten under this step's matrix instructions.
 constexpr int SPLIT_KC = 16;
-constexpr size_t SPLIT_LDS_BYTES = sizeof(float) * (size_t)(4 * STAGE_FLOATS > TAIL_FLOATS ? 4 * STAGE_FLOATS : TAIL_FLOATS);   // 133 KB
+constexpr size_t SPLIT_LDS_BYTES = sizeof(float) * (size_t)(4 * STAGE_FLOATS > TAIL_FLOATS ? 4 * STAGE_FLOATS : TAIL_FLOATS);   // 133 KB: two stages of 2 x 8 channels
 constexpr int SPLIT_POS_BYTES = 3 * 64 * SPLIT_KC * 2;          // one position of one slab: 3 pieces x [64 cout][16 cin] bf16
 constexpr int SPLIT_SLAB_BYTES = NPOS * SPLIT_POS_BYTES;        // 98304
 
@@ -499,9 +530,11 @@ __device__ __forceinline__ void split8(const float4 lo, const float4 hi, bf16x8 
   p1 = __builtin_bit_cast(bf16x8, q1); p2 = __builtin_bit_cast(bf16x8, q2); p3 = __builtin_bit_cast(bf16x8, q3);
 }
 
-__global__ void __launch_bounds__(THREADS, 1)
+constexpr int SPLIT_THREADS = 512;
+
+__global__ void __launch_bounds__(SPLIT_THREADS, 1)
 winograd_split_kernel(const WinoParams p) {
-  static_assert(WG_TILES == 32, "the split kernel is written for 4 waves of 32 tiles");
+  static_assert(WG_TILES == 32 && THREADS == 256, "the split kernel is written for 32 tiles: 8 waves = 4 rows x 2 position pairs");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
@@ -515,18 +548,18 @@ winograd_split_kernel(const WinoParams p) {
   const int tile0 = tile_m * WG_TILES, n0 = tile_n * WG_COUT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = wave & 3, tb = 0;
+  const int wi = wave & 3, jh = wave >> 2;          // transform-domain row; positions j = 2 jh, 2 jh + 1
 
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
 
-  // ---------------------------------------------------------------- loader state (as the fp32 kernel: thread = row r of the
-  // 4x4 patch of one (tile, 4-channel quad) unit; here it serves quad q of BOTH 8-channel stages of a step)
-  uint32_t v_src[4], u_src[4];
+  // ---------------------------------------------------------------- loader state: thread = row r of the 4x4 patch of one
+  // (tile, 8-channel stage h, 4-channel quad q) unit; the four rows of a unit are the four lanes of a DPP quad
+  uint32_t v_src[4], u_src[2];
   int v_dst;
   float sgn;
   {
-    const int r = tid & 3, q = (tid >> 2) & 1, tl = tid >> 3;
+    const int r = tid & 3, q = (tid >> 2) & 1, h = (tid >> 3) & 1, tl = tid >> 4;
     const int T = tile0 + tl;
     const bool tv = T < p.total_tiles;
     const int TT = tv ? T : 0;
@@ -537,114 +570,105 @@ winograd_split_kernel(const WinoParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int xx = x0 + j;
-      v_src[j] = (yok && xx >= 0 && xx < p.W) ? (uint32_t)(((img * p.H + y) * p.W + xx) * p.Cin + q * 4) * 4u : INVALID_PIXEL;
+      v_src[j] = (yok && xx >= 0 && xx < p.W) ? (uint32_t)(((img * p.H + y) * p.W + xx) * p.Cin + h * KC + q * 4) * 4u : INVALID_PIXEL;
     }
-    v_dst = r * V_SLOT + tl * KC + 4 * (q ^ ((tl >> 3) & 1));
+    v_dst = h * STAGE_FLOATS + r * V_SLOT + tl * KC + 4 * (q ^ ((tl >> 3) & 1));
     sgn = (r == 1) ? 1.f : -1.f;
     const int fr_ = lane & 31, fh_ = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) u_src[j] = (uint32_t)((4 * j + wi) * SPLIT_POS_BYTES + fr_ * (SPLIT_KC * 2) + 16 * fh_);
+    for (int jj = 0; jj < 2; ++jj) u_src[jj] = (uint32_t)((4 * (2 * jh + jj) + wi) * SPLIT_POS_BYTES + fr_ * (SPLIT_KC * 2) + 16 * fh_);
   }
 
-  float4 ldv[2][4];
-  uintx4 bfr[4][2][3];              // [position j][cout half][piece]
+  float4 ldv[2][4];                 // the inputs of the next two steps (fetched two steps ahead: HBM latency under load)
+  uintx4 bfr[2][2][3];              // [position jj][cout half][piece]
   const int nsteps = p.Cin / SPLIT_KC;
   int f_step = 0;
-  auto fetch = [&]() {
-    // Unconditional (no branch in the step body).  Beyond the last step the LAST step is fetched again -- never consumed;
-    // the scalar offset of a raw buffer load is not range-checked, so it must not run past the tensor.
+  auto fetch = [&](float4 (&lv)[4]) {
+    // beyond the last step the LAST step is fetched again (never consumed): the scalar offset of a raw buffer load is not
+    // range-checked, so it must not run past the tensor
     const int choff = min(f_step, nsteps - 1) * (SPLIT_KC * 4);
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        ldv[h][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)v_src[j], choff + h * (KC * 4), 0));
+    for (int j = 0; j < 4; ++j) lv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)v_src[j], choff, 0));
     ++f_step;
   };
-  // c += sgn * quad_perm[2,2,1,1](c): the row mixing of the input transform.  Written with the DPP move builtin (two
-  // instructions per value where the fp32 kernel's inline asm has one fused v_fmac_f32_dpp): an asm block is a wall for the
-  // scheduler, and this kernel needs the transform interleaved with the matrix instructions.
-  auto qmix = [&](float v) -> float {
-    const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x5A /* quad_perm:[2,2,1,1] */, 0xf, 0xf, true);
-    return fmaf(sgn, __int_as_float(m), v);
-  };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, const float4 (&lv)[4]) {
+    float *Vd = lds + buf * 2 * STAGE_FLOATS + v_dst;
+    float4 c[4];
+    c[0] = f4sub(lv[0], lv[2]); c[1] = f4add(lv[1], lv[2]); c[2] = f4sub(lv[2], lv[1]); c[3] = f4sub(lv[1], lv[3]);
+#define IDIFF_QFMA(x) "v_fmac_f32_dpp " x ", " x ", %16 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    asm volatile("s_nop 1\n" IDIFF_QFMA("%0") IDIFF_QFMA("%1") IDIFF_QFMA("%2") IDIFF_QFMA("%3") IDIFF_QFMA("%4") IDIFF_QFMA("%5")
+                 IDIFF_QFMA("%6") IDIFF_QFMA("%7") IDIFF_QFMA("%8") IDIFF_QFMA("%9") IDIFF_QFMA("%10") IDIFF_QFMA("%11")
+                 IDIFF_QFMA("%12") IDIFF_QFMA("%13") IDIFF_QFMA("%14") IDIFF_QFMA("%15")
+                 : "+v"(c[0].x), "+v"(c[0].y), "+v"(c[0].z), "+v"(c[0].w), "+v"(c[1].x), "+v"(c[1].y), "+v"(c[1].z), "+v"(c[1].w),
+                   "+v"(c[2].x), "+v"(c[2].y), "+v"(c[2].z), "+v"(c[2].w), "+v"(c[3].x), "+v"(c[3].y), "+v"(c[3].z), "+v"(c[3].w)
+                 : "v"(sgn));
+#undef IDIFF_QFMA
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float *Vd = lds + (buf * 2 + h) * STAGE_FLOATS + v_dst;
-      float4 c[4];
-      c[0] = f4sub(ldv[h][0], ldv[h][2]); c[1] = f4add(ldv[h][1], ldv[h][2]); c[2] = f4sub(ldv[h][2], ldv[h][1]); c[3] = f4sub(ldv[h][1], ldv[h][3]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        c[j] = make_float4(qmix(c[j].x), qmix(c[j].y), qmix(c[j].z), qmix(c[j].w));
-        *reinterpret_cast<float4 *>(Vd + j * 4 * V_SLOT) = c[j];
-      }
-    }
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(Vd + j * 4 * V_SLOT) = c[j];
   };
 
-  floatx16 acc[8];
+  floatx16 acc[4];                  // [position jj][cout half]
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5, sw = (fr >> 3) & 1;
   // stage fh, row fr; first the half the fp32 kernel's lane would read (conflict-free), then the other one
-  const int a_first = fh * STAGE_FLOATS + wi * V_SLOT + fr * KC + 4 * (fh ^ sw);
-  const int a_second = fh * STAGE_FLOATS + wi * V_SLOT + fr * KC + 4 * (fh ^ sw ^ 1);
+  const int a_first = fh * STAGE_FLOATS + (4 * 2 * jh + wi) * V_SLOT + fr * KC + 4 * (fh ^ sw);
+  const int a_second = fh * STAGE_FLOATS + (4 * 2 * jh + wi) * V_SLOT + fr * KC + 4 * (fh ^ sw ^ 1);
 
-  auto load_b = [&](int j, int step) {
+  auto load_b = [&](int jj, int step) {
     const int slab = (step * p.tiles_n + tile_n) * SPLIT_SLAB_BYTES;
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
       for (int q = 0; q < 3; ++q)
-        bfr[j][hb][q] = __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[j] + q * (64 * SPLIT_KC * 2) + hb * (32 * SPLIT_KC * 2), slab, 0);
+        bfr[jj][hb][q] = __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[jj] + q * (64 * SPLIT_KC * 2) + hb * (32 * SPLIT_KC * 2), slab, 0);
   };
 
-#pragma unroll
-  for (int j = 0; j < 4; ++j) load_b(j, 0);
-  fetch();
-  stage(0);
-  fetch();
+  load_b(0, 0);
+  load_b(1, 0);
+  fetch(ldv[0]);
+  stage(0, ldv[0]);
+  fetch(ldv[0]);                    // step 1
+  fetch(ldv[1]);                    // step 2
   __syncthreads();
 
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // the six partial products, smallest first
-  for (int s = 0; s < nsteps; ++s) {
+  const bool early = jh == 0;
+  // step s: the V of step s + 1 is in ldv[s & 1] (requested two steps ago); `lv` is that set
+  auto step = [&](int s, float4 (&lv)[4]) {
     const int buf = s & 1;
     const float *S = lds + buf * 2 * STAGE_FLOATS;
-    float4 alo[4], ahi[4];
+    float4 alo[2], ahi[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      alo[j] = *reinterpret_cast<const float4 *>(S + a_first + 4 * j * V_SLOT);
-      ahi[j] = *reinterpret_cast<const float4 *>(S + a_second + 4 * j * V_SLOT);
+    for (int jj = 0; jj < 2; ++jj) {
+      alo[jj] = *reinterpret_cast<const float4 *>(S + a_first + 4 * jj * V_SLOT);
+      ahi[jj] = *reinterpret_cast<const float4 *>(S + a_second + 4 * jj * V_SLOT);
     }
-    // the next step's input: transform + LDS writes of the values fetched one step ago, then the fetch for the step after
-    stage(buf ^ 1);
-    fetch();
+    // waves w and w + 4 share a SIMD: one writes the other stage (vector work) while its partner's matrix instructions run
+    if (early) { stage(buf ^ 1, lv); fetch(lv); }
     const int snext = min(s + 1, nsteps - 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int jj = 0; jj < 2; ++jj) {
       bf16x8 a[3];
-      split8(alo[j], ahi[j], a[0], a[1], a[2]);
+      split8(alo[jj], ahi[jj], a[0], a[1], a[2]);
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
-          acc[2 * j + hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]], __builtin_bit_cast(bf16x8, bfr[j][hb][PB[t]]), acc[2 * j + hb], 0, 0, 0);
-      load_b(j, snext);
+          acc[2 * jj + hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]], __builtin_bit_cast(bf16x8, bfr[jj][hb][PB[t]]), acc[2 * jj + hb], 0, 0, 0);
+      load_b(jj, snext);
     }
-    // 48 MFMAs; ~5 vector instructions fit in the shadow of each
-#pragma unroll
-    for (int k = 0; k < 48; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-      if (k % 6 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // 8 LDS writes
-      if (k % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // 32 memory reads (24 of U, 8 of x)
-    }
+    if (!early) { stage(buf ^ 1, lv); fetch(lv); }
     __syncthreads();
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, ldv[0]);
+    if (s + 1 < nsteps) step(s + 1, ldv[1]);
   }
-  wino_tail(p, acc, lds, tile0, n0, tile_m, tid, lane, wave, wi, tb);
+  wino_tail<1>(p, acc, lds, tile0, n0, tile_m, tid, lane, wave, wi, 0);
 }
 
 // U = G g G^T (fp64, rounded once to fp32 exactly as idiff_winograd_pack_f32 does), then cut into the three bf16 pieces and
@@ -858,7 +882,7 @@ int conv2d_winograd_impl(const float *x, const float *u, float *out, int B, int 
     static AttrGuard sguard;
     const void *fn = reinterpret_cast<const void *>(winograd_split_kernel);
     if (int rc = set_dynamic_lds_once(sguard, &fn, 1, (int)SPLIT_LDS_BYTES, "conv2d_winograd_split")) return rc;
-    hipLaunchKernelGGL(winograd_split_kernel, dim3(nwg), dim3(THREADS), SPLIT_LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(winograd_split_kernel, dim3(nwg), dim3(SPLIT_THREADS), SPLIT_LDS_BYTES, (hipStream_t)stream, p);
     return launch_status("conv2d_winograd_split");
   }
   if (nwg >= PEEL_MIN_WORKGROUPS)

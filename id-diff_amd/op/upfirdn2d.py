@@ -78,6 +78,9 @@ def upfirdn2d_xy(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_
     if kernel.ndim != 2:
         raise RuntimeError(f"upfirdn2d: expected a 2-D FIR kernel, got {tuple(kernel.shape)}")
     kernel = _lib._dev(kernel.detach().to(device=input.device, dtype=torch.float32).contiguous(), "kernel")
+    if not (torch.is_grad_enabled() and input.requires_grad):
+        # nothing to differentiate: one native call, no autograd.Function around it (host time matters on small tensors)
+        return _launch(input.contiguous(), kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
     return UpFirDn2d.apply(input.contiguous(), kernel, (up_x, up_y), (down_x, down_y), (pad_x0, pad_x1, pad_y0, pad_y1))
 
 
