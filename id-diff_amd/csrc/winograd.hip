@@ -117,7 +117,7 @@ __device__ __forceinline__ void wino_tail(const WinoParams &p, const floatx16 *a
   // issued at its point of use cost 0.3 ms of a 3.1 ms launch).
   const idiff_epilogue &ep = p.ep;
   const bool has_ep = p.has_ep != 0;
-#ifdef IDIFF_WINO_STAMP
+#if defined(IDIFF_WINO_STAMP) || defined(IDIFF_SPLIT_PHASES)
   const bool want_stats = false;          // epilogue.colstats carries the stamp buffer in this build
 #else
   const bool want_stats = has_ep && ep.colstats != nullptr;
@@ -503,6 +503,12 @@ winograd_kernel(const WinoParams p) {
 //     waves x 4 positions, 128 accumulators + 96 registers of U) nothing covered a wait and the kernel ran at 0.8x of the
 //     fp32 one, its matrix pipe busy 24 % of the time.  One LDS stage of V: fragments go to registers, a barrier, then
 //     the stage is rewritten under this step's matrix instructions.
+//   * What bounds it (round 3, scripts/wino_split_phases.py + PMC): a 16-channel step moves 96 KB of U and 32 KB of x from
+//     L2 into the CU, 128 KB in ~3.9k cycles = 33 B/clk/CU = 13.6 TB/s chip-wide -- the rate the vector-memory path of a
+//     CU sustains from L2 (MI355X_MICROARCH.md, 'Indexed rows': 66-73 GB/s per CU), against 1536 cycles of matrix work per
+//     SIMD.  Re-ordering the step (M1 held back across the barrier, roles in separate loops) only moved the waiting from
+//     one phase to another.  Fewer bytes per product need 64 tiles per workgroup (U read once for twice the tiles), i.e.
+//     128 accumulators per wave next to ~130 other registers at two waves per SIMD: does not fit.  Hence opt-in, not default.
 constexpr int SPLIT_KC = 16;
 constexpr size_t SPLIT_LDS_BYTES = sizeof(float) * (size_t)(4 * STAGE_FLOATS > TAIL_FLOATS ? 4 * STAGE_FLOATS : TAIL_FLOATS);   // 133 KB: two stages of 2 x 8 channels
 constexpr int SPLIT_POS_BYTES = 3 * 64 * SPLIT_KC * 2;          // one position of one slab: 3 pieces x [64 cout][16 cin] bf16
@@ -637,6 +643,14 @@ winograd_split_kernel(const WinoParams p) {
 
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // the six partial products, smallest first
   const bool early = jh == 0;
+#ifdef IDIFF_SPLIT_PHASES   // diagnostic build only (scripts/wino_split_phases.py): shader-clock ticks per phase of a step
+  uint32_t ph[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t ph_last = __builtin_amdgcn_s_memtime();
+  const uint64_t ph_first = ph_last;
+#define IDIFF_PH(k) { __builtin_amdgcn_sched_barrier(0); const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[k] += (uint32_t)(t_ - ph_last); ph_last = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define IDIFF_PH(k)
+#endif
   // step s: the V of step s + 1 is in ldv[s & 1] (requested two steps ago); `lv` is that set
   auto step = [&](int s, float4 (&lv)[4]) {
     const int buf = s & 1;
@@ -649,6 +663,7 @@ winograd_split_kernel(const WinoParams p) {
     }
     // waves w and w + 4 share a SIMD: one writes the other stage (vector work) while its partner's matrix instructions run
     if (early) { stage(buf ^ 1, lv); fetch(lv); }
+    IDIFF_PH(0)
     const int snext = min(s + 1, nsteps - 1);
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
@@ -660,16 +675,33 @@ winograd_split_kernel(const WinoParams p) {
         for (int hb = 0; hb < 2; ++hb)
           acc[2 * jj + hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]], __builtin_bit_cast(bf16x8, bfr[jj][hb][PB[t]]), acc[2 * jj + hb], 0, 0, 0);
       load_b(jj, snext);
+      IDIFF_PH(1 + jj)
     }
     if (!early) { stage(buf ^ 1, lv); fetch(lv); }
+    IDIFF_PH(3)
     __syncthreads();
+    IDIFF_PH(4)
   };
   for (int s = 0; s < nsteps; s += 2) {
     step(s, ldv[0]);
     if (s + 1 < nsteps) step(s + 1, ldv[1]);
   }
+#ifdef IDIFF_SPLIT_PHASES
+  const uint64_t ph_loop = __builtin_amdgcn_s_memtime();
+#endif
   wino_tail<1>(p, acc, lds, tile0, n0, tile_m, tid, lane, wave, wi, 0);
+#ifdef IDIFF_SPLIT_PHASES
+  if (p.has_ep && p.ep.colstats && lane == 0) {
+    // a buffer nothing else reads: [workgroup][wave][8]
+    uint32_t *st = reinterpret_cast<uint32_t *>(p.ep.colstats) + ((int64_t)blockIdx.x * 8 + wave) * 8;
+    for (int k = 0; k < 5; ++k) st[k] = ph[k];
+    st[5] = (uint32_t)(ph_loop - ph_first);
+    st[6] = (uint32_t)(__builtin_amdgcn_s_memtime() - ph_loop);
+    st[7] = (uint32_t)nsteps;
+  }
+#endif
 }
+#undef IDIFF_PH
 
 // U = G g G^T (fp64, rounded once to fp32 exactly as idiff_winograd_pack_f32 does), then cut into the three bf16 pieces and
 // laid out for winograd_split_kernel: [Cin / 16][Cout / 64][16 positions][3 pieces][64 cout][16 cin], where the 16 channels
