@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const doub
                                                          int off /* lo & 63, or -1: both triangles of A' are valid */) {
   __shared__ double Vs[KSPLIT_COLS][BW];
   const int rb = blockIdx.x, ks = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fl = lane & 15, fk = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fl = lane & 15, fk = lane >> 4;
   const int k_lo = ks * krange, k_hi = min(g.m, k_lo + krange);
   const int row0 = rb * YROWS + wave * 32 + fl, row1 = row0 + 16;           // local rows of A'
   const int r0c = min(row0, g.m - 1), r1c = min(row1, g.m - 1);
@@ -429,22 +429,34 @@ __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const doub
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (doublex4){0.0, 0.0, 0.0, 0.0};
-  for (int c0 = k_lo; c0 < k_hi; c0 += KSPLIT_COLS) {
-    const int c1 = min(k_hi, c0 + KSPLIT_COLS);
-    __syncthreads();
-    for (int e = tid; e < KSPLIT_COLS * BW; e += 256) {
-      const int kl = e / BW, k = c0 + kl;
-      // rows 4 apart would sit on the same banks (1 KB stride): rotate every other group of four rows by 16 columns
-      Vs[kl][(e % BW + 16 * ((kl >> 2) & 1)) & 31] = k < c1 ? V[(int64_t)k * BW + e % BW] : 0.0;
-    }
-    __syncthreads();
-    for (int c = c0; c < c1; c += 32) {
-      double a0[2][4], a1[2][4];
+  // The 32-column chunks of the slice are software-pipelined: chunk i + 1 is requested before the MFMAs of chunk i (the
+  // plain load -> use loop left every wave waiting out a full memory latency per chunk at two waves per SIMD: 146 us per
+  // panel at D = 12288, 1.4 TB/s of the triangle's bytes).
+  typedef double double4u __attribute__((ext_vector_type(4), aligned(8)));     // 32 bytes of a row, 8-byte aligned
+  auto load_chunk = [&](int c, double (&a0)[2][4], double (&a1)[2][4]) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int kb = c + 16 * h + 4 * fk;
-        const int tc = (c + 16 * h + off) >> 6;          // tile column of this group of sixteen columns (uniform)
-        const bool up0 = tc > t0, up1 = tc > t1;
+    for (int h = 0; h < 2; ++h) {
+      const int kb = c + 16 * h + 4 * fk;
+      const int tc = (c + 16 * h + off) >> 6;          // tile column of this group of sixteen columns (wave-uniform)
+      const bool up0 = tc > t0, up1 = tc > t1;
+      if (c + 32 <= g.m) {                             // every chunk but the last: no clamping, whole-row-piece loads
+        if (up0) {
+          const double *q = Ap + (int64_t)kb * g.D + r0c;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a0[h][u] = q[(int64_t)u * g.D];
+        } else {
+          const double4u v = *reinterpret_cast<const double4u *>(ar0 + kb);
+          a0[h][0] = v.x; a0[h][1] = v.y; a0[h][2] = v.z; a0[h][3] = v.w;
+        }
+        if (up1) {
+          const double *q = Ap + (int64_t)kb * g.D + r1c;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a1[h][u] = q[(int64_t)u * g.D];
+        } else {
+          const double4u v = *reinterpret_cast<const double4u *>(ar1 + kb);
+          a1[h][0] = v.x; a1[h][1] = v.y; a1[h][2] = v.z; a1[h][3] = v.w;
+        }
+      } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int k = min(kb + u, g.m - 1);        // columns beyond the slice meet zero rows of Vs
@@ -452,19 +464,40 @@ __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const doub
           a1[h][u] = up1 ? Ap[(int64_t)k * g.D + r1c] : ar1[k];
         }
       }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int kl = c - c0 + 16 * h + 4 * fk + u;
-          const int rot = 16 * ((kl >> 2) & 1);
-          const double b0 = Vs[kl][(fl + rot) & 31], b1 = Vs[kl][(16 + fl + rot) & 31];
-          acc[0][0] = mfma(a0[h][u], b0, acc[0][0]);
-          acc[0][1] = mfma(a0[h][u], b1, acc[0][1]);
-          acc[1][0] = mfma(a1[h][u], b0, acc[1][0]);
-          acc[1][1] = mfma(a1[h][u], b1, acc[1][1]);
-        }
     }
+  };
+  const int nch = (k_hi - k_lo + 31) >> 5;
+  double A0[2][2][4], A1[2][2][4];
+  auto body = [&](int i, double (&a0)[2][4], double (&a1)[2][4], double (&n0)[2][4], double (&n1)[2][4]) {
+    const int c = k_lo + 32 * i, inblk = (32 * i) & (KSPLIT_COLS - 1);
+    if (inblk == 0) {                                  // uniform over the workgroup: the next KSPLIT_COLS rows of V
+      const int c1 = min(k_hi, c + KSPLIT_COLS);
+      __syncthreads();
+      for (int e = tid; e < KSPLIT_COLS * BW; e += 256) {
+        const int kl = e / BW, k = c + kl;
+        // rows 4 apart would sit on the same banks (1 KB stride): rotate every other group of four rows by 16 columns
+        Vs[kl][(e % BW + 16 * ((kl >> 2) & 1)) & 31] = k < c1 ? V[(int64_t)k * BW + e % BW] : 0.0;
+      }
+      __syncthreads();
+    }
+    if (i + 1 < nch) load_chunk(c + 32, n0, n1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kl = inblk + 16 * h + 4 * fk + u;
+        const int rot = 16 * ((kl >> 2) & 1);
+        const double b0 = Vs[kl][(fl + rot) & 31], b1 = Vs[kl][(16 + fl + rot) & 31];
+        acc[0][0] = mfma(a0[h][u], b0, acc[0][0]);
+        acc[0][1] = mfma(a0[h][u], b1, acc[0][1]);
+        acc[1][0] = mfma(a1[h][u], b0, acc[1][0]);
+        acc[1][1] = mfma(a1[h][u], b1, acc[1][1]);
+      }
+  };
+  if (nch > 0) load_chunk(k_lo, A0[0], A1[0]);
+  for (int i = 0; i < nch; i += 2) {
+    body(i, A0[0], A1[0], A0[1], A1[1]);
+    if (i + 1 < nch) body(i + 1, A0[1], A1[1], A0[0], A1[0]);
   }
   double *yp = Ypart + ((int64_t)ks * g.m) * BW;
 #pragma unroll
@@ -662,16 +695,25 @@ __global__ void __launch_bounds__(256) trailing_update_kernel(PanelGeom g, const
 //
 // k11s: A' -= V Z^T + Z V^T on the tiles of the absolute 64-grid at or below the diagonal (wave = 32 x 32 = 2 x 2 MFMA
 // tiles, K = 2 BW).  Diagonal tiles write their lower half and its mirror, so they stay valid in both halves.
+// part 0: the whole block.  Look-ahead (sbr_to_band): part 1 = only the first 32 columns of A' (the next panel and the band
+// block above it; launched over tile column 0, one workgroup per tile row), part 2 = everything else -- the two parts
+// write disjoint elements (a wave owns 32 columns, and wj == 0 names exactly the waves of columns [0, 32)).
 __global__ void __launch_bounds__(256) trailing_update_lower_kernel(PanelGeom g, int off, const double *__restrict__ V,
-                                                                    const double *__restrict__ Z) {
+                                                                    const double *__restrict__ Z, int part) {
   // triangular launch: block b -> (ti, tj), tj <= ti
   const int b = blockIdx.x;
-  int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-  while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-  while (ti * (ti + 1) / 2 > b) --ti;
-  const int tj = b - ti * (ti + 1) / 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fl = lane & 15, fk = lane >> 4;
+  int ti, tj;
+  if (part == 1) {
+    ti = b; tj = 0;
+  } else {
+    ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    tj = b - ti * (ti + 1) / 2;
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fl = lane & 15, fk = lane >> 4;
   const int wi = ti * 64 + (wave >> 1) * 32 - off, wj = tj * 64 + (wave & 1) * 32 - off;      // local indices (may start at -32)
+  if ((part == 1 && wj != 0) || (part == 2 && wj == 0)) return;      // wave-uniform; no barrier in this kernel
   doublex4 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -1250,12 +1292,44 @@ __global__ void __launch_bounds__(256) fro2_kernel(const double *__restrict__ A,
 
 namespace idiff {
 
+// Helper stream and the two events of the band reduction's look-ahead: one set per host thread and device, made on first
+// use with the priority of the stream that asked, kept for the life of the thread.
+constexpr int LOOKAHEAD_MIN_M = 4096;
+struct Lookahead {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+static Lookahead *lookahead_for(hipStream_t st) {
+  thread_local Lookahead cache[64];
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  Lookahead &l = cache[dev & 63];
+  if (!l.side) {
+    int prio = 0;
+    if (hipStreamGetPriority(st, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
+    hipStream_t s2 = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio) != hipSuccess ||
+        hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      if (a) (void)hipEventDestroy(a);
+      if (s2) (void)hipStreamDestroy(s2);
+      return nullptr;                                   // no helper stream: the serial form is always available
+    }
+    l.side = s2; l.fork = a; l.join = b;
+  }
+  return &l;
+}
+
 int64_t sbr_scratch_doubles(int D) {
   const int64_t m = D;
   const int64_t nchunk = (m + CHUNK - 1) / CHUNK, nks = (m + KSPLIT_COLS - 1) / KSPLIT_COLS;
   return (int64_t)(D + PAD) * LDB             // band, zero-padded
          + (int64_t)D * (BW + 1)              // carried reflectors of stage 2
-         + 4 * m * BW                         // Q, V, Y, Z
+         + 5 * m * BW                         // Q, V (two: look-ahead), Y, Z
          + nks * m * BW                       // Ypart
          + 4 * nchunk * BW * BW               // Gram partials (G / G2 share, VtV, VtP, K)
          + 8 * BW * BW + BW + 16;             // R1, R2, U, Vtop, Tinv, C, W2, spare | sgn | scalars
@@ -1267,7 +1341,8 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
   double *AB = scratch;
   double *vs = AB + (int64_t)(D + PAD) * LDB;
   double *Q = vs + (int64_t)D * (BW + 1);
-  double *V = Q + (int64_t)D * BW, *Y = V + (int64_t)D * BW, *Z = Y + (int64_t)D * BW;
+  double *Vbuf[2] = {Q + (int64_t)D * BW, Q + 2 * (int64_t)D * BW};
+  double *Y = Vbuf[1] + (int64_t)D * BW, *Z = Y + (int64_t)D * BW;
   const int64_t nchunk_max = (D + CHUNK - 1) / CHUNK, nks_max = (D + KSPLIT_COLS - 1) / KSPLIT_COLS;
   double *Ypart = Z + (int64_t)D * BW;
   double *Gp = Ypart + nks_max * D * BW;
@@ -1293,15 +1368,25 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
   after("fro2", 0);
   // IDIFF_SBR_FULL (A/B): the round-2 form that keeps both triangles of the trailing block up to date
   const bool full = option(OPT_SBR_FULL);
-  int j0 = 0;
+  // Look-ahead: the six panel kernels of panel j + 1 need only the first 32 columns of the updated block.  Those are
+  // updated first (part 1, m x 32), then the rest of the update (part 2: the launch that moves the bytes) runs on a helper
+  // stream BESIDE the latency-bound panel chain and joins before Y = A' V needs the whole block.  Only for blocks large
+  // enough that the update outlasts the cross-stream hand-off.
+  Lookahead *la = (full || dbg || option(OPT_SBR_SERIAL) || D - BW < LOOKAHEAD_MIN_M) ? nullptr : lookahead_for(st);
+  bool join_pending = false;
+  int j0 = 0, panel = 0;
   while (D - j0 > CORNER) {
+    double *V = Vbuf[panel & 1];
+    ++panel;
     PanelGeom g;
     g.A = G; g.D = D; g.j0 = j0; g.lo = j0 + BW; g.m = D - g.lo;
     g.chunk_rows = CHUNK;
     g.nchunk = ceil_div(g.m, g.chunk_rows);
-    // column range per workgroup of the Y kernel: >= 512 workgroups when the block is large enough, few partials otherwise
+    // column range per workgroup of the Y kernel: as many workgroups as fit the chip AT ONCE (two per CU: 64 KB of LDS
+    // each), never a few more -- the kernel is bound by the fp64 matrix pipe, and 576 equal workgroups on 512 places
+    // took two rounds (435 us at m = 12256 against 250 us at m = 11040)
     const int rbs = ceil_div(g.m, YROWS);
-    int nks = min(ceil_div(g.m, KSPLIT_COLS), max(1, ceil_div(512, rbs)));
+    int nks = min(ceil_div(g.m, KSPLIT_COLS), max(1, 512 / rbs));
     const int krange = ceil_div(ceil_div(g.m, nks), KSPLIT_COLS) * KSPLIT_COLS;
     nks = ceil_div(g.m, krange);
     hipLaunchKernelGGL(panel_gram_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp);
@@ -1317,6 +1402,10 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     hipLaunchKernelGGL(panel_t_kernel, dim3(1), dim3(256), 0, st, g, VtVp, VtPp, Vtop, Tinv, C);
     after("panel_t_kernel", j0);
     const int off = g.lo & 63;                           // the trailing block starts `off` into its first tile of the absolute grid
+    if (join_pending) {                                  // the rest of the previous update
+      if (hipError_t e2 = hipStreamWaitEvent(st, la->join, 0); e2 != hipSuccess) { set_error("sbr: hipStreamWaitEvent: %s", hipGetErrorString(e2)); return (int)e2; }
+      join_pending = false;
+    }
     hipLaunchKernelGGL(trailing_y_kernel, dim3(rbs, nks), dim3(256), 0, st, g, V, Ypart, krange, full ? -1 : off);
     after("trailing_y_kernel", j0);
     hipLaunchKernelGGL(trailing_yk_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Ypart, nks, V, Y, Kp);
@@ -1330,10 +1419,24 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
       hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, g, V, Z);
     } else {
       const int nt = ceil_div(g.m + off, 64);
-      hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, g, off, V, Z);
+      if (la && g.m >= LOOKAHEAD_MIN_M) {
+        hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(nt), dim3(256), 0, st, g, off, V, Z, 1);
+        hipError_t e2 = hipEventRecord(la->fork, st);
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(la->side, la->fork, 0);
+        if (e2 != hipSuccess) { set_error("sbr: look-ahead fork: %s", hipGetErrorString(e2)); return (int)e2; }
+        hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, la->side, g, off, V, Z, 2);
+        e2 = hipEventRecord(la->join, la->side);
+        if (e2 != hipSuccess) { set_error("sbr: look-ahead join: %s", hipGetErrorString(e2)); return (int)e2; }
+        join_pending = true;
+      } else {
+        hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, g, off, V, Z, 0);
+      }
     }
     after("trailing_update_kernel", j0);
     j0 += BW;
+  }
+  if (join_pending) {
+    if (hipError_t e2 = hipStreamWaitEvent(st, la->join, 0); e2 != hipSuccess) { set_error("sbr: hipStreamWaitEvent: %s", hipGetErrorString(e2)); return (int)e2; }
   }
   {
     const int n = D - j0;

@@ -41,7 +41,8 @@ const char *idiff_source_stamp(void);
  * (CU count used when sizing the systolic chase; tests), IDIFF_SBR_SYNC (band reduction waits for and names every launch on
  * stderr: a fault then names its kernel), IDIFF_SBR_FULL (band reduction keeps both triangles up to date, the round-2 form),
  * IDIFF_NO_SPLIT (contractions of idiff_gemm_f32 / idiff_conv2d_nhwc_f32 on the fp32 matrix cores instead of the
- * split-precision products described there), IDIFF_WINO_SPLIT (opt-in: the split-precision Winograd kernel).
+ * split-precision products described there), IDIFF_WINO_SPLIT (opt-in: the split-precision Winograd kernel),
+ * IDIFF_SBR_SERIAL (band reduction without the look-ahead: every launch of a panel on the caller's stream).
  * Returns the previous value, -1 for an unknown name.  No reference counterpart. */
 int idiff_set_option(const char *name, int value);
 
