@@ -422,8 +422,7 @@ __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const doub
   // Only the tiles of the absolute 64-grid at or below the diagonal are kept up to date (k11s).  A 16 x 16 block whose
   // column tile lies to the right of its row tile is read as the transpose of its mirror image: lane (fl, fk) then takes
   // A'[column][row fl] -- for a fixed column the sixteen lanes of a row group read 128 contiguous bytes.
-  const int t0 = off < 0 ? 0x7fffffff : (rb * YROWS + wave * 32 + off) >> 6;          // tile rows of the wave's two row groups
-  const int t1 = off < 0 ? 0x7fffffff : (rb * YROWS + wave * 32 + 16 + off) >> 6;
+  const int t0 = off < 0 ? 0x3fffffff : (rb * YROWS + wave * 32 + off) >> 6;          // the tile row of the wave's 32 rows
   doublex4 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -431,56 +430,56 @@ __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const doub
     for (int b = 0; b < 2; ++b) acc[a][b] = (doublex4){0.0, 0.0, 0.0, 0.0};
   // The 32-column chunks of the slice are software-pipelined: chunk i + 1 is requested before the MFMAs of chunk i (the
   // plain load -> use loop left every wave waiting out a full memory latency per chunk at two waves per SIMD: 146 us per
-  // panel at D = 12288, 1.4 TB/s of the triangle's bytes).
+  // panel at D = 12288).  The compiler's wait counts are static, so the loop is written for them: the prefetch is
+  // unconditional (the last chunk of a range re-requests itself) and there is no branch between a request and its use -- a
+  // conditional prefetch, or per-chunk mode tests, merge into `s_waitcnt vmcnt(0)` in front of the MFMAs, which waits for
+  // the chunk just requested.  A wave's 32 rows lie in ONE tile row (32-row blocks, 64-row tiles), so its chunks split
+  // into a run read directly (tile column <= tile row) and a run read as mirrored transposes: one loop each.
   typedef double double4u __attribute__((ext_vector_type(4), aligned(8)));     // 32 bytes of a row, 8-byte aligned
-  auto load_chunk = [&](int c, double (&a0)[2][4], double (&a1)[2][4]) {
+  auto load_direct = [&](int c, double (&a0)[2][4], double (&a1)[2][4]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int kb = c + 16 * h + 4 * fk;
-      const int tc = (c + 16 * h + off) >> 6;          // tile column of this group of sixteen columns (wave-uniform)
-      const bool up0 = tc > t0, up1 = tc > t1;
-      if (c + 32 <= g.m) {                             // every chunk but the last: no clamping, whole-row-piece loads
-        if (up0) {
-          const double *q = Ap + (int64_t)kb * g.D + r0c;
+      const double4u v = *reinterpret_cast<const double4u *>(ar0 + kb), w = *reinterpret_cast<const double4u *>(ar1 + kb);
+      a0[h][0] = v.x; a0[h][1] = v.y; a0[h][2] = v.z; a0[h][3] = v.w;
+      a1[h][0] = w.x; a1[h][1] = w.y; a1[h][2] = w.z; a1[h][3] = w.w;
+    }
+  };
+  auto load_mirror = [&](int c, double (&a0)[2][4], double (&a1)[2][4]) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) a0[h][u] = q[(int64_t)u * g.D];
-        } else {
-          const double4u v = *reinterpret_cast<const double4u *>(ar0 + kb);
-          a0[h][0] = v.x; a0[h][1] = v.y; a0[h][2] = v.z; a0[h][3] = v.w;
-        }
-        if (up1) {
-          const double *q = Ap + (int64_t)kb * g.D + r1c;
+    for (int h = 0; h < 2; ++h) {
+      const double *q = Ap + (int64_t)(c + 16 * h + 4 * fk) * g.D;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) a1[h][u] = q[(int64_t)u * g.D];
-        } else {
-          const double4u v = *reinterpret_cast<const double4u *>(ar1 + kb);
-          a1[h][0] = v.x; a1[h][1] = v.y; a1[h][2] = v.z; a1[h][3] = v.w;
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = min(kb + u, g.m - 1);        // columns beyond the slice meet zero rows of Vs
-          a0[h][u] = up0 ? Ap[(int64_t)k * g.D + r0c] : ar0[k];
-          a1[h][u] = up1 ? Ap[(int64_t)k * g.D + r1c] : ar1[k];
-        }
+      for (int u = 0; u < 4; ++u) {
+        a0[h][u] = q[(int64_t)u * g.D + r0c];
+        a1[h][u] = q[(int64_t)u * g.D + r1c];
       }
     }
   };
-  const int nch = (k_hi - k_lo + 31) >> 5;
-  double A0[2][2][4], A1[2][2][4];
-  auto body = [&](int i, double (&a0)[2][4], double (&a1)[2][4], double (&n0)[2][4], double (&n1)[2][4]) {
-    const int c = k_lo + 32 * i, inblk = (32 * i) & (KSPLIT_COLS - 1);
-    if (inblk == 0) {                                  // uniform over the workgroup: the next KSPLIT_COLS rows of V
-      const int c1 = min(k_hi, c + KSPLIT_COLS);
-      __syncthreads();
-      for (int e = tid; e < KSPLIT_COLS * BW; e += 256) {
-        const int kl = e / BW, k = c + kl;
-        // rows 4 apart would sit on the same banks (1 KB stride): rotate every other group of four rows by 16 columns
-        Vs[kl][(e % BW + 16 * ((kl >> 2) & 1)) & 31] = k < c1 ? V[(int64_t)k * BW + e % BW] : 0.0;
+  auto load_clamped = [&](int c, double (&a0)[2][4], double (&a1)[2][4]) {     // the one partial chunk at the end of A'
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kb = c + 16 * h + 4 * fk;
+      const bool up = ((c + 16 * h + off) >> 6) > t0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = min(kb + u, g.m - 1);          // columns beyond the slice meet zero rows of Vs
+        a0[h][u] = up ? Ap[(int64_t)k * g.D + r0c] : ar0[k];
+        a1[h][u] = up ? Ap[(int64_t)k * g.D + r1c] : ar1[k];
       }
-      __syncthreads();
     }
-    if (i + 1 < nch) load_chunk(c + 32, n0, n1);
+  };
+  auto fill = [&](int c) {                             // uniform over the workgroup: the next KSPLIT_COLS rows of V
+    const int c1 = min(k_hi, c + KSPLIT_COLS);
+    __syncthreads();
+    for (int e = tid; e < KSPLIT_COLS * BW; e += 256) {
+      const int kl = e / BW, k = c + kl;
+      // rows 4 apart would sit on the same banks (1 KB stride): rotate every other group of four rows by 16 columns
+      Vs[kl][(e % BW + 16 * ((kl >> 2) & 1)) & 31] = k < c1 ? V[(int64_t)k * BW + e % BW] : 0.0;
+    }
+    __syncthreads();
+  };
+  auto mma = [&](int inblk, const double (&a0)[2][4], const double (&a1)[2][4]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -494,10 +493,36 @@ __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const doub
         acc[1][1] = mfma(a1[h][u], b1, acc[1][1]);
       }
   };
-  if (nch > 0) load_chunk(k_lo, A0[0], A1[0]);
-  for (int i = 0; i < nch; i += 2) {
-    body(i, A0[0], A1[0], A0[1], A1[1]);
-    if (i + 1 < nch) body(i + 1, A0[1], A1[1], A0[0], A1[0]);
+  double A0[2][2][4], A1[2][2][4];
+  // chunks cb, cb + 32, ... < ce, every one of them whole; every wave of the workgroup passes the same chunks in the same
+  // order (only the loader differs), so the barriers of fill() meet
+  auto run = [&](auto loader, int cb, int ce) {
+    if (cb >= ce) return;
+    loader(cb, A0[0], A1[0]);
+    for (int c = cb; c < ce; c += 64) {
+      {
+        const int inblk = (c - k_lo) & (KSPLIT_COLS - 1);
+        if (inblk == 0) fill(c);
+        loader(min(c + 32, ce - 32), A0[1], A1[1]);
+        mma(inblk, A0[0], A1[0]);
+      }
+      if (c + 32 < ce) {
+        const int inblk = (c + 32 - k_lo) & (KSPLIT_COLS - 1);
+        if (inblk == 0) fill(c + 32);
+        loader(min(c + 64, ce - 32), A0[0], A1[0]);
+        mma(inblk, A0[1], A1[1]);
+      }
+    }
+  };
+  const int k_full = k_lo + ((k_hi - k_lo) & ~31);                       // k_hi <= g.m: chunks below k_full are whole
+  const int cm = off < 0 ? k_full : min(max(64 * (t0 + 1) - off, k_lo), k_full);     // first mirrored column of this wave
+  run(load_direct, k_lo, cm);
+  run(load_mirror, cm, k_full);
+  if (k_full < k_hi) {
+    const int inblk = (k_full - k_lo) & (KSPLIT_COLS - 1);
+    if (inblk == 0) fill(k_full);
+    load_clamped(k_full, A0[0], A1[0]);
+    mma(inblk, A0[0], A1[0]);
   }
   double *yp = Ypart + ((int64_t)ks * g.m) * BW;
 #pragma unroll
@@ -698,13 +723,21 @@ __global__ void __launch_bounds__(256) trailing_update_kernel(PanelGeom g, const
 // part 0: the whole block.  Look-ahead (sbr_to_band): part 1 = only the first 32 columns of A' (the next panel and the band
 // block above it; launched over tile column 0, one workgroup per tile row), part 2 = everything else -- the two parts
 // write disjoint elements (a wave owns 32 columns, and wj == 0 names exactly the waves of columns [0, 32)).
+// sel 0: every tile (triangular launch); sel 1: tile column 0 (nt workgroups; with part 1); sel 2: only the tiles the
+// pipelined kernel below leaves out -- the diagonal, tile column 0 when the block starts inside a tile, the last tile row
+// when it ends inside one (3 nt workgroups, duplicates exit).
 __global__ void __launch_bounds__(256) trailing_update_lower_kernel(PanelGeom g, int off, const double *__restrict__ V,
-                                                                    const double *__restrict__ Z, int part) {
+                                                                    const double *__restrict__ Z, int part, int sel, int nt) {
   // triangular launch: block b -> (ti, tj), tj <= ti
   const int b = blockIdx.x;
   int ti, tj;
-  if (part == 1) {
+  if (sel == 1) {
     ti = b; tj = 0;
+  } else if (sel == 2) {
+    const bool ragged = ((g.m + off) & 63) != 0;
+    if (b < nt) { ti = b; tj = b; }
+    else if (b < 2 * nt) { ti = b - nt; tj = 0; if (off == 0 || ti == 0 || (ragged && ti == nt - 1)) return; }
+    else { ti = nt - 1; tj = b - 2 * nt; if (!ragged || tj == ti) return; }
   } else {
     ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
@@ -771,6 +804,136 @@ __global__ void __launch_bounds__(256) trailing_update_lower_kernel(PanelGeom g,
           }
         }
       }
+}
+
+// k11p: the same update for large blocks, software-pipelined.  trailing_update_lower_kernel is load -> 64 MFMAs -> store per
+// wave with three waves per SIMD, and the three phases of co-resident workgroups drift into step: 54 ms of a D = 12288
+// band reduction against 26 ms for the same kernel with its MFMAs removed (5.9 TB/s) and a 16 ms fp64-MFMA floor.  Here a
+// workgroup walks a STRIP of up to `strip` consecutive tiles of one tile row: the row operands (Z_i, V_i) stay in
+// registers, the column operands (V_j, Z_j: 32 KB per tile) pass through a double-buffered LDS stage, and the next
+// tile's 32 KB of A' and its column operands are requested before the MFMAs of the current tile.  Only tiles that lie
+// wholly inside the block and strictly below the diagonal come here (no predicates, no mirror writes): tile rows
+// ti_lo .. , tile columns tj_lo .. ti - 1; trailing_update_lower_kernel (sel 2) takes the rest.
+// Grid (strips per row, rows): block (s, y) takes tiles tj = tj_lo + s strip ... of row ti = ti_lo + y.
+constexpr int UPITCH = BW + 2;          // LDS pitch of an operand row (doubles): 272 bytes, 16 rows cover all 64 banks
+__global__ void __launch_bounds__(256, 2) trailing_update_strip_kernel(PanelGeom g, int off, const double *__restrict__ V,
+                                                                       const double *__restrict__ Z, int part, int strip,
+                                                                       int ti_lo, int tj_lo) {
+  __shared__ __attribute__((aligned(16))) double Bs[2][2][64][UPITCH];      // [stage][V | Z][column of the tile][k]
+  const int ti = ti_lo + blockIdx.y, tj0 = tj_lo + blockIdx.x * strip;
+  if (tj0 > ti - 1) return;
+  const int tj1 = min(ti - 1, tj0 + strip - 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fl = lane & 15, fk = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int wi = ti * 64 + wr * 32 - off;                                 // local row of this wave's 32 x 32 block
+  double *Ap = g.A + (int64_t)g.lo * g.D + g.lo;
+  typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
+
+  // row operands: av[pass][kc / 16][q][u] = (pass == 0 ? Z : V)[row wi + 16 q + fl][kc + 4 fk + u]
+  double av[2][2][2][4];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const double *Ai = pass == 0 ? Z : V;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const double *row = Ai + (int64_t)(wi + q * 16 + fl) * BW + 4 * fk;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[pass][kc][q][u] = row[kc * 16 + u];
+    }
+  }
+  // staging role: thread -> (matrix, column of the tile, half of the 32 k)
+  const int s_mat = tid >> 7, s_col = (tid >> 1) & 63, s_half = tid & 1;
+  const double *s_src = (s_mat == 0 ? V : Z) + (int64_t)(s_col - off) * BW + s_half * 16;
+  double2u opr[8];
+  auto fetch_operands = [&](int tj) {
+    const double2u *src = reinterpret_cast<const double2u *>(s_src + (int64_t)tj * 64 * BW);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) opr[e] = src[e];
+  };
+  auto stage_operands = [&](int st) {
+    double2u *dst = reinterpret_cast<double2u *>(&Bs[st][s_mat][s_col][s_half * 16]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = opr[e];
+  };
+  // element (a, c, r) of the wave's block = block origin (uniform) + lane offset (one register) + a uniform offset
+  const int lane_off = fk * g.D + fl;
+  auto fetch_cold = [&](int tj, double (&cold)[2][2][4]) {
+    const int wj = tj * 64 + wc * 32 - off;
+    if (part == 2 && wj == 0) return;
+    const double *blk = Ap + ((int64_t)wi * g.D + wj);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cold[a][c][r] = blk[((int64_t)(a * 16 + 4 * r) * g.D + c * 16) + lane_off];
+  };
+  auto tile = [&](int tj, int st, const double (&cold)[2][2][4], int next_st) {
+    const int wj = tj * 64 + wc * 32 - off;
+    if (part == 2 && wj == 0) {                        // wave-uniform; the barriers are outside
+      if (next_st >= 0) stage_operands(next_st);
+      return;
+    }
+    doublex4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[a][c] = (doublex4){0.0, 0.0, 0.0, 0.0};
+    // acc += Z_i V_j^T + V_i Z_j^T, in this order for every tile (as trailing_update_lower_kernel: bit-identical results)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        double bv[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const double2u *b = reinterpret_cast<const double2u *>(&Bs[st][pass][wc * 32 + c * 16 + fl][kc * 16 + 4 * fk]);
+          const double2u lo = b[0], hi = b[1];
+          bv[c][0] = lo.x; bv[c][1] = lo.y; bv[c][2] = hi.x; bv[c][3] = hi.y;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[a][c] = mfma(av[pass][kc][a][u], bv[c][u], acc[a][c]);
+      }
+    // the next tile's column operands go to LDS BEFORE this tile's stores are issued: the wait for those loads would
+    // otherwise also wait for the stores (one counter for both)
+    if (next_st >= 0) stage_operands(next_st);
+    double *blk = Ap + ((int64_t)wi * g.D + wj);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          blk[((int64_t)(a * 16 + 4 * r) * g.D + c * 16) + lane_off] = cold[a][c][r] - acc[a][c][r];
+  };
+
+  double coldA[2][2][4], coldB[2][2][4];
+  fetch_operands(tj0);
+  fetch_cold(tj0, coldA);
+  stage_operands(0);
+  // every load of the prologue (the row operands among them) is complete before the loop: the compiler's wait-count
+  // bookkeeping otherwise carries "row operands pending" around the back edge and makes the MFMAs of EVERY tile wait for
+  // the loads just issued for the next one (vmcnt(14) ... vmcnt(0) inside the MFMA sequence: the prefetch hid nothing)
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+  __syncthreads();
+  for (int tj = tj0; tj <= tj1; tj += 2) {
+    // even position of the strip: stage 0 / coldA; odd: stage 1 / coldB
+    const bool more1 = tj + 1 <= tj1;
+    if (more1) { fetch_operands(tj + 1); __builtin_amdgcn_sched_barrier(0); fetch_cold(tj + 1, coldB); }
+    tile(tj, 0, coldA, more1 ? 1 : -1);
+    __syncthreads();
+    if (!more1) break;
+    const bool more2 = tj + 2 <= tj1;
+    if (more2) { fetch_operands(tj + 2); __builtin_amdgcn_sched_barrier(0); fetch_cold(tj + 2, coldA); }
+    tile(tj + 1, 1, coldB, more2 ? 0 : -1);
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- stage 1: corner in LDS
@@ -1335,6 +1498,24 @@ int64_t sbr_scratch_doubles(int D) {
          + 8 * BW * BW + BW + 16;             // R1, R2, U, Vtop, Tinv, C, W2, spare | sgn | scalars
 }
 
+// The read-modify-write pass over the lower triangle of A': strips of tiles through the pipelined kernel once there are
+// enough tiles to fill the chip with strips, one tile per workgroup below that.
+constexpr int STRIP_MIN_TILES = 2048;
+static void launch_update(hipStream_t st, const PanelGeom &g, int off, const double *V, const double *Z, int part, int nt) {
+  const int tiles = nt * (nt + 1) / 2;
+  if (tiles < STRIP_MIN_TILES || option(OPT_SBR_SERIAL)) {
+    hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(tiles), dim3(256), 0, st, g, off, V, Z, part, 0, nt);
+    return;
+  }
+  const int strip = min(8, max(2, tiles / 1024));
+  const bool ragged = ((g.m + off) & 63) != 0;
+  const int ti_lo = 1, ti_hi = ragged ? nt - 2 : nt - 1, tj_lo = off ? 1 : 0;       // rows ti_lo .. ti_hi, columns tj_lo .. ti - 1
+  if (ti_hi >= ti_lo && ti_hi - 1 >= tj_lo)
+    hipLaunchKernelGGL(trailing_update_strip_kernel, dim3(ceil_div(ti_hi - tj_lo, strip), ti_hi - ti_lo + 1), dim3(256), 0, st, g, off, V, Z,
+                       part, strip, ti_lo, tj_lo);
+  hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(3 * nt), dim3(256), 0, st, g, off, V, Z, part, 2, nt);
+}
+
 // Stage 1: G (D x D, both triangles, overwritten) -> compact lower band AB = scratch[0 .. D * LDB) (column-major band:
 // AB[j * LDB + k] = B[j + k][j]).  Everything is enqueued on `st`.
 int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
@@ -1420,16 +1601,16 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     } else {
       const int nt = ceil_div(g.m + off, 64);
       if (la && g.m >= LOOKAHEAD_MIN_M) {
-        hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(nt), dim3(256), 0, st, g, off, V, Z, 1);
+        hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(nt), dim3(256), 0, st, g, off, V, Z, 1, 1, nt);
         hipError_t e2 = hipEventRecord(la->fork, st);
         if (e2 == hipSuccess) e2 = hipStreamWaitEvent(la->side, la->fork, 0);
         if (e2 != hipSuccess) { set_error("sbr: look-ahead fork: %s", hipGetErrorString(e2)); return (int)e2; }
-        hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, la->side, g, off, V, Z, 2);
+        launch_update(la->side, g, off, V, Z, 2, nt);
         e2 = hipEventRecord(la->join, la->side);
         if (e2 != hipSuccess) { set_error("sbr: look-ahead join: %s", hipGetErrorString(e2)); return (int)e2; }
         join_pending = true;
       } else {
-        hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, g, off, V, Z, 0);
+        launch_update(st, g, off, V, Z, 0, nt);
       }
     }
     after("trailing_update_kernel", j0);
