@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0
 DTYPE = "f32" if os.environ.get("IDIFF_NO_SPLIT") else \
     "f32 (3x3 convs: fp32 MFMA; 1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate)"
 WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=1e-5, B=128 -> S 4480x3072 + centred spectrum + ID"
-TRAFFIC_TABLE = os.path.join("profiles", "r02_wino_traffic.json")
+TRAFFIC_TABLE = os.path.join("profiles", "r03_wino_traffic.json")
 WINOGRAD_SOURCE = os.path.join("id-diff_amd", "csrc", "winograd.hip")
 
 

@@ -1470,8 +1470,15 @@ static Lookahead *lookahead_for(hipStream_t st) {
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   Lookahead &l = cache[dev & 63];
   if (!l.side) {
-    int prio = 0;
+    // A priority class of its own: the runtime maps streams of one class onto a small pool of hardware queues, and a
+    // helper that lands on the caller's queue runs its launches in line with the caller's (measured inside bench.py, where
+    // a third stream exists: band reduction at D = 12288 253 ms with the helper in the caller's class, 231 ms serial).
+    // The update is the bandwidth-bound half, so it takes the lower class where there is one.
+    int prio = 0, least = 0, greatest = 0;
     if (hipStreamGetPriority(st, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = prio; }
+    if (prio < least) ++prio;                          // numerically larger = lower priority
+    else if (prio > greatest) --prio;
     hipStream_t s2 = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
     if (hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio) != hipSuccess ||
@@ -1503,7 +1510,7 @@ int64_t sbr_scratch_doubles(int D) {
 constexpr int STRIP_MIN_TILES = 2048;
 static void launch_update(hipStream_t st, const PanelGeom &g, int off, const double *V, const double *Z, int part, int nt) {
   const int tiles = nt * (nt + 1) / 2;
-  if (tiles < STRIP_MIN_TILES || option(OPT_SBR_SERIAL)) {
+  if (tiles < STRIP_MIN_TILES) {
     hipLaunchKernelGGL(trailing_update_lower_kernel, dim3(tiles), dim3(256), 0, st, g, off, V, Z, part, 0, nt);
     return;
   }
@@ -1549,11 +1556,15 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
   after("fro2", 0);
   // IDIFF_SBR_FULL (A/B): the round-2 form that keeps both triangles of the trailing block up to date
   const bool full = option(OPT_SBR_FULL);
-  // Look-ahead: the six panel kernels of panel j + 1 need only the first 32 columns of the updated block.  Those are
-  // updated first (part 1, m x 32), then the rest of the update (part 2: the launch that moves the bytes) runs on a helper
-  // stream BESIDE the latency-bound panel chain and joins before Y = A' V needs the whole block.  Only for blocks large
-  // enough that the update outlasts the cross-stream hand-off.
-  Lookahead *la = (full || dbg || option(OPT_SBR_SERIAL) || D - BW < LOOKAHEAD_MIN_M) ? nullptr : lookahead_for(st);
+  // Look-ahead (OPT-IN, IDIFF_SBR_LOOKAHEAD): the six panel kernels of panel j + 1 need only the first 32 columns of the
+  // updated block.  Those are updated first (part 1, m x 32), then the rest of the update (part 2: the launch that moves
+  // the bytes) runs on a helper stream BESIDE the latency-bound panel chain and joins before Y = A' V needs the whole
+  // block.  Only for blocks large enough that the update outlasts the cross-stream hand-off.  Measured at D = 12288:
+  // band reduction 164 -> 151 ms in a process with two or three streams; 164 -> 262 ms once the process had made a few
+  // more (bench.py after its config-2 leg): the runtime then maps the helper onto the caller's hardware queue, whatever
+  // its priority class, and every fork / join becomes an in-queue barrier.  A library cannot see that mapping, so the
+  // default is the serial form.
+  Lookahead *la = (full || dbg || !option(OPT_SBR_LOOKAHEAD) || D - BW < LOOKAHEAD_MIN_M) ? nullptr : lookahead_for(st);
   bool join_pending = false;
   int j0 = 0, panel = 0;
   while (D - j0 > CORNER) {

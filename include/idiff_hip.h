@@ -42,7 +42,9 @@ const char *idiff_source_stamp(void);
  * stderr: a fault then names its kernel), IDIFF_SBR_FULL (band reduction keeps both triangles up to date, the round-2 form),
  * IDIFF_NO_SPLIT (contractions of idiff_gemm_f32 / idiff_conv2d_nhwc_f32 on the fp32 matrix cores instead of the
  * split-precision products described there), IDIFF_WINO_SPLIT (opt-in: the split-precision Winograd kernel),
- * IDIFF_SBR_SERIAL (band reduction without the look-ahead: every launch of a panel on the caller's stream).
+ * IDIFF_SBR_LOOKAHEAD (opt-in: band reduction with the look-ahead -- the bulk of a panel's trailing update on a helper
+ * stream beside the next panel's factorisation; 5 % at D = 12288 when the helper gets a hardware queue of its own, 50 %
+ * SLOWER when the runtime maps it onto the caller's queue, which happens once a process has made a few streams).
  * Returns the previous value, -1 for an unknown name.  No reference counterpart. */
 int idiff_set_option(const char *name, int value);
 

@@ -10,8 +10,8 @@ for D in [int(a) for a in sys.argv[1:]] or [3072, 12288]:
     G = torch.randn(D + 64, D, device="cuda", dtype=torch.float64)
     G = G.T @ G
     ref = None
-    for name, serial in (("serial", 1), ("look-ahead", 0), ("serial", 1), ("look-ahead", 0)):
-        _lib.set_option("IDIFF_SBR_SERIAL", serial)
+    for name, la in (("serial", 0), ("look-ahead", 1), ("serial", 0), ("look-ahead", 1)):
+        _lib.set_option("IDIFF_SBR_LOOKAHEAD", la)
         A = [G.clone() for _ in range(3)]
         ev = _lib.sym_eigvals(A[0])
         torch.cuda.synchronize()
@@ -24,4 +24,4 @@ for D in [int(a) for a in sys.argv[1:]] or [3072, 12288]:
             ref = ev.clone()
         print(f"D = {D:6d} {name:10s}: {e0.elapsed_time(e1) / 2:8.2f} ms per eigensolve; max |d eig| / max eig vs first run "
               f"{((ev - ref).abs().max() / ref.abs().max()).item():.2e}", flush=True)
-    _lib.set_option("IDIFF_SBR_SERIAL", 0)
+    _lib.set_option("IDIFF_SBR_LOOKAHEAD", 0)

@@ -210,6 +210,28 @@ def test_two_stage_eigensolver(kind, D):
         assert float((other - ref).abs().max()) <= tol, opt
 
 
+@pytest.mark.parametrize("D", [4352, 4330])
+def test_band_reduction_large_block_forms(D):
+    """Blocks of >= 2048 tiles take the pipelined strip kernel for the trailing update (sbr.hip, k11p; D = 4330 does not end
+    on a tile boundary: the last tile row, the diagonal and the half first column go through the one-tile kernel), and
+    IDIFF_SBR_LOOKAHEAD (opt-in) runs the bulk of the update on a helper stream: the same eigenvalues as LAPACK in the
+    default form, and bit for bit the same result with the look-ahead."""
+    g = torch.Generator(device="cpu").manual_seed(D)
+    S = torch.randn(D + 40, D, generator=g, dtype=torch.float64)
+    G = (S.T @ S).to(DEV)
+    ref = torch.linalg.eigvalsh(G).cpu()                       # rocSOLVER on the device: seconds at this size on the host
+    scale = float(ref.abs().max())
+    ev = _lib.sym_eigvals(G.clone())
+    assert float((ev.cpu() - ref).abs().max()) <= 5e-14 * scale
+    prev = _lib.set_option("IDIFF_SBR_LOOKAHEAD", True)
+    try:
+        ev2 = _lib.sym_eigvals(G.clone())
+        ev3 = _lib.sym_eigvals(G.clone())                     # the helper stream and its events are reused
+    finally:
+        _lib.set_option("IDIFF_SBR_LOOKAHEAD", int(prev))
+    assert torch.equal(ev, ev2) and torch.equal(ev, ev3)
+
+
 def test_stage_exports():
     g = torch.Generator().manual_seed(4)
     M, D = 257, 70
