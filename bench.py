@@ -236,15 +236,16 @@ def spectrum_stage_report(rows, D, dev, reps=3):
     G = _lib.centered_gram(S, mean)
     band_ms = timed(lambda: _lib.sym_band(G.clone(), dense=False)) - timed(lambda: G.clone())
     eig_ms = timed(lambda: _lib.sym_eigvals(G.clone())) - timed(lambda: G.clone())
-    # algorithmic work: Gram = 2 M D^2 / 2 flops (upper-triangular tiles); band reduction streams the trailing block three
-    # times per 32-column panel (read for Y = A'V, read + write for the rank-64 update): 24 bytes x sum_k m_k^2
+    # algorithmic work: Gram = 2 M D^2 / 2 flops (upper-triangular tiles); band reduction streams the LOWER TRIANGLE of the
+    # trailing block three times per 32-column panel (read for Y = A'V, read + write for the rank-64 update): 12 bytes x
+    # sum_k m_k^2 (24 in round 2, when both triangles were kept)
     m2 = sum((D - 32 * (k + 1)) ** 2 for k in range(max(0, (D - 128 + 31) // 32)))
     stages = [
         {"kernel": "gram_big_kernel + mirror pass (fp64 centred Gram, upper-triangular 128x128 tiles, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": rows * D * D / (gram_ms * 1e-3) / 1e12,
          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rows * D * D / (gram_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms": gram_ms},
         {"kernel": "band reduction, stage 1 of the eigensolver (launches per 32-column panel: see DESIGN 4.2; latency-bound at D = 3072)", "bound": "hbm",
-         "achieved": 24.0 * m2 / (band_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": 24.0 * m2 / (band_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": band_ms},
+         "achieved": 12.0 * m2 / (band_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": 12.0 * m2 / (band_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": band_ms},
         {"kernel": "systolic bulge chasing + Sturm bisection (one persistent launch; a chain of 2D dependent steps)", "bound": "latency",
          "ms": eig_ms - band_ms, "us_per_sweep": (eig_ms - band_ms) * 1e3 / D},
     ]
