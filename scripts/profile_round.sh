@@ -39,7 +39,7 @@ PY
 cat $O/${TAG}_pmc_winograd.txt
 echo "[3] kernel stats of the bench"
 cd $R
-( cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/bench_under_rocprof.err ) || echo "stats run failed"
+( cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_bench_under_rocprof.json 2> $O/bench_under_rocprof.err ) || echo "stats run failed"
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f $O/${TAG}_kernel_stats.csv && python3 scripts/stats_top.py $O/stats 30 > $O/${TAG}_kernel_stats_top.txt
 cat $O/${TAG}_kernel_stats_top.txt | head -12
