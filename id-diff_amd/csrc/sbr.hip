@@ -408,6 +408,13 @@ __global__ void __launch_bounds__(256) panel_t_kernel(PanelGeom g, const double 
 // as two 16-row MFMA tiles x two 16-column tiles.  A lane fetches four consecutive k of each of its two rows (32 bytes
 // each) and spends them on four MFMAs per tile.
 constexpr int YROWS = 128;
+// BUF: A' is addressed through one buffer descriptor with 32-bit byte offsets (per-lane part in one register, per-chunk
+// part in the scalar offset): no vector instruction per load.  PMC at D = 12288 had shown 4.8 vector instructions per MFMA
+// in this kernel (64-bit address arithmetic per element, LDS index arithmetic per operand), and on gfx950 they do not
+// overlap the fp64 MFMAs of the same SIMD.  Matrices of 4 GB and more (D >= 23171) keep the pointer form.
+typedef unsigned int sbr_uintx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int sbr_uintx2 __attribute__((ext_vector_type(2)));
+template <bool BUF>
 __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const double *__restrict__ V, double *__restrict__ Ypart, int krange,
                                                          int off /* lo & 63, or -1: both triangles of A' are valid */) {
   __shared__ double Vs[KSPLIT_COLS][BW];
@@ -436,23 +443,49 @@ __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const doub
   // the chunk just requested.  A wave's 32 rows lie in ONE tile row (32-row blocks, 64-row tiles), so its chunks split
   // into a run read directly (tile column <= tile row) and a run read as mirrored transposes: one loop each.
   typedef double double4u __attribute__((ext_vector_type(4), aligned(8)));     // 32 bytes of a row, 8-byte aligned
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, BUF ? (int)((int64_t)g.D * g.D * 8) : 0, 0x00020000);
+  // byte offsets of this lane's share of a chunk at column 0: rows r0c / r1c, four columns from 4 fk (direct), and the
+  // transposed positions (mirror)
+  const unsigned vd0 = (unsigned)((((int64_t)(g.lo + r0c) * g.D) + g.lo + 4 * fk) * 8), vd1 = (unsigned)((((int64_t)(g.lo + r1c) * g.D) + g.lo + 4 * fk) * 8);
+  const unsigned vm0 = (unsigned)((((int64_t)(g.lo + 4 * fk) * g.D) + g.lo + r0c) * 8), vm1 = (unsigned)((((int64_t)(g.lo + 4 * fk) * g.D) + g.lo + r1c) * 8);
+  auto as2 = [](sbr_uintx4 v, double &x, double &y) {
+    x = __builtin_bit_cast(double, (sbr_uintx2){v.x, v.y});
+    y = __builtin_bit_cast(double, (sbr_uintx2){v.z, v.w});
+  };
   auto load_direct = [&](int c, double (&a0)[2][4], double (&a1)[2][4]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int kb = c + 16 * h + 4 * fk;
-      const double4u v = *reinterpret_cast<const double4u *>(ar0 + kb), w = *reinterpret_cast<const double4u *>(ar1 + kb);
-      a0[h][0] = v.x; a0[h][1] = v.y; a0[h][2] = v.z; a0[h][3] = v.w;
-      a1[h][0] = w.x; a1[h][1] = w.y; a1[h][2] = w.z; a1[h][3] = w.w;
+      if constexpr (BUF) {
+        const int so = (c + 16 * h) * 8;               // wave-uniform: rides in the scalar offset
+        as2(__builtin_amdgcn_raw_buffer_load_b128(rA, (int)vd0, so, 0), a0[h][0], a0[h][1]);
+        as2(__builtin_amdgcn_raw_buffer_load_b128(rA, (int)vd0, so + 16, 0), a0[h][2], a0[h][3]);
+        as2(__builtin_amdgcn_raw_buffer_load_b128(rA, (int)vd1, so, 0), a1[h][0], a1[h][1]);
+        as2(__builtin_amdgcn_raw_buffer_load_b128(rA, (int)vd1, so + 16, 0), a1[h][2], a1[h][3]);
+      } else {
+        const int kb = c + 16 * h + 4 * fk;
+        const double4u v = *reinterpret_cast<const double4u *>(ar0 + kb), w = *reinterpret_cast<const double4u *>(ar1 + kb);
+        a0[h][0] = v.x; a0[h][1] = v.y; a0[h][2] = v.z; a0[h][3] = v.w;
+        a1[h][0] = w.x; a1[h][1] = w.y; a1[h][2] = w.z; a1[h][3] = w.w;
+      }
     }
   };
   auto load_mirror = [&](int c, double (&a0)[2][4], double (&a1)[2][4]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const double *q = Ap + (int64_t)(c + 16 * h + 4 * fk) * g.D;
+      if constexpr (BUF) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a0[h][u] = q[(int64_t)u * g.D + r0c];
-        a1[h][u] = q[(int64_t)u * g.D + r1c];
+        for (int u = 0; u < 4; ++u) {
+          const int so = (c + 16 * h + u) * g.D * 8;   // wave-uniform (D^2 x 8 < 2^32 on this path)
+          a0[h][u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rA, (int)vm0, so, 0));
+          a1[h][u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rA, (int)vm1, so, 0));
+        }
+      } else {
+        const double *q = Ap + (int64_t)(c + 16 * h + 4 * fk) * g.D;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a0[h][u] = q[(int64_t)u * g.D + r0c];
+          a1[h][u] = q[(int64_t)u * g.D + r1c];
+        }
       }
     }
   };
@@ -479,39 +512,42 @@ __global__ void __launch_bounds__(256) trailing_y_kernel(PanelGeom g, const doub
     }
     __syncthreads();
   };
+  // a lane's two operand columns of Vs are fixed: row kl = inblk + 16 h + 4 fk + u has (kl >> 2) & 1 = fk & 1 (inblk is a
+  // multiple of 32), so the rotation is 16 (fk & 1) for every read of the lane, and the row index is one per-lane base plus
+  // a uniform part -- one register and an immediate per LDS read instead of index arithmetic per operand
+  const double *vb0 = &Vs[4 * fk][(fl + 16 * (fk & 1)) & 31], *vb1 = &Vs[4 * fk][(16 + fl + 16 * (fk & 1)) & 31];
   auto mma = [&](int inblk, const double (&a0)[2][4], const double (&a1)[2][4]) {
+    const double *p0 = vb0 + inblk * BW, *p1 = vb1 + inblk * BW;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int kl = inblk + 16 * h + 4 * fk + u;
-        const int rot = 16 * ((kl >> 2) & 1);
-        const double b0 = Vs[kl][(fl + rot) & 31], b1 = Vs[kl][(16 + fl + rot) & 31];
+        const double b0 = p0[(16 * h + u) * BW], b1 = p1[(16 * h + u) * BW];
         acc[0][0] = mfma(a0[h][u], b0, acc[0][0]);
         acc[0][1] = mfma(a0[h][u], b1, acc[0][1]);
         acc[1][0] = mfma(a1[h][u], b0, acc[1][0]);
         acc[1][1] = mfma(a1[h][u], b1, acc[1][1]);
       }
   };
-  double A0[2][2][4], A1[2][2][4];
+  double A0[3][2][4], A1[3][2][4];
   // chunks cb, cb + 32, ... < ce, every one of them whole; every wave of the workgroup passes the same chunks in the same
-  // order (only the loader differs), so the barriers of fill() meet
+  // order (only the loader differs), so the barriers of fill() meet.  Requests run TWO chunks ahead of the MFMAs (three
+  // register sets in rotation): a chunk is 2048-4096 cycles of matrix work at two waves per SIMD, less than a loaded
+  // memory round trip.
   auto run = [&](auto loader, int cb, int ce) {
     if (cb >= ce) return;
     loader(cb, A0[0], A1[0]);
-    for (int c = cb; c < ce; c += 64) {
-      {
-        const int inblk = (c - k_lo) & (KSPLIT_COLS - 1);
-        if (inblk == 0) fill(c);
-        loader(min(c + 32, ce - 32), A0[1], A1[1]);
-        mma(inblk, A0[0], A1[0]);
-      }
-      if (c + 32 < ce) {
-        const int inblk = (c + 32 - k_lo) & (KSPLIT_COLS - 1);
-        if (inblk == 0) fill(c + 32);
-        loader(min(c + 64, ce - 32), A0[0], A1[0]);
-        mma(inblk, A0[1], A1[1]);
-      }
+    loader(min(cb + 32, ce - 32), A0[1], A1[1]);
+    auto step = [&](int c, double (&a0)[2][4], double (&a1)[2][4], double (&n0)[2][4], double (&n1)[2][4]) {
+      const int inblk = (c - k_lo) & (KSPLIT_COLS - 1);
+      if (inblk == 0) fill(c);
+      loader(min(c + 64, ce - 32), n0, n1);
+      mma(inblk, a0, a1);
+    };
+    for (int c = cb; c < ce; c += 96) {
+      step(c, A0[0], A1[0], A0[2], A1[2]);
+      if (c + 32 < ce) step(c + 32, A0[1], A1[1], A0[0], A1[0]);
+      if (c + 64 < ce) step(c + 64, A0[2], A1[2], A0[1], A1[1]);
     }
   };
   const int k_full = k_lo + ((k_hi - k_lo) & ~31);                       // k_hi <= g.m: chunks below k_full are whole
@@ -1598,7 +1634,10 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
       if (hipError_t e2 = hipStreamWaitEvent(st, la->join, 0); e2 != hipSuccess) { set_error("sbr: hipStreamWaitEvent: %s", hipGetErrorString(e2)); return (int)e2; }
       join_pending = false;
     }
-    hipLaunchKernelGGL(trailing_y_kernel, dim3(rbs, nks), dim3(256), 0, st, g, V, Ypart, krange, full ? -1 : off);
+    if ((int64_t)D * D * 8 < 0xFFFFFFFFll)
+      hipLaunchKernelGGL(trailing_y_kernel<true>, dim3(rbs, nks), dim3(256), 0, st, g, V, Ypart, krange, full ? -1 : off);
+    else
+      hipLaunchKernelGGL(trailing_y_kernel<false>, dim3(rbs, nks), dim3(256), 0, st, g, V, Ypart, krange, full ? -1 : off);
     after("trailing_y_kernel", j0);
     hipLaunchKernelGGL(trailing_yk_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Ypart, nks, V, Y, Kp);
     after("trailing_yk_kernel", j0);
