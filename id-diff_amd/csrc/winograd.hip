@@ -374,7 +374,7 @@ winograd_kernel(const WinoParams p) {
   // the per-step offsets are wave-uniform: they ride in the buffer instruction's scalar offset (not part of the range
   // check of a raw buffer, so an out-of-range pixel stays out of range) instead of costing a VALU add per load
   auto fetch = [&]() {
-    const int choff = f_step * (KC * 4);
+    const int choff = min(f_step, nsteps - 1) * (KC * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) ldv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)v_src[j], choff, 0));
     ++f_step;
@@ -436,19 +436,18 @@ winograd_kernel(const WinoParams p) {
       load_b(j, min(s + 1, nsteps - 1));
     }
   };
-  auto step = [&](int s, auto first) {
+  // The role is a compile-time constant of the loop a wave runs, and writing the next stage / requesting the one after are
+  // unconditional (the last two steps re-request the last stage and write a stage nobody reads): the compiler's wait counts
+  // are static, and with `if (early)` / `if (s + 2 < nsteps)` inside one shared loop the paths merged into `s_waitcnt
+  // vmcnt(1) / vmcnt(0)` in front of the input transform -- an early wave waited for the filter loads of the CURRENT step
+  // (issued at the end of the previous one) before starting the work that is meant to cover them.
+  auto step = [&](int s, auto first, auto is_early) {
     const int buf = s & 1;
-    if (early) {
-      if (s + 1 < nsteps) stage(buf ^ 1);   // loaded one step ago
-      if (s + 2 < nsteps) fetch();
-    }
+    if constexpr (decltype(is_early)::value) { stage(buf ^ 1); fetch(); }
     compute(buf, 0, s, first);
     __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of the two halves from being hoisted together
     compute(buf, 2, s, first);
-    if (!early) {
-      if (s + 1 < nsteps) stage(buf ^ 1);
-      if (s + 2 < nsteps) fetch();
-    }
+    if constexpr (!decltype(is_early)::value) { stage(buf ^ 1); fetch(); }
     __syncthreads();
   };
 
@@ -456,19 +455,24 @@ winograd_kernel(const WinoParams p) {
   for (int j = 0; j < 4; ++j) load_b(j, 0);
   fetch();
   stage(0);
-  if (nsteps > 1) fetch();
+  fetch();
   __syncthreads();
 
-  if constexpr (PEEL) {
-    step(0, std::true_type());
-    for (int s = 1; s < nsteps; ++s) step(s, std::false_type());
-  } else {
+  auto run = [&](auto is_early) {
+    if constexpr (PEEL) {
+      step(0, std::true_type(), is_early);
+      for (int s = 1; s < nsteps; ++s) step(s, std::false_type(), is_early);
+    } else {
+      for (int s = 0; s < nsteps; ++s) step(s, std::false_type(), is_early);
+    }
+  };
+  if constexpr (!PEEL) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    for (int s = 0; s < nsteps; ++s) step(s, std::false_type());
   }
+  if (early) run(std::true_type()); else run(std::false_type());
 
   wino_tail<0>(p, acc, lds, tile0, n0, tile_m, tid, lane, wave, wi, tb);
 #ifdef IDIFF_WINO_STAMP
