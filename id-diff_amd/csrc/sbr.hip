@@ -918,24 +918,29 @@ __global__ void __launch_bounds__(256, 2) trailing_update_strip_kernel(PanelGeom
 #pragma unroll
       for (int c = 0; c < 2; ++c) acc[a][c] = (doublex4){0.0, 0.0, 0.0, 0.0};
     // acc += Z_i V_j^T + V_i Z_j^T, in this order for every tile (as trailing_update_lower_kernel: bit-identical results)
+    // the column operands of group g + 1 = (pass, kc) are read from LDS before the 16 MFMAs of group g are issued
+    double bv[2][2][4];
+    auto read_b = [&](int grp, double (&b)[2][4]) {
+      const int pass = grp >> 1, kc = grp & 1;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
-        double bv[2][4];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const double2u *b = reinterpret_cast<const double2u *>(&Bs[st][pass][wc * 32 + c * 16 + fl][kc * 16 + 4 * fk]);
-          const double2u lo = b[0], hi = b[1];
-          bv[c][0] = lo.x; bv[c][1] = lo.y; bv[c][2] = hi.x; bv[c][3] = hi.y;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[a][c] = mfma(av[pass][kc][a][u], bv[c][u], acc[a][c]);
+      for (int c = 0; c < 2; ++c) {
+        const double2u *q = reinterpret_cast<const double2u *>(&Bs[st][pass][wc * 32 + c * 16 + fl][kc * 16 + 4 * fk]);
+        const double2u lo = q[0], hi = q[1];
+        b[c][0] = lo.x; b[c][1] = lo.y; b[c][2] = hi.x; b[c][3] = hi.y;
       }
+    };
+    read_b(0, bv[0]);
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+      if (grp + 1 < 4) read_b(grp + 1, bv[(grp + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);              // or the scheduler sinks the reads back down to their use
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[a][c] = mfma(av[grp >> 1][grp & 1][a][u], bv[grp & 1][c][u], acc[a][c]);
+    }
     // the next tile's column operands go to LDS BEFORE this tile's stores are issued: the wait for those loads would
     // otherwise also wait for the stores (one counter for both)
     if (next_st >= 0) stage_operands(next_st);
