@@ -63,3 +63,26 @@ def test_product_does_not_import_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_no_kernel_spills_to_scratch_beyond_the_known_ones(library, tmp_path):
+    """both GPU faults of the build were inside multi-workgroup kernels whose register allocation had spilled
+    hundreds of bytes per lane to scratch; the rule since then is that no kernel of the library carries a scratch segment
+    beyond a few dwords, except the two one-workgroup factorisation kernels that always have.  Read from the code objects."""
+    import shutil, subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{llvm}/llvm-objdump") and os.path.exists(f"{llvm}/llvm-readelf")):
+        pytest.skip("no LLVM binutils")
+    so = shutil.copy(_lib.library_path(), tmp_path / "lib.so")
+    subprocess.run([f"{llvm}/llvm-objdump", "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    objs = [p for p in os.listdir(tmp_path) if "gfx950" in p]
+    assert objs, "no gfx950 code object in the library"
+    allowed = {"panel_chol1_kernel": 1024, "panel_hr_kernel": 1024}     # one workgroup each (sbr.hip), bytes per lane
+    seen = 0
+    for o in objs:
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", str(tmp_path / o)], check=True, capture_output=True, text=True).stdout
+        for name, size in re.findall(r"\.name:\s+(\S+)\s+\.private_segment_fixed_size:\s+(\d+)", notes):
+            seen += 1
+            limit = next((v for k, v in allowed.items() if k in name), 64)
+            assert int(size) <= limit, f"{name}: {size} bytes of scratch per lane"
+    assert seen >= 40
