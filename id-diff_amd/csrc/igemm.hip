@@ -297,7 +297,13 @@ constexpr uint32_t OOB = 0xFFFFFFFFu;
 // v_mfma_f32_32x32x2_f32 -- the split form is not a reduced-precision mode.  The bf16 matrix core retires a 32x32x16 block in
 // 32 cycles where the fp32 one needs 8 x 64 for the same k extent: six of them are 2.7x cheaper, and unlike the fp32 MFMA they
 // run beside the vector ALU, which is where the splitting (about 5 instructions per element) goes.
-constexpr int SP = BK + 8;            // bf16 elements per LDS row of a split plane: 80 bytes, 16-byte aligned, conflict-free b128 reads
+// bf16 elements per LDS row of a split plane: 64 bytes, NO padding -- the four 16-byte chunks of a row are XOR-swizzled by
+// (row ^ (row >> 2)) & 3, which makes the b128 fragment reads of 16 consecutive rows hit every bank once, and the three
+// planes of a 128 x 32 + 128 x 32 tile pair take 48 KB instead of 60: THREE workgroups per CU instead of two (the k-tile
+// stamps of scripts/igemm_phases.py: 2300 cycles of LDS reads + MFMAs against 2170 of barrier / cutting / staging / fetch
+// per k-tile and wave, 13 k-cycles of prologue + epilogue per 8 k-tiles -- work that only other resident waves can cover).
+constexpr int SP = BK;
+__device__ __forceinline__ int split_swz(int row) { return (row ^ (row >> 2)) & 3; }
 
 __device__ __forceinline__ void split4(const float4 v, uint2 &p1, uint2 &p2, uint2 &p3) {
   const float x[4] = {v.x, v.y, v.z, v.w};
@@ -323,6 +329,9 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t b
 template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF, bool SPLIT>
 __global__ void __launch_bounds__(WARPS_M *WARPS_N * 64, (DBUF || SPLIT) ? 2 : 4)
 igemm_pipe_kernel(const IgemmParams p) {
+#ifdef IDIFF_IGEMM_PHASES
+  const uint64_t ph_entry = __builtin_amdgcn_s_memtime();
+#endif
   static_assert(!(SPLIT && DBUF), "the split form uses one LDS buffer");
   constexpr int T = WARPS_M * WARPS_N * 64;
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
@@ -445,6 +454,9 @@ igemm_pipe_kernel(const IgemmParams p) {
     ++f_kt;
   };
 
+  // ROW_STEP is a multiple of 16, so the swizzle of a thread's rows is one constant
+  static_assert(ROW_STEP % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "split-plane swizzle");
+  const int kc_sw = (((kc >> 3) ^ split_swz(row_base)) << 3) + (kc & 7);
   auto stage = [&](int buf) {
     if (SPLIT) {
       unsigned short *a_dst = As16 + buf * 3 * BM * SP, *b_dst = Bs16 + buf * 3 * BN * SP;
@@ -452,7 +464,7 @@ igemm_pipe_kernel(const IgemmParams p) {
       for (int i = 0; i < A_PER_T; ++i) {
         uint2 q1, q2, q3;
         split4(a_reg[i], q1, q2, q3);
-        unsigned short *d = a_dst + (row_base + i * ROW_STEP) * SP + kc;
+        unsigned short *d = a_dst + (row_base + i * ROW_STEP) * SP + kc_sw;
         *reinterpret_cast<uint2 *>(d) = q1;
         *reinterpret_cast<uint2 *>(d + BM * SP) = q2;
         *reinterpret_cast<uint2 *>(d + 2 * BM * SP) = q3;
@@ -461,7 +473,7 @@ igemm_pipe_kernel(const IgemmParams p) {
       for (int i = 0; i < B_PER_T; ++i) {
         uint2 q1, q2, q3;
         split4(b_reg[i], q1, q2, q3);
-        unsigned short *d = b_dst + (row_base + i * ROW_STEP) * SP + kc;
+        unsigned short *d = b_dst + (row_base + i * ROW_STEP) * SP + kc_sw;
         *reinterpret_cast<uint2 *>(d) = q1;
         *reinterpret_cast<uint2 *>(d + BN * SP) = q2;
         *reinterpret_cast<uint2 *>(d + 2 * BN * SP) = q3;
@@ -488,6 +500,14 @@ igemm_pipe_kernel(const IgemmParams p) {
   if (nkt > 1) fetch();
   __syncthreads();
 
+#ifdef IDIFF_IGEMM_PHASES   // diagnostic build only (scripts/igemm_phases.py): shader-clock ticks per phase of a k-tile
+  uint32_t ph[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t ph_last = __builtin_amdgcn_s_memtime();
+  const uint64_t ph_first = ph_last;
+#define IDIFF_PH(k) { __builtin_amdgcn_sched_barrier(0); const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[k] += (uint32_t)(t_ - ph_last); ph_last = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define IDIFF_PH(k)
+#endif
   auto ktile = [&](int kt, auto first) {
     const int buf = DBUF ? (kt & 1) : 0;
     if (DBUF && !SPLIT) {
@@ -496,19 +516,21 @@ igemm_pipe_kernel(const IgemmParams p) {
     }
     if (SPLIT) {
       // lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8 h + e] and B[k = 8 h + e][column r], e = 0 .. 7
-      const unsigned short *a16 = As16 + buf * 3 * BM * SP + (wm0 + frag_row) * SP + (lane >> 5) * 8;
-      const unsigned short *b16 = Bs16 + buf * 3 * BN * SP + (wn0 + frag_row) * SP + (lane >> 5) * 8;
+      // chunk (lane >> 5) + 2 s of row frag_row (+ multiples of 32: same swizzle): c0 for s = 0, c0 ^ 2 for s = 1
+      const int c0 = (lane >> 5) ^ split_swz(frag_row);
+      const unsigned short *a16 = As16 + buf * 3 * BM * SP + (wm0 + frag_row) * SP;
+      const unsigned short *b16 = Bs16 + buf * 3 * BN * SP + (wn0 + frag_row) * SP;
       bf16x8 af[BK / 16][TM][3], bf[BK / 16][TN][3];
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int q = 0; q < 3; ++q) af[s][i][q] = *reinterpret_cast<const bf16x8 *>(a16 + (q * BM + i * 32) * SP + s * 16);
+          for (int q = 0; q < 3; ++q) af[s][i][q] = *reinterpret_cast<const bf16x8 *>(a16 + (q * BM + i * 32) * SP + ((c0 ^ (2 * s)) << 3));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int q = 0; q < 3; ++q) bf[s][j][q] = *reinterpret_cast<const bf16x8 *>(b16 + (q * BN + j * 32) * SP + s * 16);
+          for (int q = 0; q < 3; ++q) bf[s][j][q] = *reinterpret_cast<const bf16x8 *>(b16 + (q * BN + j * 32) * SP + ((c0 ^ (2 * s)) << 3));
       }
       // the six partial products, smallest first
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -552,24 +574,40 @@ igemm_pipe_kernel(const IgemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
+    IDIFF_PH(0)
     __syncthreads();
+    IDIFF_PH(1)
     if (!DBUF) {
       // single LDS buffer (half the LDS -> three workgroups per CU): restage between two barriers; the other
       // resident workgroups keep the matrix pipe busy meanwhile
       if (kt + 1 < nkt) stage(0);
+      IDIFF_PH(2)
       if (kt + 2 < nkt) fetch();
+      IDIFF_PH(3)
       __syncthreads();
+      IDIFF_PH(4)
     }
   };
+#ifdef IDIFF_IGEMM_PHASES
+  const uint64_t ph_loop0 = __builtin_amdgcn_s_memtime();
+  ph_last = ph_loop0;
+#endif
   ktile(0, std::true_type());
   for (int kt = 1; kt < nkt; ++kt) ktile(kt, std::false_type());
+#ifdef IDIFF_IGEMM_PHASES
+  const uint64_t ph_loop1 = __builtin_amdgcn_s_memtime();
+#endif
 
   float *Cb = p.C + (int64_t)batch * p.strideC;
   const idiff_epilogue &ep = p.ep;
   const int col_l = lane & 31, row_l = (lane >> 5) * 4;
   // optional per-tile column statistics (sum, sum of squares in fp64) of the values being stored: the GroupNorm that
   // consumes this tensor then needs no pass of its own over HBM (idiff_epilogue.colstats)
+#ifdef IDIFF_IGEMM_PHASES
+  const bool want_stats = false;                   // epilogue.colstats carries the stamp buffer in this build
+#else
   const bool want_stats = p.has_ep && ep.colstats != nullptr;
+#endif
   double *red = reinterpret_cast<double *>(lds);   // [WARPS_M][BN][2]; operand staging is finished
   if (p.vec_ep && p.buf_ep) {
     // The form every contraction of the score networks takes.  As the vector form below (each wave turns its 32-row
@@ -799,7 +837,19 @@ igemm_pipe_kernel(const IgemmParams p) {
       dst[0] = a; dst[1] = b;
     }
   }
+#ifdef IDIFF_IGEMM_PHASES
+  if (p.has_ep && ep.colstats && lane == 0) {
+    // a buffer nothing else reads: [workgroup][wave][8]
+    const int64_t wg = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    uint32_t *st = reinterpret_cast<uint32_t *>(ep.colstats) + (wg * (T / 64) + (tid >> 6)) * 8;
+    for (int k = 0; k < 5; ++k) st[k] = ph[k];
+    st[5] = (uint32_t)(ph_loop0 - ph_entry);                       // prologue: kernel entry to the first k-tile
+    st[6] = (uint32_t)(__builtin_amdgcn_s_memtime() - ph_loop1);   // epilogue
+    st[7] = (uint32_t)nkt;
+  }
+#endif
 }
+#undef IDIFF_PH
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF = true, bool SPLIT = false>
 int launch_pipe(IgemmParams &p, int batch, hipStream_t st) {
