@@ -27,7 +27,7 @@ constexpr int CORNER = 128;        // trailing block reduced in LDS by one workg
 constexpr int CHUNK = 128;         // minimum rows of a panel per workgroup in the tall-skinny kernels
 constexpr int LDB = 2 * BW;        // leading dimension of the compact lower band: diagonals 0 .. 2BW-1 (bulge room)
 constexpr int PAD = 2;             // zero columns appended to the band (indices beyond it read as zero too): node 0 runs one sweep per column
-constexpr int KSPLIT_COLS = 256;   // columns of A' per workgroup of the Y = A' V kernel (its V slice, 64 KB, sits in LDS)
+constexpr int KSPLIT_COLS = 128;   // columns of A' per LDS block of the Y = A' V kernel (its V slice, 32 KB: three workgroups per CU by registers)
 
 // ---------------------------------------------------------------------------------------------- MFMA helpers
 // v_mfma_f64_16x16x4_f64: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; the accumulator
@@ -1615,11 +1615,12 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     g.A = G; g.D = D; g.j0 = j0; g.lo = j0 + BW; g.m = D - g.lo;
     g.chunk_rows = CHUNK;
     g.nchunk = ceil_div(g.m, g.chunk_rows);
-    // column range per workgroup of the Y kernel: as many workgroups as fit the chip AT ONCE (two per CU: 64 KB of LDS
-    // each), never a few more -- the kernel is bound by the fp64 matrix pipe, and 576 equal workgroups on 512 places
-    // took two rounds (435 us at m = 12256 against 250 us at m = 11040)
+    // column range per workgroup of the Y kernel: as many workgroups as fit the chip AT ONCE (three per CU: 160 registers,
+    // 32 KB of LDS each -- with a 64 KB V block it was two, and the third resident wave per SIMD is worth 10 % here),
+    // never a few more -- the kernel is bound by the fp64 matrix pipe, and 576 equal workgroups on 512 places took two
+    // rounds (435 us at m = 12256 against 250 us at m = 11040)
     const int rbs = ceil_div(g.m, YROWS);
-    int nks = min(ceil_div(g.m, KSPLIT_COLS), max(1, 512 / rbs));
+    int nks = min(min(ceil_div(g.m, KSPLIT_COLS), 12), max(1, 768 / rbs));     // <= 12 partials for trailing_yk to add up
     const int krange = ceil_div(ceil_div(g.m, nks), KSPLIT_COLS) * KSPLIT_COLS;
     nks = ceil_div(g.m, krange);
     hipLaunchKernelGGL(panel_gram_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp);
