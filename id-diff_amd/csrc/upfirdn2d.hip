@@ -376,9 +376,10 @@ upfirdn2d_nhwc_up2_block(const float *__restrict__ x, const float *__restrict__ 
   const int plane = bid / p.in_h, i = bid - plane * p.in_h;
   const int c4 = threadIdx.x % cv, col0 = threadIdx.x / cv;
   if (col0 >= col_step) return;
+  // the sixteen taps are wave-uniform: scalar registers (the array form was kept in a 32-byte scratch slot by the compiler)
   float w[16];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) w[t] = taps[t];
+  for (int t = 0; t < 16; ++t) w[t] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, taps[t])));
   const float4 *xp = reinterpret_cast<const float4 *>(x) + (int64_t)plane * p.in_h * p.in_w * cv + c4;
   float4 *op = reinterpret_cast<float4 *>(out) + ((int64_t)plane * p.out_h + 2 * i) * p.out_w * cv + c4;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
