@@ -357,52 +357,6 @@ __global__ void __launch_bounds__(256) panel_v_kernel(PanelGeom g, const double 
   store_tile_partial(VtPpart + (int64_t)chunk * BW * BW, i0, j0, acc2);
 }
 
-// k6: Tinv = striu(V^T V) + diag(V^T V) / 2 (upper triangular; T itself is never formed: every use is a triangular solve);
-//     C = T^T (V^T P) = Tinv^-T (V^T P);  the panel's surviving block R = P_top - V_top C goes back into A (upper triangle,
-//     mirrored), C is kept for the residual check of k10.
-__global__ void __launch_bounds__(256) panel_t_kernel(PanelGeom g, const double *__restrict__ VtVpart, const double *__restrict__ VtPpart,
-                                                     const double *__restrict__ Vtop, double *__restrict__ Tinv, double *__restrict__ C) {
-  __shared__ double M[BW][BW + 1];
-  __shared__ double W[BW][BW + 1];
-  const int tid = threadIdx.x;
-  reduce_partials(VtVpart, g.nchunk, M, true);
-  for (int e = tid; e < BW * BW; e += blockDim.x) {
-    const int i = e / BW, j = e % BW;
-    const double t = i < j ? M[i][j] : (i == j ? 0.5 * M[i][i] : 0.0);
-    Tinv[e] = t;
-  }
-  __syncthreads();
-  for (int e = tid; e < BW * BW; e += blockDim.x) { const int i = e / BW, j = e % BW; M[i][j] = i < j ? M[i][j] : (i == j ? 0.5 * M[i][i] : 0.0); }
-  reduce_partials(VtPpart, g.nchunk, W, false);
-  // C = Tinv^-T W: column c of C solves Tinv^T x = W[:, c] (forward substitution, Tinv^T lower); thread c owns column c
-  if (tid < BW) {          // Tinv^T x = w has the recurrence of x Tinv = w^T: the row solver on a register copy
-    double x[BW];
-#pragma unroll
-    for (int i = 0; i < BW; ++i) x[i] = W[i][tid];
-    row_solve_upper(x, M);
-#pragma unroll
-    for (int i = 0; i < BW; ++i) W[i][tid] = x[i];
-  }
-  __syncthreads();
-  for (int e = tid; e < BW * BW; e += blockDim.x) C[e] = W[e / BW][e % BW];
-  // R = P_top - V_top C, upper triangle kept (what is below is rounding noise of an exact annihilation)
-  for (int e = tid; e < BW * BW; e += blockDim.x) {
-    const int i = e / BW, j = e % BW;
-    double r = 0.0;
-    if (i <= j) {
-      r = g.A[(int64_t)(g.lo + i) * g.D + g.j0 + j];
-      for (int k = 0; k <= i; ++k) r -= Vtop[i * BW + k] * W[k][j];      // V_top is unit lower triangular
-    }
-    M[i][j] = r;
-  }
-  __syncthreads();
-  for (int e = tid; e < BW * BW; e += blockDim.x) {
-    const int i = e / BW, j = e % BW;
-    g.A[(int64_t)(g.lo + i) * g.D + g.j0 + j] = M[i][j];
-    g.A[(int64_t)(g.j0 + j) * g.D + g.lo + i] = M[i][j];
-  }
-}
-
 // k7: Ypart[ks][m][BW] = A'[:, ks-th column slice] V[slice]; workgroup = 128 rows x BW columns x one slice of KSPLIT_COLS
 // columns.  The V slice (KSPLIT_COLS x BW doubles) is staged in LDS once per workgroup; wave w owns rows [32 w, 32 w + 32)
 // as two 16-row MFMA tiles x two 16-column tiles.  A lane fetches four consecutive k of each of its two rows (32 bytes
@@ -594,53 +548,70 @@ __global__ void __launch_bounds__(256) trailing_yk_kernel(PanelGeom g, const dou
   store_tile_partial(Kpart + (int64_t)chunk * BW * BW, i0, j0, acc);
 }
 
-// k9: W2 = -(1/2) T^T K T = -(1/2) Tinv^-T K Tinv^-1 with K = sum Kpart (symmetric)
-__global__ void __launch_bounds__(256) trailing_w2_kernel(const double *__restrict__ Kpart, int nchunk, const double *__restrict__ Tinv,
-                                                         double *__restrict__ W2) {
-  __shared__ double K[BW][BW + 1];
-  __shared__ double Ti[BW][BW + 1];
-  const int tid = threadIdx.x;
-  reduce_partials(Kpart, nchunk, K, false);
-  for (int e = tid; e < BW * BW; e += blockDim.x) Ti[e / BW][e % BW] = Tinv[e];
-  __syncthreads();
-  // symmetrise K (V^T A' V of a symmetric A' up to rounding)
-  for (int e = tid; e < BW * BW; e += blockDim.x) { const int i = e / BW, j = e % BW; if (i < j) { const double s = 0.5 * (K[i][j] + K[j][i]); K[i][j] = s; K[j][i] = s; } }
-  __syncthreads();
-  // rows: K <- K Tinv^-1 (thread i owns row i)
-  if (tid < BW) {
-    double x[BW];
-#pragma unroll
-    for (int j = 0; j < BW; ++j) x[j] = K[tid][j];
-    row_solve_upper(x, Ti);
-#pragma unroll
-    for (int j = 0; j < BW; ++j) K[tid][j] = x[j];
-  }
-  __syncthreads();
-  // columns: K <- Tinv^-T K (thread c owns column c; Tinv^T is lower triangular)
-  if (tid < BW) {
-    double x[BW];
-#pragma unroll
-    for (int i = 0; i < BW; ++i) x[i] = K[i][tid];
-    row_solve_upper(x, Ti);
-#pragma unroll
-    for (int i = 0; i < BW; ++i) K[i][tid] = x[i];
-  }
-  __syncthreads();
-  for (int e = tid; e < BW * BW; e += blockDim.x) W2[e] = -0.5 * K[e / BW][e % BW];
-}
-
-// k10: Z = Y Tinv^-1 + V W2 (one thread per row); rows >= BW of the panel are checked (|| P_low - V_low C ||^2 is what
-// the annihilation left behind, accumulated into *resid2) and zeroed, together with their mirror.
-__global__ void __launch_bounds__(256) trailing_z_kernel(PanelGeom g, const double *__restrict__ Y, const double *__restrict__ V,
-                                                         const double *__restrict__ Tinv, const double *__restrict__ W2,
-                                                         const double *__restrict__ C, double *__restrict__ Z, double *__restrict__ resid2) {
+// k6 + k9 + k10 in one launch: every workgroup REDOES the two small single-workgroup steps (T^-1 and C from the V^T V / V^T P
+// partials; W2 from the K partials) in its own LDS instead of waiting for two one-workgroup launches in between -- the
+// partial sums are a few hundred KB of L2-resident data and the three 32 x 32 triangular solves take two waves a few
+// microseconds, against 16 + 13 us for the launches (9 launches per panel instead of 11).  Same operations in the same order
+// as the three kernels it replaces (round 2's panel_t / trailing_w2 / trailing_z), so the same bits; chunk 0 also writes the panel's surviving
+// block R back into A.
+__global__ void __launch_bounds__(256) trailing_tz_kernel(PanelGeom g, const double *__restrict__ VtVpart, const double *__restrict__ VtPpart,
+                                                          const double *__restrict__ Vtop, const double *__restrict__ Kpart,
+                                                          const double *__restrict__ Y, const double *__restrict__ V,
+                                                          double *__restrict__ Z, double *__restrict__ resid2) {
   __shared__ double Ti[BW][BW + 1];
   __shared__ double Wm[BW][BW + 1];
   __shared__ double Cm[BW][BW + 1];
   __shared__ double red[4];
-  const int chunk = blockIdx.x, tid = threadIdx.x;
-  for (int e = tid; e < BW * BW; e += 256) { Ti[e / BW][e % BW] = Tinv[e]; Wm[e / BW][e % BW] = W2[e]; Cm[e / BW][e % BW] = C[e]; }
+  const int chunk = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+  // ---- panel_t: Tinv = striu(V^T V) + diag(V^T V) / 2, C = Tinv^-T (V^T P)
+  reduce_partials(VtVpart, g.nchunk, Ti, true);
+  for (int e = tid; e < BW * BW; e += 256) { const int i = e / BW, j = e % BW; Ti[i][j] = i < j ? Ti[i][j] : (i == j ? 0.5 * Ti[i][i] : 0.0); }
+  reduce_partials(VtPpart, g.nchunk, Cm, false);
+  reduce_partials(Kpart, g.nchunk, Wm, false);
+  // symmetrise K (V^T A' V of a symmetric A' up to rounding)
+  for (int e = tid; e < BW * BW; e += 256) { const int i = e / BW, j = e % BW; if (i < j) { const double s = 0.5 * (Wm[i][j] + Wm[j][i]); Wm[i][j] = s; Wm[j][i] = s; } }
   __syncthreads();
+  if (wave == 0 && tid < BW) {          // C: column c of C solves Tinv^T x = W[:, c]
+    double x[BW];
+#pragma unroll
+    for (int i = 0; i < BW; ++i) x[i] = Cm[i][tid];
+    row_solve_upper(x, Ti);
+#pragma unroll
+    for (int i = 0; i < BW; ++i) Cm[i][tid] = x[i];
+  } else if (wave == 1 && tid - 64 < BW) {   // meanwhile: K <- K Tinv^-1 (thread i owns row i)
+    const int i = tid - 64;
+    double x[BW];
+#pragma unroll
+    for (int j = 0; j < BW; ++j) x[j] = Wm[i][j];
+    row_solve_upper(x, Ti);
+#pragma unroll
+    for (int j = 0; j < BW; ++j) Wm[i][j] = x[j];
+  }
+  __syncthreads();
+  if (wave == 1 && tid - 64 < BW) {     // K <- Tinv^-T K (thread c owns column c), W2 = -K / 2
+    const int c = tid - 64;
+    double x[BW];
+#pragma unroll
+    for (int i = 0; i < BW; ++i) x[i] = Wm[i][c];
+    row_solve_upper(x, Ti);
+#pragma unroll
+    for (int i = 0; i < BW; ++i) Wm[i][c] = -0.5 * x[i];
+  }
+  if (chunk == 0) {
+    // R = P_top - V_top C, upper triangle kept (what is below is rounding noise of an exact annihilation), mirrored
+    for (int e = tid; e < BW * BW; e += 256) {
+      const int i = e / BW, j = e % BW;
+      double r = 0.0;
+      if (i <= j) {
+        r = g.A[(int64_t)(g.lo + i) * g.D + g.j0 + j];
+        for (int k = 0; k <= i; ++k) r -= Vtop[i * BW + k] * Cm[k][j];      // V_top is unit lower triangular
+      }
+      g.A[(int64_t)(g.lo + i) * g.D + g.j0 + j] = r;
+      g.A[(int64_t)(g.j0 + j) * g.D + g.lo + i] = r;
+    }
+  }
+  __syncthreads();
+  // ---- trailing_z: Z = Y Tinv^-1 + V W2, residual of the rows below the band
   double res = 0.0;
   const int row = chunk * g.chunk_rows + tid;
   if (tid < g.chunk_rows && row < g.m) {
@@ -1633,8 +1604,6 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     after("panel_hr_kernel", j0);
     hipLaunchKernelGGL(panel_v_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Q, R2, U, Vtop, sgn, V, VtVp, VtPp);
     after("panel_v_kernel", j0);
-    hipLaunchKernelGGL(panel_t_kernel, dim3(1), dim3(256), 0, st, g, VtVp, VtPp, Vtop, Tinv, C);
-    after("panel_t_kernel", j0);
     const int off = g.lo & 63;                           // the trailing block starts `off` into its first tile of the absolute grid
     if (join_pending) {                                  // the rest of the previous update
       if (hipError_t e2 = hipStreamWaitEvent(st, la->join, 0); e2 != hipSuccess) { set_error("sbr: hipStreamWaitEvent: %s", hipGetErrorString(e2)); return (int)e2; }
@@ -1647,10 +1616,8 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     after("trailing_y_kernel", j0);
     hipLaunchKernelGGL(trailing_yk_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Ypart, nks, V, Y, Kp);
     after("trailing_yk_kernel", j0);
-    hipLaunchKernelGGL(trailing_w2_kernel, dim3(1), dim3(256), 0, st, Kp, g.nchunk, Tinv, W2);
-    after("trailing_w2_kernel", j0);
-    hipLaunchKernelGGL(trailing_z_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Y, V, Tinv, W2, C, Z, scal);
-    after("trailing_z_kernel", j0);
+    hipLaunchKernelGGL(trailing_tz_kernel, dim3(g.nchunk), dim3(256), 0, st, g, VtVp, VtPp, Vtop, Kp, Y, V, Z, scal);
+    after("trailing_tz_kernel", j0);
     const int tiles = ceil_div(g.m, 64);
     if (full) {
       hipLaunchKernelGGL(trailing_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, g, V, Z);
