@@ -188,6 +188,42 @@ __device__ __forceinline__ void cholesky_upper(double (*M)[BW + 1], double *dsc 
   wave_lds_sync();
 }
 
+// The same factorisation with TWO lanes per row: lane (i, h) = (tid & 31, tid >> 5) keeps columns 16 h .. 16 h + 15 of row i.
+// 89 registers and no scratch where the one-lane form needs more than 512 and spills (fine in the one-workgroup kernels
+// that use it, not in a multi-workgroup one: DESIGN.md 7.1); every element sees the same operations in the same order, so
+// the same bits.  Used where every workgroup of a row kernel redoes the factorisation (panel_q_kernel).
+__device__ __forceinline__ void cholesky_upper2(double (*M)[BW + 1], double *dsc /* [BW] */, double (*bc)[BW] /* [2][BW] */) {
+  static_assert(BW == 32, "lane = (row, column half)");
+  const int tid = threadIdx.x, i = tid & 31, h = (tid >> 5) & 1;
+  const double dii = M[i][i];
+  const double rdi = dii > 0.0 ? fast_rsqrt(dii) : 1.0;          // 1 / d_i
+  if (h == 0) dsc[i] = rdi;
+  wave_lds_sync();
+  double a[16];                   // a[kk] = element (i, 16 h + kk); turns into R[16 h + kk][i] once that step is done
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) a[kk] = M[i][16 * h + kk] * (rdi * dsc[16 * h + kk]);
+#pragma unroll
+  for (int j = 0; j < BW; ++j) {
+    double (*buf) = bc[j & 1];
+    if (h == (j >> 4)) buf[i] = a[j & 15];
+    wave_lds_sync();
+    const double piv = buf[j];
+    const bool ok = piv > 1e-30;
+    const double rinv = ok ? fast_rsqrt(piv) : 0.0;
+    const double rji = buf[i] * rinv;                  // R[j][i], this row's multiplier
+    if (h == (j >> 4)) a[j & 15] = i == j ? (ok ? piv * rinv : 1.0) : (i > j ? rji : 0.0);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const double upd = a[kk] - rji * (buf[(16 * h + kk) & 31] * rinv);
+      a[kk] = 16 * h + kk > j ? upd : a[kk];
+    }
+  }
+  const double di = dii > 0.0 ? dii * rdi : 1.0;                  // d_i = sqrt(G_ii)
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) M[16 * h + kk][i] = a[kk] * di;  // R[j][i] (zero for j > i), column scaling folded back
+  wave_lds_sync();
+}
+
 // LU without pivoting of the matrix in LDS (in place: unit-lower multipliers below the diagonal, U on and above it).
 // Lane i keeps row i in registers; the pivot row is passed through LDS by its owner.  Wave 0 only.
 __device__ __forceinline__ void lu_nopivot(double (*Bm)[BW + 1], double (*bc)[BW] /* [2][BW] */) {
@@ -217,17 +253,6 @@ __device__ __forceinline__ void lu_nopivot(double (*Bm)[BW + 1], double (*bc)[BW
   wave_lds_sync();
 }
 
-// k2: R1 = chol(sum Gpart)
-__global__ void __launch_bounds__(256) panel_chol1_kernel(const double *__restrict__ Gpart, int nchunk, double *__restrict__ R1) {
-  __shared__ double M[BW][BW + 1];
-  __shared__ double dsc[BW];
-  __shared__ double bc[2][BW];
-  reduce_partials(Gpart, nchunk, M, true);
-  if (threadIdx.x < 64) cholesky_upper(M, dsc, bc);
-  __syncthreads();
-  for (int e = threadIdx.x; e < BW * BW; e += blockDim.x) R1[e] = M[e / BW][e % BW];
-}
-
 // x <- x R^-1 for one row x (forward substitution over the columns of the upper-triangular R held in LDS).
 // Right-looking: as soon as x[j] is final it is taken out of every later column, so the 31 - j updates of a step are
 // independent of each other and only one multiply-add per column sits on the dependency chain (the left-looking loop
@@ -243,12 +268,17 @@ __device__ __forceinline__ void row_solve_upper(double *x, const double (*R)[BW 
   }
 }
 
-// k3: Q_chunk = P_chunk R1^-1 (one thread per row), stored; Gpart2[chunk] = Q_chunk^T Q_chunk
-__global__ void __launch_bounds__(256) panel_q_kernel(PanelGeom g, const double *__restrict__ R1, double *__restrict__ Q,
+// k2 + k3: R1 = chol(sum Gpart) redone by EVERY workgroup in its own LDS (two lanes per row: no scratch), then
+// Q_chunk = P_chunk R1^-1 (one thread per row), stored; Gpart2[chunk] = Q_chunk^T Q_chunk (a buffer of its own: other
+// workgroups may still be adding up Gpart).  One launch instead of a one-workgroup launch followed by this one.
+__global__ void __launch_bounds__(256) panel_q_kernel(PanelGeom g, const double *__restrict__ Gpart, double *__restrict__ Q,
                                                       double *__restrict__ Gpart2) {
   __shared__ double R[BW][BW + 1];
+  __shared__ double dsc[BW];
+  __shared__ double bc[2][BW];
   const int chunk = blockIdx.x, tid = threadIdx.x;
-  for (int e = tid; e < BW * BW; e += 256) R[e / BW][e % BW] = R1[e];
+  reduce_partials(Gpart, g.nchunk, R, true);
+  if (tid < 64) cholesky_upper2(R, dsc, bc);
   __syncthreads();
   const int r0 = chunk * g.chunk_rows, r1 = min(g.m, r0 + g.chunk_rows);
   const int row = r0 + tid;
@@ -1513,7 +1543,7 @@ int64_t sbr_scratch_doubles(int D) {
          + (int64_t)D * (BW + 1)              // carried reflectors of stage 2
          + 5 * m * BW                         // Q, V (two: look-ahead), Y, Z
          + nks * m * BW                       // Ypart
-         + 4 * nchunk * BW * BW               // Gram partials (G / G2 share, VtV, VtP, K)
+         + 5 * nchunk * BW * BW               // Gram partials (G, G2, VtV, VtP, K)
          + 8 * BW * BW + BW + 16;             // R1, R2, U, Vtop, Tinv, C, W2, spare | sgn | scalars
 }
 
@@ -1546,7 +1576,8 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
   const int64_t nchunk_max = (D + CHUNK - 1) / CHUNK, nks_max = (D + KSPLIT_COLS - 1) / KSPLIT_COLS;
   double *Ypart = Z + (int64_t)D * BW;
   double *Gp = Ypart + nks_max * D * BW;
-  double *VtVp = Gp + nchunk_max * BW * BW, *VtPp = VtVp + nchunk_max * BW * BW, *Kp = VtPp + nchunk_max * BW * BW;
+  double *Gp2 = Gp + nchunk_max * BW * BW;
+  double *VtVp = Gp2 + nchunk_max * BW * BW, *VtPp = VtVp + nchunk_max * BW * BW, *Kp = VtPp + nchunk_max * BW * BW;
   double *R1 = Kp + nchunk_max * BW * BW;
   double *R2 = R1 + BW * BW, *U = R2 + BW * BW, *Vtop = U + BW * BW, *Tinv = Vtop + BW * BW, *C = Tinv + BW * BW,
          *W2 = C + BW * BW;
@@ -1596,11 +1627,9 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     nks = ceil_div(g.m, krange);
     hipLaunchKernelGGL(panel_gram_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp);
     after("panel_gram_kernel", j0);
-    hipLaunchKernelGGL(panel_chol1_kernel, dim3(1), dim3(256), 0, st, Gp, g.nchunk, R1);
-    after("panel_chol1_kernel", j0);
-    hipLaunchKernelGGL(panel_q_kernel, dim3(g.nchunk), dim3(256), 0, st, g, R1, Q, Gp);
+    hipLaunchKernelGGL(panel_q_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp, Q, Gp2);
     after("panel_q_kernel", j0);
-    hipLaunchKernelGGL(panel_hr_kernel, dim3(1), dim3(256), 0, st, Gp, g.nchunk, Q, R2, U, Vtop, sgn);
+    hipLaunchKernelGGL(panel_hr_kernel, dim3(1), dim3(256), 0, st, Gp2, g.nchunk, Q, R2, U, Vtop, sgn);
     after("panel_hr_kernel", j0);
     hipLaunchKernelGGL(panel_v_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Q, R2, U, Vtop, sgn, V, VtVp, VtPp);
     after("panel_v_kernel", j0);
