@@ -48,6 +48,31 @@ class VPSDE(SDE):
         return mean, torch.sqrt(1. - torch.exp(2. * log_mean_coeff))
 
 
+class subVPSDE(VPSDE):
+    """sde_lib.py:276-304 of the reference: the VP mean with std = 1 - exp(2 log_mean_coeff); get_score_fn treats it as VP
+    (models/utils.py:238)."""
+
+    def marginal_prob(self, x, t):
+        log_mean_coeff = -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        mean = torch.exp(log_mean_coeff).reshape((-1,) + (1,) * (x.ndim - 1)) * x
+        return mean, 1 - torch.exp(2. * log_mean_coeff)
+
+
+class SNRSDE(SDE):
+    """sde_lib.py:153-187 of the reference (default gamma): configure_sde builds it, get_score_fn refuses it -- as there."""
+
+    def __init__(self, N, a=2, b=3, c=6, minus_log_SNR_0=-10, minus_log_SNR_1=5):
+        super().__init__(N)
+        gamma = lambda t: a * t + b * t ** c
+        k = (minus_log_SNR_1 - minus_log_SNR_0) / (gamma(1) - gamma(0))
+        self.log_SNR = lambda t: -(minus_log_SNR_0 + k * (gamma(t) - gamma(0)))
+
+    def marginal_prob(self, x, t):
+        snr = torch.exp(self.log_SNR(t))
+        alpha = torch.sqrt(snr / (1 + snr)).reshape((-1,) + (1,) * (x.ndim - 1))
+        return alpha * x, torch.sqrt(1 / (1 + snr))
+
+
 def configure_sde(config):
     """(sde, sampling_eps) exactly as BaseSdeGenerativeModel.configure_sde (lightning_modules/BaseSdeGenerativeModel.py:27-47)."""
     kind = config.training.sde.lower()
@@ -57,4 +82,8 @@ def configure_sde(config):
         return VESDE(sigma_min=config.model.sigma_min, sigma_max=config.model.sigma_max, N=config.model.num_scales), 1e-5
     if kind == "vpsde":
         return VPSDE(beta_min=config.model.beta_min, beta_max=config.model.beta_max, N=config.model.num_scales), 1e-3
+    if kind == "subvpsde":
+        return subVPSDE(beta_min=config.model.beta_min, beta_max=config.model.beta_max, N=config.model.num_scales), 1e-3
+    if kind == "snrsde":
+        return SNRSDE(N=config.model.num_scales), 1e-3
     raise NotImplementedError(f"SDE {config.training.sde} unknown.")

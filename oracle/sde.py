@@ -34,6 +34,32 @@ class VPSDE:
         return mean, torch.sqrt(1. - torch.exp(2. * log_coeff))
 
 
+class subVPSDE(VPSDE):
+    """sub-VP SDE, /root/reference/sde_lib.py:276-304: the VP mean, std = 1 - exp(2 log_mean_coeff) (no square root)."""
+
+    def marginal_prob(self, x, t):
+        log_coeff = -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        mean = torch.exp(log_coeff).reshape((-1,) + (1,) * (x.ndim - 1)) * x
+        return mean, 1 - torch.exp(2. * log_coeff)
+
+
+class SNRSDE:
+    """/root/reference/sde_lib.py:153-187 with the default gamma(t) = a t + b t^c (a, b, c = 2, 3, 6), normalised so that
+    -log SNR runs from -10 at t = 0 to 5 at t = 1: mean = sqrt(SNR / (1 + SNR)) x, std = sqrt(1 / (1 + SNR)).
+    configure_sde can build it; get_score_fn refuses it (models/utils.py:233 / 268), so it never reaches a score network."""
+
+    def __init__(self, N, a=2, b=3, c=6, minus_log_SNR_0=-10, minus_log_SNR_1=5):
+        self.N = N
+        gamma = lambda t: a * t + b * t ** c
+        k = (minus_log_SNR_1 - minus_log_SNR_0) / (gamma(1) - gamma(0))
+        self.log_SNR = lambda t: -(minus_log_SNR_0 + k * (gamma(t) - gamma(0)))
+
+    def marginal_prob(self, x, t):
+        snr = torch.exp(self.log_SNR(t))
+        alpha = torch.sqrt(snr / (1 + snr)).reshape((-1,) + (1,) * (x.ndim - 1))
+        return alpha * x, torch.sqrt(1 / (1 + snr))
+
+
 def make_sde(config):
     """(sde, sampling_eps) as /root/reference/lightning_modules/BaseSdeGenerativeModel.py:27-47."""
     kind = config.training.sde.lower()
@@ -41,6 +67,10 @@ def make_sde(config):
         return VESDE(config.model.sigma_min, config.model.sigma_max, config.model.num_scales), 1e-5
     if kind == "vpsde":
         return VPSDE(config.model.beta_min, config.model.beta_max, config.model.num_scales), 1e-3
+    if kind == "subvpsde":
+        return subVPSDE(config.model.beta_min, config.model.beta_max, config.model.num_scales), 1e-3
+    if kind == "snrsde":
+        return SNRSDE(config.model.num_scales), 1e-3
     raise NotImplementedError(f"SDE {config.training.sde} is not on the manifold_dimension path")
 
 
@@ -52,6 +82,8 @@ def get_score_fn(sde, model, conditional=False, train=False, continuous=True):
     """
     if conditional or not continuous:
         raise NotImplementedError("only the unconditional continuous branch is on the hot path")
+    if not isinstance(sde, (VESDE, VPSDE)):              # subVPSDE is a VPSDE here, as in the reference's isinstance test
+        raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
 
     def score_fn(x, t):
         model.eval()

@@ -182,6 +182,21 @@ def gen_fused_act():
     save("fused_act.npz", **out)
 
 
+def gen_sde_extra():
+    """The two other SDEs configure_sde can build (BaseSdeGenerativeModel.py:33-35, 44-46): subVPSDE takes the VP branch of
+    get_score_fn (models/utils.py:238-255); SNRSDE has a perturbation kernel but get_score_fn refuses it."""
+    t = torch.tensor([1e-5, 1e-3, 0.1, 0.3, 0.5, 1.0], dtype=torch.float32)
+    x = torch.arange(12, dtype=torch.float32).reshape(6, 2)
+    out = {"t": t.numpy(), "x": x.numpy()}
+    s = sde_lib.subVPSDE(beta_min=0.1, beta_max=20., N=1000)
+    mean, std = s.marginal_prob(x, t)
+    out["subvp::mean"], out["subvp::std"] = mean.numpy(), std.numpy()
+    s = sde_lib.SNRSDE(N=1000)
+    mean, std = s.marginal_prob(x, t)
+    out["snr::mean"], out["snr::std"] = mean.numpy(), std.numpy()
+    save("sde_extra.npz", **out)
+
+
 def gen_sde():
     t = torch.tensor([1e-5, 1e-3, 0.1, 0.3, 0.5, 1.0], dtype=torch.float32)
     x = torch.arange(12, dtype=torch.float32).reshape(6, 2)
@@ -642,9 +657,9 @@ def gen_conditional():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "fcn", "ncsnpp", "ksphere", "svd", "beatgans", "ddpm", "vp", "wide", "conditional"]
+    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "sde_extra", "fcn", "ncsnpp", "ksphere", "svd", "beatgans", "ddpm", "vp", "wide", "conditional"]
     table = {"upfirdn2d": gen_upfirdn2d, "fused_act": gen_fused_act, "sde": gen_sde, "fcn": gen_fcn,
-             "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule, "beatgans": gen_beatgans, "ddpm": gen_ddpm, "vp": gen_vp, "wide": gen_wide,
+             "sde_extra": gen_sde_extra, "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule, "beatgans": gen_beatgans, "ddpm": gen_ddpm, "vp": gen_vp, "wide": gen_wide,
              "conditional": gen_conditional}
     for w in which:
         table[w]()

@@ -422,6 +422,29 @@ def test_vp_score_fn_golden(golden):
     torch.testing.assert_close(out.cpu().reshape(ref.shape), ref, rtol=2e-6, atol=2e-6)
 
 
+def test_subvp_score_fn_vs_oracle(golden):
+    """config.training.sde = 'subvpsde' (BaseSdeGenerativeModel.py:33-35): the VP branch of get_score_fn with
+    std = 1 - exp(2 log_mean_coeff); the oracle's restatement is pinned by the reference's own marginal_prob
+    (tests/golden/sde_extra.npz), the network by the stored reference weights."""
+    z = golden("ncsnpp_vp.npz")
+    w = golden(str(z["weights_of"]))
+    cfg = ncsnpp_config(**overrides_from_golden(w))
+    cfg.training.sde = "subvpsde"
+    cfg.model.beta_min, cfg.model.beta_max = 0.1, 20.
+    model = mutils.create_model(cfg)
+    model.load_state_dict(state_dict_from_golden(w))
+    ref_model = omodels.create_model(cfg)
+    ref_model.load_state_dict(state_dict_from_golden(w))
+    sde, eps = sde_lib.configure_sde(cfg)
+    assert type(sde) is sde_lib.subVPSDE and eps == 1e-3
+    model.to(DEV)
+    x, t = torch.from_numpy(z["perturbed"]), torch.from_numpy(z["t"])
+    y = mutils.get_score_fn(sde, model)(x.to(DEV), t.to(DEV))
+    with torch.no_grad():
+        ref = osde.get_score_fn(osde.make_sde(cfg)[0], ref_model)(x, t)
+    assert rel_err(y.cpu(), ref) < NET_RTOL
+
+
 def test_vp_score_matrix_and_spectrum_vs_oracle(golden):
     """The whole per-point recipe under the VP SDE at its sampling_eps = 1e-3 (BaseSdeGenerativeModel.py:44-47): HIP
     score matrix against the oracle's on identical noise, spectrum at the 1e-4 bar, same integer ID."""

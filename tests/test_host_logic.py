@@ -53,6 +53,21 @@ def test_sde_matches_golden(golden):
     cfg = fcn_config()
     sde, eps = sde_lib.configure_sde(cfg)
     assert isinstance(sde, sde_lib.VESDE) and eps == 1e-5
+    # the two other SDEs configure_sde builds (BaseSdeGenerativeModel.py:33-35, 44-46), against reference outputs
+    e = golden("sde_extra.npz")
+    mean, std = sde_lib.subVPSDE(0.1, 20., 1000).marginal_prob(x, t)
+    assert torch.equal(mean, torch.from_numpy(e["subvp::mean"])) and torch.equal(std, torch.from_numpy(e["subvp::std"]))
+    mean, std = sde_lib.SNRSDE(1000).marginal_prob(x, t)
+    assert torch.equal(mean, torch.from_numpy(e["snr::mean"])) and torch.equal(std, torch.from_numpy(e["snr::std"]))
+    cfg.training.sde = "subvpsde"; cfg.model.beta_min, cfg.model.beta_max = 0.1, 20.
+    sde, eps = sde_lib.configure_sde(cfg)
+    assert type(sde) is sde_lib.subVPSDE and eps == 1e-3
+    cfg.training.sde = "snrsde"
+    sde, eps = sde_lib.configure_sde(cfg)
+    assert type(sde) is sde_lib.SNRSDE and eps == 1e-3
+    from id_diff_amd.models import utils as mutils
+    with pytest.raises(NotImplementedError, match="SNRSDE not yet supported"):      # models/utils.py:268 of the reference
+        mutils.get_score_fn(sde, None)
 
 
 def test_state_dict_keys_match_reference(golden):

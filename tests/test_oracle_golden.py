@@ -74,6 +74,18 @@ def test_sde_marginals(golden):
     assert torch.equal(std, torch.from_numpy(z["vp::std"]))
 
 
+def test_sde_marginals_of_the_two_other_sdes(golden):
+    """subVPSDE and SNRSDE (configure_sde can build both; only subVPSDE reaches a score network): reference outputs."""
+    z = golden("sde_extra.npz")
+    t, x = torch.from_numpy(z["t"]), torch.from_numpy(z["x"])
+    mean, std = osde.subVPSDE(0.1, 20., 1000).marginal_prob(x, t)
+    assert torch.equal(mean, torch.from_numpy(z["subvp::mean"])) and torch.equal(std, torch.from_numpy(z["subvp::std"]))
+    mean, std = osde.SNRSDE(1000).marginal_prob(x, t)
+    assert torch.equal(mean, torch.from_numpy(z["snr::mean"])) and torch.equal(std, torch.from_numpy(z["snr::std"]))
+    with pytest.raises(NotImplementedError, match="SNRSDE not yet supported"):
+        osde.get_score_fn(osde.SNRSDE(1000), None)
+
+
 def test_fcn_score_fn_tiny(golden):
     z = golden("fcn_tiny.npz")
     model = omodels.create_model(fcn_config(hidden_nodes=64))
