@@ -411,30 +411,47 @@ winograd_kernel(const WinoParams p) {
     bfr[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[j], slab, 0));
     bfr[j][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_src[j] + 32 * 32, slab, 0));
   };
-  auto compute = [&](int buf, int j0, int s, auto first) {
-    const float *S = lds + buf * STAGE_FLOATS;
-#pragma unroll
-    for (int j = j0; j < j0 + 2; ++j) {
-      const float4 a = *reinterpret_cast<const float4 *>(S + a_frag + 4 * j * V_SLOT);
-      const float4 b0 = bfr[j][0], b1 = bfr[j][1];
-      if constexpr (decltype(first)::value) {
-        const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, zero, 0, 0, 0);
-        acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, zero, 0, 0, 0);
-      } else {
-        acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[2 * j], 0, 0, 0);
-        acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[2 * j + 1], 0, 0, 0);
-      }
-      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[2 * j], 0, 0, 0);
-      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[2 * j + 1], 0, 0, 0);
-      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[2 * j], 0, 0, 0);
-      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[2 * j + 1], 0, 0, 0);
-      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[2 * j], 0, 0, 0);
-      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[2 * j + 1], 0, 0, 0);
-      // the registers are free once these MFMAs have read them; the last step re-requests its own slab (clamped, not
-      // skipped: no branch per position, and the scalar offset of a raw buffer is not range-checked, so it must stay valid)
-      load_b(j, min(s + 1, nsteps - 1));
+  // The four positions of a step one after the other, their V fragments through TWO registers sets in rotation: the fragment
+  // of position j + 2 is read from LDS right after the eight MFMAs of position j have been issued, so the eight MFMAs of
+  // position j + 1 (512 cycles) cover its latency.  (Before, the compiler interleaved positions 0 / 1 and then read the
+  // fragments of positions 2 and 3 each immediately in front of its use: two exposed LDS round trips per step.)
+  auto mfma8 = [&](int j, const float4 a, auto first) {
+    const float4 b0 = bfr[j][0], b1 = bfr[j][1];
+    if constexpr (decltype(first)::value) {
+      const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, zero, 0, 0, 0);
+      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, zero, 0, 0, 0);
+    } else {
+      acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[2 * j], 0, 0, 0);
+      acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[2 * j + 1], 0, 0, 0);
     }
+    acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[2 * j], 0, 0, 0);
+    acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[2 * j + 1], 0, 0, 0);
+    acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[2 * j], 0, 0, 0);
+    acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[2 * j + 1], 0, 0, 0);
+    acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[2 * j], 0, 0, 0);
+    acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[2 * j + 1], 0, 0, 0);
+  };
+  auto compute = [&](int buf, int s, auto first) {
+    const float *S = lds + buf * STAGE_FLOATS + a_frag;
+    const int snext = min(s + 1, nsteps - 1);
+    float4 f0 = *reinterpret_cast<const float4 *>(S), f1 = *reinterpret_cast<const float4 *>(S + 4 * V_SLOT);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0, f0, first);
+    // the registers are free once these MFMAs have read them; the last step re-requests its own slab (clamped, not
+    // skipped: no branch per position, and the scalar offset of a raw buffer is not range-checked, so it must stay valid)
+    load_b(0, snext);
+    f0 = *reinterpret_cast<const float4 *>(S + 8 * V_SLOT);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1, f1, first);
+    load_b(1, snext);
+    f1 = *reinterpret_cast<const float4 *>(S + 12 * V_SLOT);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(2, f0, first);
+    load_b(2, snext);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(3, f1, first);
+    load_b(3, snext);
   };
   // The role is a compile-time constant of the loop a wave runs, and writing the next stage / requesting the one after are
   // unconditional (the last two steps re-request the last stage and write a stage nobody reads): the compiler's wait counts
@@ -444,9 +461,7 @@ winograd_kernel(const WinoParams p) {
   auto step = [&](int s, auto first, auto is_early) {
     const int buf = s & 1;
     if constexpr (decltype(is_early)::value) { stage(buf ^ 1); fetch(); }
-    compute(buf, 0, s, first);
-    __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of the two halves from being hoisted together
-    compute(buf, 2, s, first);
+    compute(buf, s, first);
     if constexpr (!decltype(is_early)::value) { stage(buf ^ 1); fetch(); }
     __syncthreads();
   };
