@@ -432,7 +432,7 @@ winograd_kernel(const WinoParams p) {
     acc[2 * j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[2 * j], 0, 0, 0);
     acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[2 * j + 1], 0, 0, 0);
   };
-  auto compute = [&](int buf, int s, auto first) {
+  auto compute = [&](int buf, int s, auto first, auto before_last) {
     const float *S = lds + buf * STAGE_FLOATS + a_frag;
     const int snext = min(s + 1, nsteps - 1);
     float4 f0 = *reinterpret_cast<const float4 *>(S), f1 = *reinterpret_cast<const float4 *>(S + 4 * V_SLOT);
@@ -450,6 +450,8 @@ winograd_kernel(const WinoParams p) {
     mfma8(2, f0, first);
     load_b(2, snext);
     __builtin_amdgcn_sched_barrier(0);
+    before_last();                      // the late role writes its stage HERE: its LDS writes then land under eight MFMAs
+    __builtin_amdgcn_sched_barrier(0);  // instead of in front of the barrier
     mfma8(3, f1, first);
     load_b(3, snext);
   };
@@ -460,9 +462,12 @@ winograd_kernel(const WinoParams p) {
   // (issued at the end of the previous one) before starting the work that is meant to cover them.
   auto step = [&](int s, auto first, auto is_early) {
     const int buf = s & 1;
-    if constexpr (decltype(is_early)::value) { stage(buf ^ 1); fetch(); }
-    compute(buf, s, first);
-    if constexpr (!decltype(is_early)::value) { stage(buf ^ 1); fetch(); }
+    if constexpr (decltype(is_early)::value) {
+      stage(buf ^ 1); fetch();
+      compute(buf, s, first, [] {});
+    } else {
+      compute(buf, s, first, [&] { stage(buf ^ 1); fetch(); });
+    }
     __syncthreads();
   };
 
