@@ -55,6 +55,13 @@ def test_gather_two_ranks_ragged_and_idle_rank():
     _run(2, 1)   # rank 1 owns nothing but still joins the collective
 
 
+def test_gather_eight_ranks_like_the_scaling_run():
+    """The driver's scaling run is 1 / 2 / 4 / 8 ranks of one node; no 8-GPU box exists in the build loop, so the 8-rank
+    exchange (round-robin ownership, ragged tail, idle ranks, IDs riding in the same collective) is rehearsed on gloo."""
+    _run(8, 19)  # ranks 0-2 own three points, ranks 3-7 two
+    _run(8, 5)   # ranks 5-7 own nothing
+
+
 # ---- row-sharded single point (SURVEY 8(f) rank 2): the two all-reduces, with plain-torch stand-ins for the HIP stages
 def _torch_ops():
     col_sums = lambda S: S.double().sum(0)
@@ -131,6 +138,26 @@ def _bench_worker(rank, world, port, q):
 
     line = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--device", "cpu"], workload_factory=FakeWork)
     q.put((rank, line))
+
+
+def test_bench_main_eight_ranks_gloo():
+    """bench.main at the world size of the driver's largest scaling leg (CPU / gloo, stand-in workload): max-over-ranks
+    timing, one JSON line from rank 0, value = 8 ranks x steps x rows / time, every rank's IDs in the line."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(8))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(got[r] is None for r in range(1, 8))
+    line = got[0]
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["process_group"] == "gloo"
+    assert line["value"] == pytest.approx(8 * 3 * 12 / (line["ms_per_step"] * 3e-3), rel=1e-6)
+    assert line["id_estimates_all_ranks"] == [2] * 24
 
 
 def test_bench_main_two_ranks_gloo(capfd):
