@@ -500,6 +500,10 @@ def main(argv=None, workload_factory=Workload):
     dev = torch.device(args.device) if args.device else torch.device(f"cuda:{local_rank}")
     if dev.type == "cuda":
         torch.cuda.set_device(dev)
+        # one process per GPU: every rank launches from its own host thread; the few CPU-side tensor ops (ID rule, pinned
+        # flags) must not fan out over every core of the node in each of N processes
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(16, ncores // max(1, world))))
 
     work = workload_factory(args, rank, dev)
     with torch.no_grad():
