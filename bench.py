@@ -431,7 +431,8 @@ class Workload:
         self.images = smooth_decoder_images(args.steps + args.warmup, [3, 32, 32], 64, seed=100 + rank).to(dev)
         _, _, self.rows = dim_reduction.batching((3, 32, 32), self.B)
         self.D = 3 * 32 * 32
-        self.builder = dim_reduction.ScoreMatrixBuilder(score_fn, sde, eps, dev, inflight_rows=args.inflight)
+        self.builder = dim_reduction.ScoreMatrixBuilder(score_fn, sde, eps, dev, inflight_rows=args.inflight,
+                                                        concurrent_sets=getattr(args, "concurrent_sets", 1))
         self.rank = rank
         self.pipe = dim_reduction.SpectrumPipeline(dev, overlap=not args.no_overlap)
         self.last_S = None
@@ -490,6 +491,8 @@ def main(argv=None, workload_factory=Workload):
     ap.add_argument("--no-overlap", action="store_true", help="run each point's spectrum on the main stream")
     ap.add_argument("--no-probe", action="store_true", help="skip the instrumented second pass (roofline = null)")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-2 / config-5 side measurements (extra = null)")
+    ap.add_argument("--concurrent-sets", type=int, default=1,
+                    help="launch sets of a point on this many worker streams (2: -1.8 %% per point; per-kernel events then overlap)")
     ap.add_argument("--device", default=None, help="(tests) 'cpu' with a stand-in workload")
     args = ap.parse_args(argv)
 
@@ -538,7 +541,7 @@ def main(argv=None, workload_factory=Workload):
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": WORKLOAD, "rows_per_point": rows, "cols": D, "batch_size": getattr(work, "B", None),
-                       "inflight_rows": args.inflight, "points_per_gpu": args.steps,
+                       "inflight_rows": args.inflight, "concurrent_sets": getattr(args, "concurrent_sets", 1), "points_per_gpu": args.steps,
                        "parallelism": f"points sharded over {world} rank(s), one all-gather of spectra",
                        "process_group": dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None},
             "id_estimates": ids, "id_estimates_all_ranks": alldims.tolist(),

@@ -422,6 +422,25 @@ def test_vp_score_fn_golden(golden):
     torch.testing.assert_close(out.cpu().reshape(ref.shape), ref, rtol=2e-6, atol=2e-6)
 
 
+def test_concurrent_launch_sets_give_the_same_score_matrix(golden):
+    """ScoreMatrixBuilder(concurrent_sets=2) (opt-in): the launch sets of a point on two worker streams -- same kernels on
+    the same inputs, so S is the sequential S bit for bit (in-kernel noise keyed by the row, explicit noise by index)."""
+    cfg = ncsnpp_config(init_scale=1.)               # init_scale = 0 would zero the output conv: a score matrix of zeros
+    cfg.model.allow_random_init = True
+    torch.manual_seed(3)
+    model = mutils.create_model(cfg).to(DEV)
+    sde, eps = sde_lib.configure_sde(cfg)
+    score_fn = mutils.get_score_fn(sde, model)
+    x = torch.rand(cfg.data.num_channels, cfg.data.image_size, cfg.data.image_size, device=DEV)
+    seq = dim_reduction.ScoreMatrixBuilder(score_fn, sde, eps, torch.device(DEV), inflight_rows=48, concurrent_sets=1)
+    con = dim_reduction.ScoreMatrixBuilder(score_fn, sde, eps, torch.device(DEV), inflight_rows=48, concurrent_sets=2)
+    ref = seq.build(x, 32, seed=11)
+    con.build(x, 32, seed=5)                        # the first point of a builder warms the lazily made banks on one stream
+    assert con._warmed and torch.equal(con.build(x, 32, seed=11), ref) and con._workers is not None
+    noise = torch.randn(ref.shape, device=DEV)
+    assert torch.equal(con.build(x, 32, noise=noise), seq.build(x, 32, noise=noise))
+
+
 def test_subvp_score_fn_vs_oracle(golden):
     """config.training.sde = 'subvpsde' (BaseSdeGenerativeModel.py:33-35): the VP branch of get_score_fn with
     std = 1 - exp(2 log_mean_coeff); the oracle's restatement is pinned by the reference's own marginal_prob
