@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) panel_hr_kernel(const double *__restrict_
   __shared__ double bc[2][BW];
   const int tid = threadIdx.x;
   reduce_partials(Gpart2, nchunk, M, true);
-  if (tid < 64) cholesky_upper(M, dsc, bc);
+  if (tid < 64) cholesky_upper2(M, dsc, bc);
   __syncthreads();
   for (int e = tid; e < BW * BW; e += blockDim.x) R2out[e] = M[e / BW][e % BW];
   // Q1_top rows
