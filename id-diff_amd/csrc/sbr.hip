@@ -153,45 +153,13 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
 
 // Upper Cholesky factor R (G = R^T R) of the Jacobi-scaled symmetric matrix M (LDS, pitch BW + 1), pivots clamped: a
 // column whose pivot is not positive keeps R[j][j] = 1 and a zero row (its Q column comes out ~0; the T factor built from
-// the stored V keeps the block reflector orthogonal whatever happens here).  One wave: lane i < BW keeps ROW i of the
-// working matrix in registers (the matrix is symmetric, so a[j] is also the lane's element of column j); per step one
-// LDS word per lane broadcasts column j, everything else is register arithmetic.  On exit M holds R (upper, scaling
-// folded back in), zeros below.
-__device__ __forceinline__ void cholesky_upper(double (*M)[BW + 1], double *dsc /* [BW] */, double (*bc)[BW] /* [2][BW] */) {
-  // executed by wave 0 only (the other waves of the workgroup wait at the caller's barrier)
-  const int tid = threadIdx.x, i = tid < BW ? tid : 0;
-  const double dii = M[i][i];
-  const double rdi = dii > 0.0 ? fast_rsqrt(dii) : 1.0;          // 1 / d_i
-  if (tid < BW) dsc[tid] = rdi;
-  wave_lds_sync();
-  double a[BW];                   // row i of the working matrix; a[j] turns into R[j][i] once step j is done
-#pragma unroll
-  for (int k = 0; k < BW; ++k) a[k] = M[i][k] * (rdi * dsc[k]);
-#pragma unroll
-  for (int j = 0; j < BW; ++j) {
-    double (*buf) = bc[j & 1];
-    if (tid < BW) buf[tid] = a[j];
-    wave_lds_sync();
-    const double piv = buf[j];
-    const bool ok = piv > 1e-30;
-    const double rinv = ok ? fast_rsqrt(piv) : 0.0;
-    const double rji = a[j] * rinv;                    // R[j][i], this lane's multiplier
-    a[j] = i == j ? (ok ? piv * rinv : 1.0) : (i > j ? rji : 0.0);
-#pragma unroll
-    for (int k = j + 1; k < BW; ++k) a[k] -= rji * (buf[k] * rinv);
-  }
-  const double di = dii > 0.0 ? dii * rdi : 1.0;                  // d_i = sqrt(G_ii)
-  if (tid < BW) {
-#pragma unroll
-    for (int j = 0; j < BW; ++j) M[j][i] = a[j] * di;    // R[j][i] (zero for j > i), column scaling folded back
-  }
-  wave_lds_sync();
-}
-
-// The same factorisation with TWO lanes per row: lane (i, h) = (tid & 31, tid >> 5) keeps columns 16 h .. 16 h + 15 of row i.
-// 89 registers and no scratch where the one-lane form needs more than 512 and spills (fine in the one-workgroup kernels
-// that use it, not in a multi-workgroup one: DESIGN.md 7.1); every element sees the same operations in the same order, so
-// the same bits.  Used where every workgroup of a row kernel redoes the factorisation (panel_q_kernel).
+// the stored V keeps the block reflector orthogonal whatever happens here).  One wave, TWO lanes per row: lane (i, h) =
+// (tid & 31, tid >> 5) keeps columns 16 h .. 16 h + 15 of row i of the working matrix in registers (the matrix is
+// symmetric, so a[j] is also the lane's element of column j); per step one LDS word per row broadcasts column j.  89
+// registers and no scratch -- the first form, one lane per row with all 32 columns, needed more than 512 registers fully
+// unrolled and spilled 176 of them; every element sees the same operations in the same order as there.
+// Every workgroup of panel_q_kernel / panel_v_kernel redoes the factorisation it needs.  On exit M holds R (upper,
+// scaling folded back in), zeros below.
 __device__ __forceinline__ void cholesky_upper2(double (*M)[BW + 1], double *dsc /* [BW] */, double (*bc)[BW] /* [2][BW] */) {
   static_assert(BW == 32, "lane = (row, column half)");
   const int tid = threadIdx.x, i = tid & 31, h = (tid >> 5) & 1;
@@ -301,75 +269,62 @@ __global__ void __launch_bounds__(256) panel_q_kernel(PanelGeom g, const double 
   store_tile_partial(Gpart2 + (int64_t)chunk * BW * BW, i0, j0, acc);
 }
 
-// k4: R2 = chol(sum Gpart2); Q1_top = Q_top R2^-1; S' = -sign(diag Q1_top); LU (no pivoting) of I - Q1_top S' = V_top U'.
-// Outputs (all BW x BW): R2, U' (upper), Vtop (unit lower), sgn[BW] = S'.
-__global__ void __launch_bounds__(256) panel_hr_kernel(const double *__restrict__ Gpart2, int nchunk, const double *__restrict__ Q,
-                                                      double *__restrict__ R2out, double *__restrict__ Uout,
-                                                      double *__restrict__ Vtop, double *__restrict__ sgn) {
-  __shared__ double M[BW][BW + 1];
-  __shared__ double Bm[BW][BW + 1];
-  __shared__ double dsc[BW];
+// k4 + k5: the Householder reconstruction redone by EVERY workgroup in its own LDS, then the V rows.
+//   R2 = chol(sum Gpart2); Q1_top = Q_top R2^-1; S' = -sign(diag Q1_top); LU (no pivoting) of I - Q1_top S' = V_top U'
+//   (Ballard et al., "Reconstructing Householder vectors from TSQR": diagonal entries start at 1 + |q_ii| >= 1, the
+//   multipliers stay bounded by 1 for an orthonormal Q1); rows < BW of V are V_top (unit lower), rows >= BW:
+//   v = ((q R2^-1) * (-S')) U'^-1; then the partials of V^T V and V^T P.  Chunk 0 stores V_top for the R write-back of
+//   trailing_tz_kernel.  One launch instead of a one-workgroup launch followed by the row kernel: 7 launches per panel.
+//   (Possible since the two-lane Cholesky: with it neither factorisation spills, 126 registers in the one-workgroup form.)
+__global__ void __launch_bounds__(256) panel_v_kernel(PanelGeom g, const double *__restrict__ Gpart2, const double *__restrict__ Q,
+                                                      double *__restrict__ Vtop, double *__restrict__ V,
+                                                      double *__restrict__ VtVpart, double *__restrict__ VtPpart) {
+  __shared__ double Ra[BW][BW + 1];       // R2
+  __shared__ double Ub[BW][BW + 1];       // U' on and above the diagonal, the multipliers of V_top below it
+  __shared__ double sg[BW];               // S'
   __shared__ double bc[2][BW];
-  const int tid = threadIdx.x;
-  reduce_partials(Gpart2, nchunk, M, true);
-  if (tid < 64) cholesky_upper2(M, dsc, bc);
+  const int chunk = blockIdx.x, tid = threadIdx.x;
+  reduce_partials(Gpart2, g.nchunk, Ra, true);
+  if (tid < 64) cholesky_upper2(Ra, sg, bc);          // sg doubles as the factorisation's scaling scratch here
   __syncthreads();
-  for (int e = tid; e < BW * BW; e += blockDim.x) R2out[e] = M[e / BW][e % BW];
-  // Q1_top rows
-  if (tid < BW) {
+  if (tid < BW) {                                     // Q1_top rows
     double x[BW];
 #pragma unroll
     for (int j = 0; j < BW; ++j) x[j] = Q[(int64_t)tid * BW + j];
-    row_solve_upper(x, M);
+    row_solve_upper(x, Ra);
 #pragma unroll
-    for (int j = 0; j < BW; ++j) Bm[tid][j] = x[j];
+    for (int j = 0; j < BW; ++j) Ub[tid][j] = x[j];
   }
   __syncthreads();
-  if (tid < BW) dsc[tid] = Bm[tid][tid] >= 0.0 ? -1.0 : 1.0;      // S'
+  if (tid < BW) sg[tid] = Ub[tid][tid] >= 0.0 ? -1.0 : 1.0;      // S'
   __syncthreads();
-  for (int e = tid; e < BW * BW; e += blockDim.x) {
+  for (int e = tid; e < BW * BW; e += 256) {
     const int i = e / BW, j = e % BW;
-    Bm[i][j] = (i == j ? 1.0 : 0.0) - Bm[i][j] * dsc[j];
+    Ub[i][j] = (i == j ? 1.0 : 0.0) - Ub[i][j] * sg[j];
   }
   __syncthreads();
-  // LU without pivoting (diagonal entries start at 1 + |q_ii| >= 1; Ballard et al., "Reconstructing Householder vectors
-  // from TSQR": the multipliers stay bounded by 1 for an orthonormal Q1)
-  if (tid < 64) lu_nopivot(Bm, bc);
+  if (tid < 64) lu_nopivot(Ub, bc);
   __syncthreads();
-  for (int e = tid; e < BW * BW; e += blockDim.x) {
-    const int i = e / BW, j = e % BW;
-    Uout[e] = i <= j ? Bm[i][j] : 0.0;
-    Vtop[e] = i > j ? Bm[i][j] : (i == j ? 1.0 : 0.0);
+  if (chunk == 0) {
+    for (int e = tid; e < BW * BW; e += 256) {
+      const int i = e / BW, j = e % BW;
+      Vtop[e] = i > j ? Ub[i][j] : (i == j ? 1.0 : 0.0);
+    }
   }
-  if (tid < BW) sgn[tid] = dsc[tid];
-}
-
-// k5: V rows.  Rows < BW come from Vtop; rows >= BW: v = ((q R2^-1) * (-S')) U'^-1.  Then partials of V^T V and V^T P.
-__global__ void __launch_bounds__(256) panel_v_kernel(PanelGeom g, const double *__restrict__ Q, const double *__restrict__ R2,
-                                                      const double *__restrict__ U, const double *__restrict__ Vtop,
-                                                      const double *__restrict__ sgn, double *__restrict__ V,
-                                                      double *__restrict__ VtVpart, double *__restrict__ VtPpart) {
-  __shared__ double Ra[BW][BW + 1];
-  __shared__ double Ub[BW][BW + 1];
-  __shared__ double sg[BW];
-  const int chunk = blockIdx.x, tid = threadIdx.x;
-  for (int e = tid; e < BW * BW; e += 256) { Ra[e / BW][e % BW] = R2[e]; Ub[e / BW][e % BW] = U[e]; }
-  if (tid < BW) sg[tid] = sgn[tid];
-  __syncthreads();
   const int r0 = chunk * g.chunk_rows, r1 = min(g.m, r0 + g.chunk_rows);
   const int row = r0 + tid;
   if (row < r1) {
     double x[BW];
     if (row < BW) {
 #pragma unroll
-      for (int j = 0; j < BW; ++j) x[j] = Vtop[row * BW + j];
+      for (int j = 0; j < BW; ++j) x[j] = j < row ? Ub[row][j] : (j == row ? 1.0 : 0.0);
     } else {
 #pragma unroll
       for (int j = 0; j < BW; ++j) x[j] = Q[(int64_t)row * BW + j];
       row_solve_upper(x, Ra);
 #pragma unroll
       for (int j = 0; j < BW; ++j) x[j] *= -sg[j];
-      row_solve_upper(x, Ub);
+      row_solve_upper(x, Ub);                         // reads U' only: the diagonal and what is above it
     }
     double *v = V + (int64_t)row * BW;
 #pragma unroll
@@ -1629,9 +1584,7 @@ int sbr_to_band(double *G, int D, double *scratch, hipStream_t st) {
     after("panel_gram_kernel", j0);
     hipLaunchKernelGGL(panel_q_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp, Q, Gp2);
     after("panel_q_kernel", j0);
-    hipLaunchKernelGGL(panel_hr_kernel, dim3(1), dim3(256), 0, st, Gp2, g.nchunk, Q, R2, U, Vtop, sgn);
-    after("panel_hr_kernel", j0);
-    hipLaunchKernelGGL(panel_v_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Q, R2, U, Vtop, sgn, V, VtVp, VtPp);
+    hipLaunchKernelGGL(panel_v_kernel, dim3(g.nchunk), dim3(256), 0, st, g, Gp2, Q, Vtop, V, VtVp, VtPp);
     after("panel_v_kernel", j0);
     const int off = g.lo & 63;                           // the trailing block starts `off` into its first tile of the absolute grid
     if (join_pending) {                                  // the rest of the previous update
