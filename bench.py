@@ -445,6 +445,24 @@ class Workload:
         return torch.stack(self.pipe.results())
 
 
+class HostRehearsal:
+    """`--device cpu`: NOT a measurement.  A stand-in with no GPU work (12 'rows' per point, a fixed 5-value spectrum that encodes
+    rank and point) so that the launch / process-group / barrier / exchange / JSON logic of this file can be run as plain
+    processes on a box without GPUs (tests/test_parallel_gloo.py); the line says so in `data` and `config.workload`."""
+    rows, D, B = 12, 5, 4
+    data = "none: host rehearsal of the launch and exchange logic, no GPU work"
+
+    def __init__(self, args, rank, dev):
+        self.rank, self.out, self.cfg, self.last_S = rank, [], None, None
+
+    def point(self, i):
+        self.out.append(torch.tensor([50., 40., 30., 2., 1.]) + 0.01 * i + 0.001 * self.rank)
+
+    def collect(self):
+        out, self.out = torch.stack(self.out), []
+        return out
+
+
 def timed_region(work, warmup, steps, dev):
     """W untimed points, then EXACTLY `steps` points between barrier + synchronize on both sides; the region includes the
     path's one exchange step.  Returns (max-over-ranks seconds, spectra and int32 IDs of ALL ranks' points in point order)."""
@@ -496,10 +514,23 @@ def main(argv=None, workload_factory=Workload):
     ap.add_argument("--device", default=None, help="(tests) 'cpu' with a stand-in workload")
     args = ap.parse_args(argv)
 
+    if args.gpus > 1 and not parallel.launched():
+        # a plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (importing torch
+        # does not; device_count only enumerates) and never will -- it starts N fresh rank processes of this file, relays
+        # rank 0's one JSON line and exits with the first non-zero code of any rank.
+        if workload_factory is not Workload:
+            raise RuntimeError("bench.main(--gpus N > 1) without RANK / WORLD_SIZE starts rank PROCESSES of bench.py; a "
+                               "stand-in workload_factory cannot travel to them -- set the launcher environment instead")
+        rc = parallel.launch_local_ranks(os.path.abspath(__file__), list(sys.argv[1:] if argv is None else argv), args.gpus,
+                                         need_devices=args.device != "cpu")
+        if rc:
+            raise SystemExit(rc)
+        return None
+
     # under a launcher this initialises RCCL (also at world size 1) BEFORE anything else touches the GPU
+    if parallel.launched():
+        parallel.check_world(args.gpus, int(os.environ["WORLD_SIZE"]), need_devices=args.device != "cpu")
     rank, world, local_rank = parallel.init_from_env(backend="gloo" if args.device == "cpu" else None)
-    if world != args.gpus and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     dev = torch.device(args.device) if args.device else torch.device(f"cuda:{local_rank}")
     if dev.type == "cuda":
         torch.cuda.set_device(dev)
@@ -507,6 +538,9 @@ def main(argv=None, workload_factory=Workload):
         # flags) must not fan out over every core of the node in each of N processes
         ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         torch.set_num_threads(max(1, min(16, ncores // max(1, world))))
+    elif workload_factory is Workload:
+        workload_factory = HostRehearsal
+    devices = parallel.rank_devices(dev)
 
     work = workload_factory(args, rank, dev)
     with torch.no_grad():
@@ -539,18 +573,21 @@ def main(argv=None, workload_factory=Workload):
             "metric": "score-vector evals/sec (rows of S per second incl. the per-point spectrum), 32x32 ncsnpp",
             "value": world * args.steps * rows / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-            "config": {"workload": WORKLOAD, "rows_per_point": rows, "cols": D, "batch_size": getattr(work, "B", None),
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE if dev.type == "cuda" else "none (host rehearsal)", "data": getattr(work, "data", "synthetic"),
+            "config": {"workload": WORKLOAD if dev.type == "cuda" else HostRehearsal.data, "rows_per_point": rows, "cols": D, "batch_size": getattr(work, "B", None),
                        "inflight_rows": args.inflight, "concurrent_sets": getattr(args, "concurrent_sets", 1), "points_per_gpu": args.steps,
                        "parallelism": f"points sharded over {world} rank(s), one all-gather of spectra",
-                       "process_group": dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None},
+                       "process_group": dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None,
+                       "world_size": world, "rank_devices": devices,
+                       "launched_by": ("bench.py (self-launched rank processes)" if os.environ.get("IDIFF_SELF_LAUNCHED")
+                                       else "external launcher" if parallel.launched() else "single process")},
             "id_estimates": ids, "id_estimates_all_ranks": alldims.tolist(),
             # SURVEY 8(d)'s 21.79 GFLOP/eval counts the 3x3 convs as direct convolutions; the Winograd kernels EXECUTE 2.25x
             # fewer multiply-adds on them (10.87 GFLOP/eval), which is why the first figure can exceed the fp32 MFMA peak
-            "model_tflops_per_gpu_direct_conv_equivalent": rows * args.steps * 21.79e9 / elapsed / 1e12,
-            "model_tflops_per_gpu_executed": rows * args.steps * 10.87e9 / elapsed / 1e12,
         }
         if dev.type == "cuda":
+            line["model_tflops_per_gpu_direct_conv_equivalent"] = rows * args.steps * 21.79e9 / elapsed / 1e12
+            line["model_tflops_per_gpu_executed"] = rows * args.steps * 10.87e9 / elapsed / 1e12
             line["svd_wall_clock_ms_per_point"] = svd_ms
             line["roofline"] = roofline
             if world == 1 and not args.no_extras:

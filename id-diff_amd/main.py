@@ -30,6 +30,10 @@ def parse(argv=None):
     ap.add_argument("--eval_folder", default="eval")
     ap.add_argument("--debug", action="store_true")
     ap.add_argument("--log_name", default=None)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="(not in the reference) shard the data points over this many GPUs of the node: without a launcher "
+                         "this process starts one fresh rank process per GPU itself; under torch.distributed.run it must "
+                         "equal WORLD_SIZE")
     ap.add_argument("--allow_random_init", action="store_true",
                     help="run on freshly initialised weights when no checkpoint is given (timing / plumbing only)")
     return ap.parse_args(argv)
@@ -50,6 +54,16 @@ def main(argv=None):
     if flags.mode not in _HOT_MODES:
         raise SystemExit(f"mode {flags.mode!r} is outside the scope of id-diff_amd (the MI355X build covers "
                          f"{', '.join(_HOT_MODES)}); use the reference for training / sampling / evaluation")
+    if flags.gpus is not None:
+        if flags.gpus > 1 and not parallel.launched():
+            # become the launcher: nothing in this process has touched the GPU; fresh rank processes, never an exec
+            rc = parallel.launch_local_ranks(os.path.abspath(__file__), list(sys.argv[1:] if argv is None else argv), flags.gpus,
+                                             need_devices=not str(getattr(config, "device", "cuda")).startswith("cpu"))
+            if rc:
+                raise SystemExit(rc)
+            return
+        if parallel.launched():
+            parallel.check_world(flags.gpus, int(os.environ["WORLD_SIZE"]))
     rank, world, local_rank = parallel.init_from_env()
     if world > 1:
         config.device = f"cuda:{local_rank}"

@@ -12,6 +12,10 @@ centred Gram ([D, D]: 75 MB at D = 3072, 1.2 GB at D = 12288, bandwidth-bound on
 ``dim_reduction.row_sharded_spectrum``.
 """
 import os
+import socket
+import subprocess
+import sys
+import threading
 
 import torch
 import torch.distributed as dist
@@ -41,6 +45,102 @@ def init_from_env(backend=None):
             kwargs["device_id"] = torch.device("cuda", local_rank)    # eager communicator on THIS device
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
+
+
+def launched():
+    """True when a launcher (torch.distributed.run, or ``launch_local_ranks`` below) set this process's rank."""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def visible_devices():
+    """Device ordinals this process can open, WITHOUT initialising the GPU (``device_count`` only enumerates on this image;
+    ``is_available`` / any other ``torch.cuda`` call would make the process unfit to start rank processes)."""
+    return torch.cuda.device_count()
+
+
+def check_world(requested, world, need_devices=True):
+    """A world that is not the one asked for is an error, never a warning: a scaling run whose ``--gpus 8`` leg silently ran
+    one rank would report a one-GPU number under an eight-GPU label."""
+    if world != requested:
+        raise SystemExit(f"error: --gpus {requested} but the launcher started WORLD_SIZE {world} rank(s)")
+    if need_devices and visible_devices() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        raise SystemExit(f"error: {world} devices needed, {visible_devices()} visible")
+
+
+def launch_local_ranks(script, argv, n, need_devices=True, timeout=None):
+    """Start ``n`` fresh rank processes of ``script`` on this node (one per GPU) and relay rank 0's stdout.
+
+    Called by a parent that has NOT touched the GPU (no HIP call, no ``torch.cuda.is_available()``): the children are new
+    interpreters (``subprocess.Popen`` -- never ``os.exec*``, never a fork of an initialised process) with RANK / LOCAL_RANK /
+    WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, i.e. exactly what ``torch.distributed.run`` would have
+    set, so the child takes the launcher path of ``init_from_env``.  Rank 0's stdout is passed through line by line (the one
+    JSON line of bench.py), the other ranks' stdout goes to stderr with a rank prefix.  Returns the first non-zero exit code
+    (the remaining ranks are terminated then), else 0."""
+    if n < 1:
+        raise SystemExit(f"error: --gpus {n}")
+    if need_devices and visible_devices() < n:
+        raise SystemExit(f"error: {n} devices needed, {visible_devices()} visible")
+    with socket.socket() as s:                       # a free rendezvous port on the loop-back interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IDIFF_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, script, *argv], env=env, stdout=subprocess.PIPE, text=True))
+
+    def relay(r, pipe):
+        for ln in pipe:
+            if r == 0:
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(f"[rank {r}] {ln}")
+        pipe.close()
+
+    threads = [threading.Thread(target=relay, args=(r, p.stdout), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    rc, pending = 0, set(range(n))
+    import time
+    t_end = None if timeout is None else time.monotonic() + timeout
+    while pending and rc == 0:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    rc = code
+                    print(f"error: rank {r} exited with code {code}", file=sys.stderr)
+                    break
+        if t_end is not None and time.monotonic() > t_end:
+            rc = 124
+            print(f"error: ranks {sorted(pending)} still running after {timeout} s", file=sys.stderr)
+        if pending and rc == 0:
+            time.sleep(0.05)
+    for r in pending:                                  # a rank died: its peers would wait in a collective for ever
+        if procs[r].poll() is None:
+            procs[r].terminate()
+    for r in pending:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()                            # the exact PID this function started, nothing else
+            procs[r].wait()
+    for t in threads:
+        t.join(timeout=5)
+    return rc
+
+
+def rank_devices(device):
+    """``[(rank, "cuda:3"), ...]`` of every rank (all-gathered), so the bench line shows which ordinal each rank drove."""
+    me = str(device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [me]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, me)
+    return out
 
 
 def rank_world():

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import id_diff_amd
-from helpers import (ncsnpp_config, overrides_from_golden, rel_err, state_dict_from_golden, write_lightning_artifacts)
+from helpers import (ROOT, ncsnpp_config, overrides_from_golden, rel_err, state_dict_from_golden, write_lightning_artifacts)
 from id_diff_amd import _lib, dim_reduction, plot_utils, sde_lib
 from id_diff_amd.configs.config_dict import ConfigDict
 from id_diff_amd.configs.utils import read_config
@@ -396,3 +396,16 @@ def test_row_sharded_spectrum_and_exchange_on_one_rank_rccl():
     p.join(timeout=120)
     assert p.exitcode == 0
     assert backend == "nccl" and err < 1e-4 and same and dims == [20]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_beyond_the_visible_devices_is_an_error_not_a_one_rank_line():
+    """On the one-GPU box `python bench.py --gpus 2` (no launcher) must fail with '2 devices needed, 1 visible' -- in round 3
+    it ran ONE rank and printed n_gpus 1."""
+    import subprocess
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and f"{n + 1} devices needed, {n} visible" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -184,3 +184,60 @@ def test_bench_main_two_ranks_gloo(capfd):
     assert line["id_estimates_all_ranks"] == [2] * 6  # every rank's IDs, computed where the spectrum lives, one collective
     printed = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
     assert len(printed) == 1 and json.loads(printed[0])["metric"] == line["metric"]
+
+
+# ---- `python bench.py --gpus N` as a PLAIN process: the file is its own launcher (no torch.distributed.run around it)
+def _plain(args, env_extra=None, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, cwd=ROOT, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_plain_process_starts_its_own_two_ranks():
+    """No launcher, no RANK in the environment: `python bench.py --gpus 2 --device cpu` must start two rank processes itself
+    and print ONE line with n_gpus 2 (round 3 printed n_gpus 1 from a single rank without an error)."""
+    import json
+    r = _plain(["--gpus", "2", "--device", "cpu", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["process_group"] == "gloo"
+    assert line["config"]["rank_devices"] == ["cpu", "cpu"] and "self-launched" in line["config"]["launched_by"]
+    assert line["id_estimates_all_ranks"] == [2] * 6 and "rehearsal" in line["data"]
+    assert line["value"] == pytest.approx(2 * 3 * 12 / (line["ms_per_step"] * 3e-3), rel=1e-6)
+
+
+def test_bench_world_size_mismatch_is_an_error():
+    """A launcher that started another world than --gpus asks for is an error on every rank, not a warning."""
+    r = _plain(["--gpus", "2", "--device", "cpu", "--steps", "1", "--warmup", "0"],
+               {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29411"})
+    assert r.returncode != 0 and "--gpus 2 but the launcher started WORLD_SIZE 1" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_more_gpus_than_visible_without_touching_one():
+    """`--gpus 9` on any box of this pool (at most 8 devices; none here): loud error before any rank process starts."""
+    r = _plain(["--gpus", "9", "--steps", "1"])
+    assert r.returncode != 0 and "9 devices needed" in r.stderr and "visible" in r.stderr
+    assert not r.stdout.strip()
+
+
+def test_a_dead_rank_ends_the_launch_with_its_code(tmp_path):
+    """launch_local_ranks: a rank that exits non-zero ends the job (its peers, waiting in a collective, are terminated) and
+    the launcher returns that code."""
+    sys.path.insert(0, ROOT)
+    import id_diff_amd  # noqa: F401
+    from id_diff_amd import parallel
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "print('hello from', r, os.environ['WORLD_SIZE'], os.environ['MASTER_PORT'], flush=True)\n"
+                      "if r == 1:\n    sys.exit(7)\n"
+                      "time.sleep(60)\n")
+    import time
+    t0 = time.monotonic()
+    rc = parallel.launch_local_ranks(str(script), [], 3, need_devices=False)
+    assert rc == 7 and time.monotonic() - t0 < 30
