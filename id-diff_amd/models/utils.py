@@ -1,7 +1,8 @@
 """Model registry and the score-function wrapper (drop-in for /root/reference/models/utils.py).
 
 ``get_score_fn(sde, model, conditional=False, train=False, continuous=True)`` returns ``score_fn(x, t)``
-with the reference's semantics for the unconditional continuous branch (models/utils.py:236-282):
+with the reference's semantics for the unconditional continuous branches (models/utils.py:236-280: VP / subVP :238-255,
+VE :257-268, SNR :270-277 -- the same three lines in each; other SDE classes are refused, :279-280):
 
     labels = t * (sde.N - 1);  out = model.eval()(x, labels);  std = sde.marginal_prob(0, t)[1]
     score  = -out / std[:, None, ...]
@@ -41,7 +42,7 @@ def get_score_fn(sde, model, conditional=False, train=False, continuous=True):
         raise NotImplementedError("conditional score estimators are outside the manifold_dimension path")
     if not continuous:
         raise NotImplementedError("only continuously-trained models are on the manifold_dimension path")
-    if not isinstance(sde, (sde_lib.VESDE, sde_lib.VPSDE)):
+    if not isinstance(sde, (sde_lib.VESDE, sde_lib.VPSDE, sde_lib.SNRSDE)):
         raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
     get_model_fn(model, train=train)
 

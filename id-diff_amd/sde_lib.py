@@ -59,7 +59,8 @@ class subVPSDE(VPSDE):
 
 
 class SNRSDE(SDE):
-    """sde_lib.py:153-187 of the reference (default gamma): configure_sde builds it, get_score_fn refuses it -- as there."""
+    """sde_lib.py:153-187 of the reference (default gamma); get_score_fn evaluates it through its own branch
+    (models/utils.py:270-277), the driver perturbs with mean = alpha(t) x (the mean-coefficient path of idiff_perturb_f32)."""
 
     def __init__(self, N, a=2, b=3, c=6, minus_log_SNR_0=-10, minus_log_SNR_1=5):
         super().__init__(N)

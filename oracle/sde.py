@@ -46,7 +46,8 @@ class subVPSDE(VPSDE):
 class SNRSDE:
     """/root/reference/sde_lib.py:153-187 with the default gamma(t) = a t + b t^c (a, b, c = 2, 3, 6), normalised so that
     -log SNR runs from -10 at t = 0 to 5 at t = 1: mean = sqrt(SNR / (1 + SNR)) x, std = sqrt(1 / (1 + SNR)).
-    configure_sde can build it; get_score_fn refuses it (models/utils.py:233 / 268), so it never reaches a score network."""
+    The unconditional get_score_fn has a branch for it (models/utils.py:270-277: labels = t (N - 1), score = -model / std),
+    pinned by tests/golden/ncsnpp_snr.npz (the reference's own score_fn output)."""
 
     def __init__(self, N, a=2, b=3, c=6, minus_log_SNR_0=-10, minus_log_SNR_1=5):
         self.N = N
@@ -75,14 +76,15 @@ def make_sde(config):
 
 
 def get_score_fn(sde, model, conditional=False, train=False, continuous=True):
-    """Unconditional branch of /root/reference/models/utils.py:238-268.
+    """Unconditional branch of /root/reference/models/utils.py:236-280.
 
     labels = t*(N-1); out = model.eval()(x, labels); std = marginal_prob(0,t)[1];
-    score = -out/std (VE and VP continuous alike).
+    score = -out/std -- the same three lines in the VP / subVP (:238-255, continuous), VE (:257-268) and SNR (:270-277)
+    branches; any other SDE class is refused (:279-280).
     """
     if conditional or not continuous:
         raise NotImplementedError("only the unconditional continuous branch is on the hot path")
-    if not isinstance(sde, (VESDE, VPSDE)):              # subVPSDE is a VPSDE here, as in the reference's isinstance test
+    if not isinstance(sde, (VESDE, VPSDE, SNRSDE)):      # subVPSDE is a VPSDE here, as in the reference's isinstance test
         raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
 
     def score_fn(x, t):

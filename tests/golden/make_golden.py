@@ -184,7 +184,7 @@ def gen_fused_act():
 
 def gen_sde_extra():
     """The two other SDEs configure_sde can build (BaseSdeGenerativeModel.py:33-35, 44-46): subVPSDE takes the VP branch of
-    get_score_fn (models/utils.py:238-255); SNRSDE has a perturbation kernel but get_score_fn refuses it."""
+    get_score_fn (models/utils.py:238-255); SNRSDE has a branch of its own (:270-277, fixture: gen_snr)."""
     t = torch.tensor([1e-5, 1e-3, 0.1, 0.3, 0.5, 1.0], dtype=torch.float32)
     x = torch.arange(12, dtype=torch.float32).reshape(6, 2)
     out = {"t": t.numpy(), "x": x.numpy()}
@@ -521,6 +521,32 @@ def gen_vp():
          params=np.array([0.1, 20., 1000]))
 
 
+def gen_snr():
+    """SNRSDE branch of the unconditional get_score_fn (models/utils.py:270-277; the SDE itself sde_lib.py:153-186): the
+    reference's own score_fn on the weights of ncsnpp_bench_init1 at t = 1e-3 (sampling_eps, BaseSdeGenerativeModel.py:44-47),
+    0.2 and 0.7, fed with the driver's perturbation mean + std * z (dim_reduction.py:180-182) from its marginal_prob."""
+    torch.manual_seed(0)
+    cfg = ncsnpp_config(**NCSNPP_VARIANTS["bench_init1"])
+    cfg.training.sde = "snrsde"
+    model = mutils.create_model(cfg)
+    stored = np.load(os.path.join(HERE, "ncsnpp_bench_init1.npz"))
+    for k, v in model.state_dict().items():
+        assert np.array_equal(stored["sd::" + k], v.numpy()), k
+    sde = sde_lib.SNRSDE(N=1000)
+    score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(4, 3, 32, 32, generator=g)
+    t = torch.tensor([1e-3, 1e-3, 0.2, 0.7])
+    z = torch.randn(4, 3, 32, 32, generator=g)
+    mean, std = sde.marginal_prob(x, t)
+    perturbed = mean + std[(...,) + (None,) * 3] * z      # dim_reduction.py:180-182
+    with torch.no_grad():
+        y = score_fn(perturbed, t)
+    save("ncsnpp_snr.npz", x=x.numpy(), t=t.numpy(), z=z.numpy(), mean=mean.numpy(), std=std.numpy(),
+         perturbed=perturbed.numpy(), score=y.numpy(), weights_of=np.array("ncsnpp_bench_init1.npz"),
+         params=np.array([1000]))
+
+
 WIDE_SEED = 20260
 
 
@@ -657,9 +683,9 @@ def gen_conditional():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "sde_extra", "fcn", "ncsnpp", "ksphere", "svd", "beatgans", "ddpm", "vp", "wide", "conditional"]
+    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "sde_extra", "fcn", "ncsnpp", "ksphere", "svd", "beatgans", "ddpm", "vp", "snr", "wide", "conditional"]
     table = {"upfirdn2d": gen_upfirdn2d, "fused_act": gen_fused_act, "sde": gen_sde, "fcn": gen_fcn,
-             "sde_extra": gen_sde_extra, "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule, "beatgans": gen_beatgans, "ddpm": gen_ddpm, "vp": gen_vp, "wide": gen_wide,
+             "sde_extra": gen_sde_extra, "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule, "beatgans": gen_beatgans, "ddpm": gen_ddpm, "vp": gen_vp, "snr": gen_snr, "wide": gen_wide,
              "conditional": gen_conditional}
     for w in which:
         table[w]()

@@ -422,6 +422,52 @@ def test_vp_score_fn_golden(golden):
     torch.testing.assert_close(out.cpu().reshape(ref.shape), ref, rtol=2e-6, atol=2e-6)
 
 
+def test_snr_score_fn_golden(golden):
+    """SNR branch of get_score_fn (models/utils.py:270-277) on the GPU against the REFERENCE's output
+    (tests/golden/ncsnpp_snr.npz), and the driver's SNR perturbation mean = alpha(t) x (sde_lib.py:175-180) through the
+    mean-coefficient path of idiff_perturb_f32 against the reference's mean + std * z."""
+    z = golden("ncsnpp_snr.npz")
+    w = golden(str(z["weights_of"]))
+    cfg = ncsnpp_config(**overrides_from_golden(w))
+    cfg.training.sde = "snrsde"
+    model = mutils.create_model(cfg)
+    model.load_state_dict(state_dict_from_golden(w))
+    model.to(DEV)
+    sde, eps = sde_lib.configure_sde(cfg)
+    assert type(sde) is sde_lib.SNRSDE and eps == 1e-3
+    t = torch.from_numpy(z["t"]).to(DEV)
+    y = mutils.get_score_fn(sde, model)(torch.from_numpy(z["perturbed"]).to(DEV), t)
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+    for i in range(4):                       # row i: sample i perturbed at t[i], as the driver does for one point's rows
+        x0 = torch.from_numpy(z["x"][i]).to(DEV)
+        noise = torch.from_numpy(z["z"][i:i + 1]).to(DEV).reshape(1, -1).contiguous()
+        mean_unit, std = sde.marginal_prob(torch.ones((), device=DEV), t[i:i + 1])
+        out = torch.empty(1, x0.numel(), device=DEV)
+        _lib.perturb(x0.reshape(-1).contiguous(), noise, std.contiguous(), mean_unit.reshape(-1).contiguous(), out, 1, x0.numel())
+        torch.testing.assert_close(out.cpu().reshape(z["perturbed"][i].shape), torch.from_numpy(z["perturbed"][i]), rtol=2e-6, atol=2e-6)
+
+
+def test_snr_score_matrix_and_spectrum_vs_oracle(golden):
+    """The whole per-point recipe under the SNR SDE at its sampling_eps = 1e-3: HIP score matrix against the oracle's on
+    identical noise, spectrum at the 1e-4 bar, same integer ID."""
+    z = golden("conditional.npz")                                  # 16x16 nf=8 NCSN++ with stored weights
+    cfg = ncsnpp_config(**overrides_from_golden(z))
+    ref_model = omodels.create_model(cfg)
+    ref_model.load_state_dict(state_dict_from_golden(z))
+    model = mutils.create_model(cfg)
+    model.load_state_dict(state_dict_from_golden(z))
+    model.to(DEV)
+    x = torch.from_numpy(z["val_images"][2])
+    sde_c, sde_h = osde.SNRSDE(1000), sde_lib.SNRSDE(1000)
+    S, S_ref = _pipeline_pair(mutils.get_score_fn(sde_h, model), osde.get_score_fn(sde_c, ref_model), sde_h, sde_c, x, 100, 1e-3)
+    assert S.shape == (1156, 768) and rel_err(S.cpu(), S_ref) < NET_RTOL
+    sv = _lib.spectrum(S).cpu()
+    ref64 = odim.spectrum_f64(S.cpu())
+    keep = ref64 > 2e-5 * ref64[0]
+    np.testing.assert_allclose(sv.numpy()[keep], odim.spectrum(S.cpu()).numpy()[keep], rtol=1e-4)
+    assert plot_utils.estimate_dim(sv.tolist()) == odim.estimate_dim(odim.spectrum(S_ref).tolist())
+
+
 def test_concurrent_launch_sets_give_the_same_score_matrix(golden):
     """ScoreMatrixBuilder(concurrent_sets=2) (opt-in): the launch sets of a point on two worker streams -- same kernels on
     the same inputs, so S is the sequential S bit for bit (in-kernel noise keyed by the row, explicit noise by index)."""

@@ -66,8 +66,12 @@ def test_sde_matches_golden(golden):
     sde, eps = sde_lib.configure_sde(cfg)
     assert type(sde) is sde_lib.SNRSDE and eps == 1e-3
     from id_diff_amd.models import utils as mutils
-    with pytest.raises(NotImplementedError, match="SNRSDE not yet supported"):      # models/utils.py:268 of the reference
-        mutils.get_score_fn(sde, None)
+    assert callable(mutils.get_score_fn(sde, None))                     # SNR branch, models/utils.py:270-277 of the reference
+
+    class VVSDE(sde_lib.SDE):                                            # a class outside VP / subVP / VE / SNR: :279-280
+        pass
+    with pytest.raises(NotImplementedError, match="SDE class VVSDE not yet supported"):
+        mutils.get_score_fn(VVSDE(1000), None)
 
 
 def test_state_dict_keys_match_reference(golden):

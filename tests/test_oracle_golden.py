@@ -75,15 +75,19 @@ def test_sde_marginals(golden):
 
 
 def test_sde_marginals_of_the_two_other_sdes(golden):
-    """subVPSDE and SNRSDE (configure_sde can build both; only subVPSDE reaches a score network): reference outputs."""
+    """subVPSDE and SNRSDE (configure_sde builds both, get_score_fn evaluates both): reference outputs."""
     z = golden("sde_extra.npz")
     t, x = torch.from_numpy(z["t"]), torch.from_numpy(z["x"])
     mean, std = osde.subVPSDE(0.1, 20., 1000).marginal_prob(x, t)
     assert torch.equal(mean, torch.from_numpy(z["subvp::mean"])) and torch.equal(std, torch.from_numpy(z["subvp::std"]))
     mean, std = osde.SNRSDE(1000).marginal_prob(x, t)
     assert torch.equal(mean, torch.from_numpy(z["snr::mean"])) and torch.equal(std, torch.from_numpy(z["snr::std"]))
-    with pytest.raises(NotImplementedError, match="SNRSDE not yet supported"):
-        osde.get_score_fn(osde.SNRSDE(1000), None)
+    assert callable(osde.get_score_fn(osde.SNRSDE(1000), None))         # models/utils.py:270-277
+
+    class VVSDE:                                                         # anything else is refused, models/utils.py:279-280
+        pass
+    with pytest.raises(NotImplementedError, match="SDE class VVSDE not yet supported"):
+        osde.get_score_fn(VVSDE(), None)
 
 
 def test_fcn_score_fn_tiny(golden):
@@ -220,6 +224,27 @@ def test_vp_score_fn(golden):
     model.load_state_dict(state_dict_from_golden(w), strict=True)
     sde, eps = osde.make_sde(cfg)
     assert isinstance(sde, osde.VPSDE) and eps == 1e-3
+    x, t, noise = torch.from_numpy(z["x"]), torch.from_numpy(z["t"]), torch.from_numpy(z["z"])
+    mean, std = sde.marginal_prob(x, t)
+    assert torch.equal(mean, torch.from_numpy(z["mean"])) and torch.equal(std, torch.from_numpy(z["std"]))
+    perturbed = mean + std[(...,) + (None,) * 3] * noise
+    assert torch.equal(perturbed, torch.from_numpy(z["perturbed"]))
+    with torch.no_grad():
+        y = osde.get_score_fn(sde, model)(perturbed, t)
+    assert rel_err(y, z["score"]) < 2e-6
+
+
+def test_snr_score_fn(golden):
+    """SNR branch of get_score_fn (models/utils.py:270-277) + SNRSDE.marginal_prob (sde_lib.py:175-180) against the
+    reference's own score_fn output on the stored nf = 8 NCSN++ weights at t = 1e-3 / 0.2 / 0.7."""
+    z = golden("ncsnpp_snr.npz")
+    w = golden(str(z["weights_of"]))
+    cfg = ncsnpp_config(**overrides_from_golden(w))
+    cfg.training.sde = "snrsde"
+    model = omodels.create_model(cfg)
+    model.load_state_dict(state_dict_from_golden(w), strict=True)
+    sde, eps = osde.make_sde(cfg)
+    assert isinstance(sde, osde.SNRSDE) and eps == 1e-3
     x, t, noise = torch.from_numpy(z["x"]), torch.from_numpy(z["t"]), torch.from_numpy(z["z"])
     mean, std = sde.marginal_prob(x, t)
     assert torch.equal(mean, torch.from_numpy(z["mean"])) and torch.equal(std, torch.from_numpy(z["std"]))
