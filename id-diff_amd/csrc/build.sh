@@ -21,5 +21,33 @@ for s in $SRC; do
 done
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -fPIC -shared -fvisibility=hidden -o libidiff_hip.so.tmp $(for s in $SRC; do echo "$OBJ/$s.o"; done)
+# No-scratch rule: both GPU memory faults of this project were inside kernels whose register allocation had
+# spilled hundreds of bytes per lane; a library with such a kernel is not produced at all.  Read from the code objects'
+# metadata: .private_segment_fixed_size (bytes of scratch per lane) of every kernel.
+SCRATCH_LIMIT=${IDIFF_SCRATCH_LIMIT:-64}
+LLVM=${LLVM_BIN:-/opt/rocm/lib/llvm/bin}
+if [ -x "$LLVM/llvm-objdump" ] && [ -x "$LLVM/llvm-readelf" ]; then
+  cp libidiff_hip.so.tmp "$OBJ/lib.so"
+  (cd "$OBJ" && "$LLVM/llvm-objdump" --offloading lib.so > /dev/null)
+  nk=0
+  for co in "$OBJ"/lib.so*gfx950*; do
+    [ -e "$co" ] || continue
+    bad=$("$LLVM/llvm-readelf" --notes "$co" | awk -v lim="$SCRATCH_LIMIT" '
+      /\.name:/ {name=$2}
+      /\.private_segment_fixed_size:/ {n++; if ($2+0 > lim) print name ": " $2 " bytes of scratch per lane (limit " lim ")"}
+      END {print "kernels " n > "/dev/stderr"}' 2> "$OBJ/count")
+    nk=$((nk + $(awk '{print $2}' "$OBJ/count")))
+    if [ -n "$bad" ]; then
+      echo "build.sh: kernels with a scratch segment -- refusing to produce libidiff_hip.so:" >&2
+      echo "$bad" >&2
+      rm -f libidiff_hip.so.tmp
+      exit 3
+    fi
+  done
+  [ "$nk" -ge 40 ] || { echo "build.sh: scratch check saw only $nk kernels" >&2; rm -f libidiff_hip.so.tmp; exit 3; }
+  echo "scratch check: $nk kernels, none above $SCRATCH_LIMIT bytes per lane"
+else
+  echo "build.sh: LLVM binutils not found under $LLVM -- scratch check SKIPPED" >&2
+fi
 mv -f libidiff_hip.so.tmp libidiff_hip.so
 echo "built $(pwd)/libidiff_hip.so"
