@@ -32,6 +32,7 @@ _SIGNATURES = {
     "idiff_last_error": (ctypes.c_char_p, []),
     "idiff_source_stamp": (ctypes.c_char_p, []),
     "idiff_set_option": (c_i, [ctypes.c_char_p, c_i]),
+    "idiff_set_thread_option": (c_i, [ctypes.c_char_p, c_i, c_i]),
     "idiff_upfirdn2d_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 14 + [c_p]),
     "idiff_fused_bias_act_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "idiff_gemm_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i,
@@ -137,6 +138,25 @@ def set_option(name, value):
     if prev < 0:
         raise KeyError(f"unknown libidiff_hip option {name!r}")
     return prev if prev > 1 else bool(prev)
+
+
+class thread_option:
+    """``with thread_option("IDIFF_CHASE_WAVEFRONT", 1): ...`` -- the switch for the launches THIS host thread makes inside the
+    block, and for nobody else's (idiff_set_thread_option: launchers read their switches on the calling thread).  This is
+    what the fail-soft re-solve uses: flipping the process-wide switch around a launch would also redirect an eigensolve
+    that another host thread launches in that window."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        if lib().idiff_set_thread_option(self.name, self.value, 1) != 0:
+            raise KeyError(f"unknown libidiff_hip option {self.name.decode()!r}")
+        return self
+
+    def __exit__(self, *exc):
+        lib().idiff_set_thread_option(self.name, 0, 0)
+        return False
 
 
 def _check(rc, what):
@@ -266,14 +286,19 @@ def conv2d_winograd_ok(B, H, W, Cin, Cout):
     return bool(lib().idiff_conv2d_winograd_ok(B, H, W, Cin, Cout))
 
 
-def winograd_pack(wt, Cin, Cout, B_hint=None):
+def conv2d_winograd_split_ok(B, H, W, Cin, Cout):
+    """True when the opt-in split-precision Winograd kernel (IDIFF_WINO_SPLIT) serves this geometry NOW: asked per call, so a
+    switch flipped after a bank was packed, or another (B, H, W) through the same layer, is seen."""
+    return bool(lib().idiff_conv2d_winograd_split_ok(B, H, W, Cin, Cout))
+
+
+def winograd_pack(wt, Cin, Cout, split=False):
     """wt [Cout, 3, 3, Cin] (the direct kernel's panel) -> the transformed filter bank of idiff_conv2d_winograd_f32, or --
-    when ``B_hint = (B, H, W)`` names a geometry the split-precision kernel serves -- of idiff_conv2d_winograd_split_f32."""
+    ``split=True`` -- of idiff_conv2d_winograd_split_f32 (three bf16 per weight)."""
     _dev(wt, "wt")
     if wt.numel() != Cout * 9 * Cin:
         raise RuntimeError(f"winograd_pack: expected {Cout}x3x3x{Cin} weights, got {tuple(wt.shape)}")
-    if B_hint is not None and lib().idiff_conv2d_winograd_split_ok(*B_hint, Cin, Cout):
-        # the split-precision bank (three bf16 per weight); conv2d_winograd tells the two apart by their size
+    if split:
         u = torch.empty(lib().idiff_winograd_split_weight_floats(Cin, Cout), device=wt.device, dtype=torch.float32)
         _check(lib().idiff_winograd_pack_split_f32(wt.data_ptr(), u.data_ptr(), Cin, Cout, _stream()), "idiff_winograd_pack_split_f32")
         return u
@@ -282,9 +307,14 @@ def winograd_pack(wt, Cin, Cout, B_hint=None):
     return u
 
 
-def conv2d_winograd(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+def conv2d_winograd(x, u, out, B, H, W, Cin, Cout, epilogue=None, split=False):
+    """``split`` names the kernel; the bank must be the one ``winograd_pack(..., split=split)`` made (sizes differ: checked)."""
     ep = ctypes.byref(epilogue) if epilogue is not None else None
-    if u.numel() == 24 * Cin * Cout:        # a split-precision bank (winograd_pack with a geometry hint)
+    want = (lib().idiff_winograd_split_weight_floats if split else lib().idiff_winograd_weight_floats)(Cin, Cout)
+    if u.numel() != want:
+        raise RuntimeError(f"conv2d_winograd: a filter bank of {u.numel()} floats for the {'split' if split else 'fp32'} kernel "
+                           f"({want} expected): pack it with winograd_pack(..., split={split})")
+    if split:
         _check(lib().idiff_conv2d_winograd_split_f32(x.data_ptr(), u.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, ep, _stream()),
                "idiff_conv2d_winograd_split_f32")
         return out
@@ -444,11 +474,8 @@ def resolve_failed_spectrum(S, full=False, log=None):
     if not bool(torch.isfinite(S).all()):
         raise RuntimeError("the score matrix holds non-finite values (NaN / inf score vectors): no spectrum exists")
     for name, what in _FALLBACKS:
-        prev = set_option(name, 1)
-        try:
+        with thread_option(name, 1):                       # this thread's launches only
             sv = spectrum(S, full=full)
-        finally:
-            set_option(name, prev)
         if not bool(torch.isnan(sv).any()):
             msg = f"id-diff_amd: the two-stage eigensolver reported a failure; spectrum re-solved with {what} ({name})"
             (log or warnings.warn)(msg)

@@ -2,6 +2,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <limits.h>
 
 namespace idiff {
 static thread_local char g_err[512] = "";
@@ -24,10 +25,22 @@ struct OptionTable {
   }
 };
 OptionTable g_options;     // constructed when the shared object is loaded
+// Per-host-thread overrides (idiff_set_thread_option): every launcher reads its switches on the CALLING thread, so an override
+// set here acts on this thread's launches only -- the fail-soft re-solve selects a slower eigensolver form for its own
+// launch without changing what any other host thread's launches do.  kUnset = fall through to the process-wide table.
+constexpr int kUnset = INT_MIN;
+struct ThreadOptions {
+  int v[OPT_COUNT];
+  ThreadOptions() { for (int i = 0; i < OPT_COUNT; ++i) v[i] = kUnset; }
+};
+thread_local ThreadOptions t_options;
 }  // namespace
 
-bool option(Option o) { return __atomic_load_n(&g_options.v[o], __ATOMIC_RELAXED) != 0; }
-int option_value(Option o) { return __atomic_load_n(&g_options.v[o], __ATOMIC_RELAXED); }
+int option_value(Option o) {
+  const int t = t_options.v[o];
+  return t != kUnset ? t : __atomic_load_n(&g_options.v[o], __ATOMIC_RELAXED);
+}
+bool option(Option o) { return option_value(o) != 0; }
 
 int set_dynamic_lds_once(AttrGuard &g, const void *const *fns, int n_fns, int bytes, const char *what) {
   int dev = 0;
@@ -58,5 +71,15 @@ IDIFF_API int idiff_set_option(const char *name, int value) {
   if (!name) return -1;
   for (int i = 0; i < OPT_COUNT; ++i)
     if (strcmp(name, kOptionNames[i]) == 0) return __atomic_exchange_n(&g_options.v[i], value, __ATOMIC_RELAXED);
+  return -1;
+}
+
+// The same switch for launches made from the CALLING host thread only; `set` = 0 removes the override again.  Returns 0, or -1
+// for an unknown name.
+IDIFF_API int idiff_set_thread_option(const char *name, int value, int set) {
+  using namespace idiff;
+  if (!name) return -1;
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, kOptionNames[i]) == 0) { t_options.v[i] = set ? value : kUnset; return 0; }
   return -1;
 }

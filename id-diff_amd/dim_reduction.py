@@ -249,41 +249,53 @@ def row_sharded_spectrum(S_local, total_rows, ops=None, block_rows=None):
     mean = sums / float(total_rows)
     if block_rows is None:
         block_rows = max(64, ((D // 8 + 63) // 64) * 64)            # ~8 blocks: enough to hide all but the first Gram block
-    G = torch.zeros(D, D, dtype=torch.float64, device=S_local.device)
-    pending = []
     grouped = parallel.is_grouped()
-    for r0 in range(0, D, block_rows):
-        r1 = min(D, r0 + block_rows)
-        gram_rows(S_local, mean, G, r0, r1)
-        if not grouped:
-            continue
-        # only the columns from the block's first diagonal tile onwards carry data (the rest is mirrored afterwards):
-        # reduce that trapezoid, packed, not whole rows -- about half the bytes of a bandwidth-bound collective
-        c0 = (r0 // 128) * 128
-        staging = G[r0:r1, c0:].contiguous()
-        pending.append((parallel.all_reduce_sum_async(staging), staging, r0, r1, c0))
-    for work, staging, r0, r1, c0 in pending:
-        parallel.wait(work)
-        G[r0:r1, c0:].copy_(staging)
-    symmetrize(G)
-    keep = G.clone() if ops is None else None                        # the eigensolver overwrites its input
-    eig = eigvals(G)
-    if keep is not None and bool(torch.isnan(eig).any()):            # fail soft (every rank takes the same branch: same G)
-        eig = _resolve_failed_eigvals(keep, eigvals)
+
+    def reduced_gram():
+        G = torch.zeros(D, D, dtype=torch.float64, device=S_local.device)
+        pending = []
+        for r0 in range(0, D, block_rows):
+            r1 = min(D, r0 + block_rows)
+            gram_rows(S_local, mean, G, r0, r1)
+            if not grouped:
+                continue
+            # only the columns from the block's first diagonal tile onwards carry data (the rest is mirrored afterwards):
+            # reduce that trapezoid, packed, not whole rows -- about half the bytes of a bandwidth-bound collective
+            c0 = (r0 // 128) * 128
+            staging = G[r0:r1, c0:].contiguous()
+            pending.append((parallel.all_reduce_sum_async(staging), staging, r0, r1, c0))
+        for work, staging, r0, r1, c0 in pending:
+            parallel.wait(work)
+            G[r0:r1, c0:].copy_(staging)
+        return symmetrize(G)
+
+    eig = eigvals(reduced_gram())                                     # the eigensolver overwrites its input
+    if ops is None:
+        # fail soft.  The failure flag is reduced (MAX) over the ranks so that EVERY rank takes the same branch even when
+        # only one device's eigensolve failed (a stalled chase is a property of one device, not of G); no copy of G is
+        # kept for this rare path -- it is rebuilt (1.2 GB of fp64 at D = 12288 otherwise sat beside G on every call).
+        failed = torch.isnan(eig).any().to(torch.int32).reshape(1)
+        if grouped:
+            torch.distributed.all_reduce(failed, op=torch.distributed.ReduceOp.MAX)
+        if bool(failed.item()):
+            eig = _resolve_failed_eigvals(reduced_gram, eigvals, grouped)
     return eig.clamp_min(0.0).sqrt().flip(0).to(torch.float32)
 
 
-def _resolve_failed_eigvals(G, eigvals):
+def _resolve_failed_eigvals(make_gram, eigvals, grouped=False):
+    """The slower eigensolver forms in turn, on a freshly built Gram matrix each (the solver overwrites it); with a process
+    group every rank runs the same form and the per-form failure flag is reduced, so all ranks return the same spectrum."""
     import warnings
+    G = make_gram()
     if not bool(torch.isfinite(G).all()):
         raise RuntimeError("the Gram matrix holds non-finite values (NaN / inf score vectors): no spectrum exists")
-    for name, what in _lib._FALLBACKS:
-        prev = _lib.set_option(name, 1)
-        try:
-            eig = eigvals(G.clone())
-        finally:
-            _lib.set_option(name, prev)
-        if not bool(torch.isnan(eig).any()):
+    for i, (name, what) in enumerate(_lib._FALLBACKS):
+        with _lib.thread_option(name, 1):                  # this thread's launches only
+            eig = eigvals(G if i == 0 else make_gram())
+        failed = torch.isnan(eig).any().to(torch.int32).reshape(1)
+        if grouped:
+            torch.distributed.all_reduce(failed, op=torch.distributed.ReduceOp.MAX)
+        if not bool(failed.item()):
             if parallel.rank_world()[0] == 0:
                 warnings.warn(f"id-diff_amd: the two-stage eigensolver reported a failure; re-solved with {what} ({name})")
             return eig

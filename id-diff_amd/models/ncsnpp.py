@@ -373,16 +373,20 @@ class NCSNpp(HipScoreModel):
             ep["rows_per_group"] = OH * OW
         if (kh, kw, stride, pad, ph) == (3, 3, 1, 1, 1) and _lib.conv2d_winograd_ok(B, x.H, x.W, cin, cout):
             # Winograd F(2x2, 3x3): 2.25x fewer MFMA flops; the transformed filter bank is cached beside the panel
+            # (keyed by the kernel form too: the split-precision form is asked for per call, so a switch flipped later or
+            # another geometry through this layer picks its own bank instead of inheriting the first one packed)
             bank = self._packed.setdefault("wino", {})
-            if id(wt) not in bank:
-                bank[id(wt)] = (wt, _lib.winograd_pack(wt, cin, cout, B_hint=(B, x.H, x.W)))
+            split = _lib.conv2d_winograd_split_ok(B, x.H, x.W, cin, cout)
+            key = (id(wt), split)
+            if key not in bank:
+                bank[key] = (wt, _lib.winograd_pack(wt, cin, cout, split=split))
             if stats:
                 ns = _lib.conv2d_winograd_colstats_split(B, x.H, x.W, cin, cout)
                 if ns > 0:
                     y.stats = (torch.empty(B * ns * cout * 2, device=x.buf.device, dtype=torch.float64), ns)
                     ep["colstats"] = y.stats[0]
-            _lib.conv2d_winograd(x.buf, bank[id(wt)][1], y.buf, B, x.H, x.W, cin, cout,
-                                 epilogue=_lib.make_epilogue(bias=bias, **ep))
+            _lib.conv2d_winograd(x.buf, bank[key][1], y.buf, B, x.H, x.W, cin, cout,
+                                 epilogue=_lib.make_epilogue(bias=bias, **ep), split=split)
             return y
         if stats:
             ns = _lib.conv2d_colstats_split(B, x.H, x.W, cin, cout, kh, kw, stride, pad, pad_hi)

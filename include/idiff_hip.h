@@ -48,6 +48,12 @@ const char *idiff_source_stamp(void);
  * Returns the previous value, -1 for an unknown name.  No reference counterpart. */
 int idiff_set_option(const char *name, int value);
 
+/* The same switch for launches made from the CALLING host thread only (every launcher reads its switches on the thread that
+ * calls it); set = 0 removes the override and the process-wide value applies again.  Used by the fail-soft re-solve of a
+ * failed eigensolve, so that selecting a slower solver form for ONE launch cannot change what another host thread launches
+ * in the meantime.  Returns 0, -1 for an unknown name.  No reference counterpart. */
+int idiff_set_thread_option(const char *name, int value, int set);
+
 /* ------------------------------------------------------------------ native ops (op/) */
 
 /* Replaces the pybind entry `upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
@@ -108,6 +114,9 @@ typedef struct idiff_epilogue {
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; what is left out is < 2^-23 of the product, the size of one fp32
  * rounding (1.7e-7 against an fp64 contraction where the k-ordered fp32 fma chain of v_mfma_f32_32x32x2_f32 gives
  * 2.0e-7).  IDIFF_NO_SPLIT selects that fp32 chain; operands the fast path does not take always use it.
+ * Non-finite operands: the cut forms x - hi(x), so a +-inf element turns into NaN in its lower pieces and every output that
+ * element reaches is NaN, where the fp32 chain would give +-inf (or NaN against a zero).  Non-finite stays non-finite -- the
+ * drivers refuse a score matrix with any non-finite entry either way -- but inf vs NaN is not preserved on this path.
  * batch strides are in elements; a stride of 0 broadcasts that operand.  The epilogue pointers are
  * shared by all batch entries. */
 int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt, int64_t ldb, int64_t strideB,

@@ -14,7 +14,7 @@ import sys
 def kernel_text(path, name):
     out, on = [], False
     for ln in open(path):
-        if re.match(r"^\S*%s\S*:\s*$" % re.escape(name), ln):
+        if re.match(r"^[\w.$]*%s[\w.$]*:" % re.escape(name), ln):
             on = True
         if on:
             out.append(ln)

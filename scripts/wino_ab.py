@@ -18,14 +18,14 @@ for H, Cin, Cout, calls in shapes:
     ms = []
     for split in (False, True):
         prev = _lib.set_option("IDIFF_WINO_SPLIT", 1)
-        u = _lib.winograd_pack(w, Cin, Cout, B_hint=(B, H, H) if split else None)
+        u = _lib.winograd_pack(w, Cin, Cout, split=bool(split))
         _lib.set_option("IDIFF_WINO_SPLIT", int(prev))
         for _ in range(2):
-            _lib.conv2d_winograd(x, u, o, B, H, H, Cin, Cout, epilogue=ep)
+            _lib.conv2d_winograd(x, u, o, B, H, H, Cin, Cout, epilogue=ep, split=bool(split))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            _lib.conv2d_winograd(x, u, o, B, H, H, Cin, Cout, epilogue=ep)
+            _lib.conv2d_winograd(x, u, o, B, H, H, Cin, Cout, epilogue=ep, split=bool(split))
         e1.record(); torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1) / 5)
     tot[0] += ms[0] * calls; tot[1] += ms[1] * calls

@@ -10,10 +10,10 @@ dev = torch.device("cuda:0")
 x = torch.randn(B, H * H, Cin, device=dev)
 w = torch.randn(Cout, 3, 3, Cin, device=dev) / (9 * Cin) ** 0.5
 split = len(sys.argv) > 5 and sys.argv[5] == 'split'
-u = _lib.winograd_pack(w, Cin, Cout, B_hint=(B, H, H) if split else None)
+u = _lib.winograd_pack(w, Cin, Cout, split=bool(split))
 o = torch.empty(B, H * H, Cout, device=dev)
 ep = _lib.make_epilogue(bias=torch.randn(Cout, device=dev))
 for _ in range(4):
-    _lib.conv2d_winograd(x, u, o, B, H, H, Cin, Cout, epilogue=ep)
+    _lib.conv2d_winograd(x, u, o, B, H, H, Cin, Cout, epilogue=ep, split=bool(split))
 torch.cuda.synchronize()
 print("done", flush=True)

@@ -27,16 +27,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         B = 2240
         x = torch.randn(B, H * H, Cin, device=dev)
         w = torch.randn(Cout, 3, 3, Cin, device=dev) / (9 * Cin) ** 0.5
-        u = _lib.winograd_pack(w, Cin, Cout, B_hint=(B, H, H))
+        u = _lib.winograd_pack(w, Cin, Cout, split=True)
         out = torch.empty(B, H * H, Cout, device=dev)
         nwg = (B * H * H // 4 // 32) * (Cout // 64)
         st = torch.zeros(nwg * 8 * 8, device=dev, dtype=torch.int32)
         ep = _lib.make_epilogue(bias=torch.randn(Cout, device=dev), colstats=st.view(torch.float64))
         for _ in range(3):
-            _lib.conv2d_winograd(x, u, out, B, H, H, Cin, Cout, epilogue=ep)
+            _lib.conv2d_winograd(x, u, out, B, H, H, Cin, Cout, epilogue=ep, split=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): _lib.conv2d_winograd(x, u, out, B, H, H, Cin, Cout, epilogue=ep)
+        for _ in range(5): _lib.conv2d_winograd(x, u, out, B, H, H, Cin, Cout, epilogue=ep, split=True)
         e1.record(); torch.cuda.synchronize()
         s = st.view(nwg, 8, 8).double()
         steps = s[0, 0, 7].item()

@@ -86,3 +86,20 @@ def test_no_kernel_spills_to_scratch_beyond_the_known_ones(library, tmp_path):
             limit = next((v for k, v in allowed.items() if k in name), 64)
             assert int(size) <= limit, f"{name}: {size} bytes of scratch per lane"
     assert seen >= 40
+
+
+def test_thread_option_acts_on_the_calling_thread_only():
+    """idiff_set_thread_option: the fail-soft re-solve selects a slower eigensolver form for ITS launch; another host thread's
+    launches keep reading the process-wide value (checked through a host-only query that reads a switch)."""
+    import threading
+    ask = lambda: _lib.conv2d_winograd_split_ok(4, 16, 16, 64, 64)       # reads IDIFF_WINO_SPLIT, no device call
+    assert ask() is False
+    seen = {}
+    with _lib.thread_option("IDIFF_WINO_SPLIT", 1):
+        assert ask() is True
+        t = threading.Thread(target=lambda: seen.setdefault("other", ask()))
+        t.start(); t.join()
+    assert seen["other"] is False and ask() is False
+    with pytest.raises(KeyError):
+        with _lib.thread_option("IDIFF_NO_SUCH_SWITCH", 1):
+            pass

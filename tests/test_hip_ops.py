@@ -255,21 +255,22 @@ def test_conv2d_winograd_vs_cpu(B, H, W, Cin, Cout, split):
     assert _lib.conv2d_winograd_ok(B, H, W, Cin, Cout)
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     wt = w.permute(0, 2, 3, 1).contiguous().to(DEV)
-    prev = _lib.set_option("IDIFF_WINO_SPLIT", 1)          # the split-precision Winograd kernel is opt-in
-    try:
-        u = _lib.winograd_pack(wt, Cin, Cout, B_hint=(B, H, W) if split else None)
-    finally:
-        _lib.set_option("IDIFF_WINO_SPLIT", int(prev))
+    with _lib.thread_option("IDIFF_WINO_SPLIT", 1):        # the split-precision Winograd kernel is opt-in; asked per call
+        assert _lib.conv2d_winograd_split_ok(B, H, W, Cin, Cout)
+    assert not _lib.conv2d_winograd_split_ok(B, H, W, Cin, Cout)
+    u = _lib.winograd_pack(wt, Cin, Cout, split=split)
     assert u.numel() == (24 if split else 16) * Cin * Cout
     out = torch.empty(B, H, W, Cout, device=DEV)
-    _lib.conv2d_winograd(xd, u, out, B, H, W, Cin, Cout, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
+    with pytest.raises(RuntimeError, match="filter bank"):  # the bank of the other form is refused, never reinterpreted
+        _lib.conv2d_winograd(xd, u, out, B, H, W, Cin, Cout, split=not split)
+    _lib.conv2d_winograd(xd, u, out, B, H, W, Cin, Cout, epilogue=_lib.make_epilogue(bias=b.to(DEV)), split=split)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 3e-6
     direct = torch.empty_like(out)
     _lib.conv2d_nhwc(xd, wt, direct, B, H, W, Cin, Cout, 3, 3, 1, 1, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
     assert rel_err(out.cpu(), direct.double().cpu()) < 3e-6
     resd = res.permute(0, 2, 3, 1).contiguous().to(DEV)
-    _lib.conv2d_winograd(xd, u, out, B, H, W, Cin, Cout,
+    _lib.conv2d_winograd(xd, u, out, B, H, W, Cin, Cout, split=split,
                          epilogue=_lib.make_epilogue(bias=b.to(DEV), rowbias=temb.to(DEV), rows_per_group=H * W, act="silu",
                                                      residual=resd, out_scale=0.7071, rowscale=rsc.to(DEV)))
     ref2 = (F.silu(ref + temb.double()[:, :, None, None]) + res.double()) * 0.7071 * rsc.double()[:, None, None, None]
@@ -367,13 +368,9 @@ def test_winograd_colstats_feed_groupnorm(B, H, Cin, Cout, split):
     out = torch.empty(B, H * H, Cout, device=DEV)
     if split and Cin % 16:
         pytest.skip("the split-precision kernel takes 16 channels per step")
-    prev = _lib.set_option("IDIFF_WINO_SPLIT", 1)
-    try:
-        u = _lib.winograd_pack(w, Cin, Cout, B_hint=(B, H, H) if split else None)
-    finally:
-        _lib.set_option("IDIFF_WINO_SPLIT", int(prev))
+    u = _lib.winograd_pack(w, Cin, Cout, split=split)
     assert u.numel() == (24 if split else 16) * Cin * Cout
-    _lib.conv2d_winograd(x, u, out, B, H, H, Cin, Cout,
+    _lib.conv2d_winograd(x, u, out, B, H, H, Cin, Cout, split=split,
                          epilogue=_lib.make_epilogue(bias=bias, act="silu", rows_per_group=H * H, colstats=cs))
     G = 32
     st_a, st_b = torch.empty(B * G * 2, device=DEV), torch.empty(B * G * 2, device=DEV)
