@@ -101,7 +101,7 @@ class KernelProbe:
         setattr(_lib, name, timed)
 
     def install(self):
-        def wino(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+        def wino(x, u, out, B, H, W, Cin, Cout, epilogue=None, split=False):
             # executed flops of F(2x2,3x3): 16 positions x [tiles x Cin] x [Cin x Cout]; the implicit GEMM would be 2.25x that
             return "winograd_kernel", 2.0 * 16 * (B * H * W // 4) * Cin * Cout, f"{B}x{H}x{W}x{Cin}->{Cout}"
 

@@ -51,7 +51,7 @@ def d_gemm2(a1, a2, bt, out, epilogue=None):
 def d_conv(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue=None, pad_hi=None):
     return (f"B{B} {H}x{W} {Cin}->{Cout} k{KH} s{stride}", 2.0 * out.numel() * Cin * KH * KW,
             4.0 * (B * H * W * Cin + out.numel()))
-def d_wino(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+def d_wino(x, u, out, B, H, W, Cin, Cout, epilogue=None, split=False):
     return (f"B{B} {H}x{W} {Cin}->{Cout} (F(2x2,3x3); TF = direct-equivalent)", 2.0 * out.numel() * Cin * 9,
             4.0 * (B * H * W * Cin + out.numel()))
 def d_gnapply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None):

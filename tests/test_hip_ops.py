@@ -256,7 +256,7 @@ def test_conv2d_winograd_vs_cpu(B, H, W, Cin, Cout, split):
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     wt = w.permute(0, 2, 3, 1).contiguous().to(DEV)
     with _lib.thread_option("IDIFF_WINO_SPLIT", 1):        # the split-precision Winograd kernel is opt-in; asked per call
-        assert _lib.conv2d_winograd_split_ok(B, H, W, Cin, Cout)
+        assert _lib.conv2d_winograd_split_ok(B, H, W, Cin, Cout) == (Cin % 16 == 0)
     assert not _lib.conv2d_winograd_split_ok(B, H, W, Cin, Cout)
     u = _lib.winograd_pack(wt, Cin, Cout, split=split)
     assert u.numel() == (24 if split else 16) * Cin * Cout
