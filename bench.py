@@ -252,9 +252,6 @@ def spectrum_stage_report(rows, D, dev, reps=3):
     return whole, stages
 
 
-LDS_PEAK_GBS = 150000.0      # MI355X_MICROARCH.md, LDS: ~150 TB/s aggregate for ds_read_b64 / b128 with every CU streaming
-
-
 def _events_ms(fn, reps=3):
     fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -300,22 +297,35 @@ def extra_cfg2(dev):
         G2.copy_(G)                                               # the kernel overwrites its input
         lib.idiff_symtridiag_f64(G2.data_ptr(), NP, D, diag.data_ptr(), offd.data_ptr(), None, st)
     tri_ms = _events_ms(tri) - clone_ms
-    # Householder step k on a trailing block of n = D - k - 1: symv reads n^2 doubles, the rank-2 update reads and writes
-    # them: 24 n^2 bytes of LDS traffic -> ~8 D^3 bytes per matrix; HBM: the 8 D^2-byte matrix once
-    lds_bytes = NP * 24.0 * sum((D - k - 1) ** 2 for k in range(D - 2))
+    # Householder tridiagonalisation: (4/3) D^3 flops per matrix (a symmetric matrix-vector product and a symmetric rank-2 update per
+    # step); the register-resident kernel spends 5 n FMAs per row and step instead of the symmetric minimum (it keeps both
+    # triangles and recomputes the step's scalars in every lane pair), so the fraction is of ALGORITHMIC flops
+    tri_flops = NP * (4.0 / 3.0) * D ** 3
     del S, G, G2, scratch
+    # north_star: "correct ID recovered": the same driver on the exact score of the noised k-sphere (models/ksphere_exact.py)
+    cfg_e = read_config('configs/dimension_estimation/paper/euclidean_data/ksphere/50dim.py')
+    cfg_e.model.name = 'ksphere_exact'
+    cfg_e.device = str(dev)
+    cfg_e.data.data_samples = 8000
+    cfg_e.dim_estimation.num_datapoints = 65                      # 64 points
+    dims_e = plot_utils.plot_dims(dim_reduction.get_manifold_dimension(cfg_e, return_svd=True))[1]
     return {"workload": "KSphere 50-sphere in R^100, random-weight fcn 2048x5, VE-SDE t=1e-5, B=500 -> S 1501x100 per point",
             "points": P, "driver_seconds": dt, "evals_per_s_end_to_end": P * M / dt,
             "id_estimates_min_max": [int(min(plot_utils.plot_dims(svd)[1])), int(max(plot_utils.plot_dims(svd)[1]))],
+            "id_estimates_note": "random-weight fcn: throughput only, its ID is meaningless",
+            "ksphere_exact": {"model": "exact score of the noised 50-sphere (models/ksphere_exact.py), same driver and recipe",
+                              "points": len(dims_e), "id_estimates_min_max": [int(min(dims_e)), int(max(dims_e))], "true_dimension": 50},
             "batched_spectra": {"matrices": NP, "shape": [M, D], "ms": spectra_ms},
             "kernels": [
-                {"kernel": "gram_kernel (fp64 centred Gram, 64x64 tiles, 4096 matrices per launch)", "bound": "mfma",
+                {"kernel": "gram_small_batched_kernel (fp64 centred Gram, one workgroup per 1501x100 matrix, 28 upper-triangular 16x16 "
+                           "blocks on v_mfma_f64_16x16x4_f64, operands centred once)", "bound": "mfma",
                  "achieved": NP * M * D * D / (gram_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": NP * M * D * D / (gram_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms": gram_ms,
                  "hbm_gbs": 4.0 * NP * M * D / (gram_ms * 1e-3) / 1e9},
-                {"kernel": "tridiag_small_kernel (one workgroup per 100x100 matrix, Householder in LDS)", "bound": "lds",
-                 "achieved": lds_bytes / (tri_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                 "frac": lds_bytes / (tri_ms * 1e-3) / 1e9 / LDS_PEAK_GBS, "ms": tri_ms,
+                {"kernel": "tridiag_reg_kernel (one 100x100 matrix per 256 threads, rows in registers, a lane pair per row, vectors "
+                           "exchanged as LDS broadcasts)", "bound": "valu-fp64",
+                 "achieved": tri_flops / (tri_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (algorithmic 4/3 D^3)",
+                 "frac": tri_flops / (tri_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms": tri_ms,
                  "hbm_gbs": 8.0 * NP * D * D / (tri_ms * 1e-3) / 1e9}]}
 
 

@@ -243,6 +243,125 @@ bool gram_big_ok(const float *S, int D) {
 // diagonal tiles are computed in full by gram_kernel (both triangles inside the tile come from the
 // same products in a different order); force exact symmetry afterwards so the Householder sweep may read
 // rows where the textbook reads columns.
+// The batched small case (BASELINE config 2: P matrices of 1501 x 100): ONE workgroup per matrix.  gram_kernel gives such a
+// matrix three 64 x 64 tiles whose lanes are a quarter to a half empty (100 = 64 + 36), re-reads S once per tile and converts /
+// centres every operand in every wave that touches it: 13 TFLOP/s, 0.17 of the fp64 matrix peak.  Here D <= 112 = 7 MFMA column
+// blocks; a stage of 32 rows is converted to fp64 and centred ONCE by the thread that stages it ([32][112] doubles, two
+// stages: 56 KB, two workgroups per CU), the 28 blocks (bi <= bj) of the upper triangle are dealt 7 to a wave so that a wave
+// needs at most 7 fragments per k-step (one 8-byte LDS read each) for its 7 MFMAs, the next stage's 16-byte global loads are in
+// flight while the current one multiplies, and S is read from HBM exactly once.  Diagonal blocks come out whole and exactly
+// symmetric (same products, same order); the rest is mirrored by the epilogue.  Row order of the reduction: k-steps of four
+// consecutive rows in ascending order, as gram_kernel -- the two agree bit for bit.
+constexpr int SB_COLS = 112;      // 7 column blocks of 16
+constexpr int SB_NB = SB_COLS / 16;
+constexpr int SB_ROWS = 32;       // rows of S per stage
+constexpr int SB_PITCH = SB_COLS; // 224 dwords = 32 mod 64 banks: rows k, k + 1 of a k-step fall on disjoint bank halves
+constexpr size_t GRAM_SMALL_LDS = (size_t)(2 * SB_ROWS * SB_PITCH + SB_COLS) * sizeof(double);
+
+// wave W's blocks: row W from the diagonal to the right, plus the short rows that fill it up to 7 blocks
+template <int W> struct SbBlocks;
+template <> struct SbBlocks<0> { static constexpr int n = 7, bi[7] = {0, 0, 0, 0, 0, 0, 0}, bj[7] = {0, 1, 2, 3, 4, 5, 6}; };
+template <> struct SbBlocks<1> { static constexpr int n = 7, bi[7] = {1, 1, 1, 1, 1, 1, 6}, bj[7] = {1, 2, 3, 4, 5, 6, 6}; };
+template <> struct SbBlocks<2> { static constexpr int n = 7, bi[7] = {2, 2, 2, 2, 2, 5, 5}, bj[7] = {2, 3, 4, 5, 6, 5, 6}; };
+template <> struct SbBlocks<3> { static constexpr int n = 7, bi[7] = {3, 3, 3, 3, 4, 4, 4}, bj[7] = {3, 4, 5, 6, 4, 5, 6}; };
+
+template <int W>
+__device__ __forceinline__ void sb_multiply(const double *__restrict__ X /* [SB_ROWS][SB_PITCH] */, doublex4 (&acc)[7], int fl, int fk) {
+  using B = SbBlocks<W>;
+#pragma unroll
+  for (int ks = 0; ks < SB_ROWS / 4; ++ks) {
+    const double *row = X + (ks * 4 + fk) * SB_PITCH + fl;
+    double f[SB_NB];
+#pragma unroll
+    for (int b = W; b < SB_NB; ++b) f[b] = row[16 * b];          // wave W touches column blocks W .. 6 only
+#pragma unroll
+    for (int q = 0; q < B::n; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[B::bi[q]], f[B::bj[q]], acc[q], 0, 0, 0);
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void sb_store(double *__restrict__ Gp, int D, const doublex4 (&acc)[7], int fl, int fk) {
+  using B = SbBlocks<W>;
+#pragma unroll
+  for (int q = 0; q < B::n; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = 16 * B::bi[q] + fk + 4 * r, gj = 16 * B::bj[q] + fl;
+      if (gi < D && gj < D) {
+        Gp[(int64_t)gi * D + gj] = acc[q][r];
+        if (B::bi[q] != B::bj[q]) Gp[(int64_t)gj * D + gi] = acc[q][r];
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+gram_small_batched_kernel(const float *__restrict__ S, const double *__restrict__ mean, int M, int D, double *__restrict__ G) {
+  extern __shared__ __attribute__((aligned(16))) double sbm[];
+  double *X0 = sbm, *X1 = sbm + SB_ROWS * SB_PITCH, *mu = sbm + 2 * SB_ROWS * SB_PITCH;
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fl = lane & 15, fk = lane >> 4;
+  const float *Sp = S + (int64_t)p * M * D;
+  for (int c = tid; c < SB_COLS; c += 256) mu[c] = c < D ? mean[(int64_t)p * D + c] : 0.0;
+  // zero both stages once: the columns D .. 111 and the rows past M are never written again
+  for (int e = tid; e < 2 * SB_ROWS * SB_PITCH; e += 256) sbm[e] = 0.0;
+  __syncthreads();
+  // staging map: a stage is SB_ROWS rows x D/4 float4 (D % 4 == 0 and a 16-byte aligned S are checked by the launcher)
+  const int c4n = D >> 2, per_stage = SB_ROWS * c4n;
+  constexpr int SLOTS = (SB_ROWS * (SB_COLS / 4) + 255) / 256;     // 4
+  float4 v[SLOTS];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+      const int idx = tid + 256 * q, r = idx / c4n, c4 = idx - r * c4n;
+      v[q] = (idx < per_stage && m0 + r < M) ? *reinterpret_cast<const float4 *>(Sp + (int64_t)(m0 + r) * D + 4 * c4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage = [&](double *X, int m0) {
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+      const int idx = tid + 256 * q, r = idx / c4n, c4 = idx - r * c4n;
+      if (idx < per_stage) {
+        const bool ok = m0 + r < M;                              // a row past the end is zero AFTER centring
+        double2 lo, hi;
+        lo.x = ok ? (double)v[q].x - mu[4 * c4] : 0.0;
+        lo.y = ok ? (double)v[q].y - mu[4 * c4 + 1] : 0.0;
+        hi.x = ok ? (double)v[q].z - mu[4 * c4 + 2] : 0.0;
+        hi.y = ok ? (double)v[q].w - mu[4 * c4 + 3] : 0.0;
+        double2 *dst = reinterpret_cast<double2 *>(X + r * SB_PITCH + 4 * c4);
+        dst[0] = lo; dst[1] = hi;
+      }
+    }
+  };
+  doublex4 acc[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) acc[q] = (doublex4){0.0, 0.0, 0.0, 0.0};
+  fetch(0);
+  stage(X0, 0);
+  __syncthreads();
+  const int nst = (M + SB_ROWS - 1) / SB_ROWS;
+  for (int t = 0; t < nst; ++t) {
+    double *cur = (t & 1) ? X1 : X0, *nxt = (t & 1) ? X0 : X1;
+    const bool more = t + 1 < nst;
+    if (more) fetch((t + 1) * SB_ROWS);                          // in flight under this stage's MFMAs
+    switch (wave) {
+      case 0: sb_multiply<0>(cur, acc, fl, fk); break;
+      case 1: sb_multiply<1>(cur, acc, fl, fk); break;
+      case 2: sb_multiply<2>(cur, acc, fl, fk); break;
+      default: sb_multiply<3>(cur, acc, fl, fk); break;
+    }
+    if (more) stage(nxt, (t + 1) * SB_ROWS);
+    __syncthreads();
+  }
+  double *Gp = G + (int64_t)p * D * D;
+  switch (wave) {
+    case 0: sb_store<0>(Gp, D, acc, fl, fk); break;
+    case 1: sb_store<1>(Gp, D, acc, fl, fk); break;
+    case 2: sb_store<2>(Gp, D, acc, fl, fk); break;
+    default: sb_store<3>(Gp, D, acc, fl, fk); break;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 symmetrize_diag_tiles_kernel(double *__restrict__ G, int D) {
   const int p = blockIdx.y, tile = blockIdx.x;
@@ -622,6 +741,253 @@ tridiag_small_kernel(const double *__restrict__ G, int D, double *__restrict__ d
   }
 }
 
+// ------------------------------------------------------------------------------------------------ tridiag, D <= 128 in registers
+// The batched k-sphere case again (4096 matrices of 100 x 100): tridiag_small_kernel keeps the matrix in LDS and walks it with
+// ~8 workgroup barriers per Householder step -- 4 us per step, 0.034 of the LDS bandwidth, one matrix per CU at a time.  Here
+// the matrix lives in REGISTERS: 256 threads per matrix, the lane pair (2 i, 2 i + 1) holds row i -- lane h of the pair the
+// columns j = 2 t + h as 64 doubles with compile-time indices only (the step loop is unrolled in blocks of 16 columns: block b
+// runs steps k = 16 b .. 16 b + 15 on the columns >= 16 b).  The symmetric matrix-vector product p_i = sum_j A[i][j] v_j and
+// the rank-2 update A[i][j] -= v_i p_j + u_i v_j (u = p - 2 c v, c = tau v.p / 2) are fp64 FMA streams over a lane's own
+// registers; the only cross-lane traffic is one DPP swap inside the pair per sum (the "wavefront shuffle" of a step) and the
+// exchange of the vectors x (column k: row j holds A[j][k] = A[k][j]), v and p through 4 KB of LDS, read back as broadcast
+// 16-byte loads; the scalars of a step (|x_tail|^2, v.p) are recomputed by every lane pair from those broadcasts, so a step
+// has TWO workgroup barriers and no reduction tree.  Finished rows / columns are masked by ZEROS in the exchanged vectors
+// (x_j = 0 for j <= k, p_i = 0 for i <= k), never by predicates in the inner loops; a wave whose 32 rows are all finished
+// skips the loops (a uniform branch) and only keeps the barriers.  252 registers: two waves per SIMD, two matrices per CU at once.
+constexpr int RT_NP = 128;        // padded dimension
+constexpr int RT_NH = RT_NP / 2;  // columns per lane of a pair (largest form)
+constexpr int RT_THREADS = 256;
+constexpr int RT_BLK = 16;        // steps (= columns) per unrolled block
+constexpr int RT_CHUNK = 8;       // register slots per scheduling group of the unrolled inner loops
+constexpr int RT_PL = RT_NH + 2;  // plane pitch in LDS: the two parities of a 16-byte broadcast read fall on different banks
+
+// exchange a double with the other lane of the pair (DPP quad_perm [1, 0, 3, 2]: no LDS, no ds_bpermute)
+__device__ __forceinline__ double rt_partner(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// `cond ? a[i] : r` chains over register-array elements are rewritten by the optimiser into ONE load through a selected
+// POINTER -- a dynamic index, which sends the whole array to scratch.  Passing the candidate through an empty asm keeps it a
+// value (no instruction is emitted).
+__device__ __forceinline__ double rt_val(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// v_rsq_f64 / v_rcp_f64 seeds + two Newton steps: full double accuracy in ~12 instructions; the IEEE sqrt and division of
+// make_reflector are ~200 instructions on the critical path of EVERY step here (as in sbr.hip's factorisations)
+__device__ __forceinline__ double rt_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+__device__ __forceinline__ double rt_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+}
+__device__ __forceinline__ Reflector rt_reflector(double x0, double tail_sq) {
+  Reflector h;
+  if (tail_sq == 0.0) { h.alpha = x0; h.v0 = 0.0; h.tau = 0.0; return h; }
+  const double n2 = fma(x0, x0, tail_sq);
+  const double norm = n2 * rt_rsqrt(n2);
+  h.alpha = x0 > 0.0 ? -norm : norm;
+  h.v0 = x0 - h.alpha;
+  h.tau = 2.0 * rt_rcp(fma(h.v0, h.v0, tail_sq));
+  return h;
+}
+
+struct RtShared {
+  double x[2][2][RT_PL];          // [step parity][column parity][column >> 1]
+  double p[2][RT_PL], v[2][RT_PL];
+};
+
+// Inner loops: RT_CHUNK register slots per group, the NEXT group's broadcast reads issued before the current group's FMAs
+// (two register sets), groups fenced for the scheduler -- unfenced it hoists every read of the unrolled loop to the top and
+// spills; fenced without the look-ahead every group pays the LDS latency in full (5800 cycles per step measured).
+template <int NH, int JLO>
+__device__ __forceinline__ void rt_block(double (&a)[NH], int D, int tid, double *__restrict__ dg, double *__restrict__ od,
+                                         RtShared &sh) {
+  constexpr int T0 = JLO / 2;
+  constexpr int TP = T0 + RT_BLK / 2 + 1 < NH ? T0 + RT_BLK / 2 + 1 : NH;   // slots that can hold column k + 1 in this block
+  constexpr int NG = (NH - T0 + RT_CHUNK - 1) / RT_CHUNK;                   // groups of the inner loops
+  const int row = tid >> 1, h = tid & 1;
+  const int wave_rows_end = ((tid >> 6) + 1) * 32;       // first row beyond this wave's
+  for (int k = JLO; k < JLO + RT_BLK && k + 2 < D; ++k) {
+    double (*X)[RT_PL] = sh.x[k & 1];
+    // my element of column k (slot k >> 1 of the lanes with h == (k & 1)): a select over the block's 8 candidate slots
+    double xk = rt_val(a[T0]);
+#pragma unroll
+    for (int t = 1; t < RT_BLK / 2; ++t)
+      if (T0 + t < NH) xk = ((k >> 1) == T0 + t) ? rt_val(a[T0 + t]) : xk;
+    if (h == (k & 1)) {
+      X[row & 1][row >> 1] = row > k ? xk : 0.0;        // x_row = A[row][k]
+      if (row == k) dg[k] = xk;
+    }
+    __syncthreads();
+    const bool live = wave_rows_end > k + 1;             // some row of this wave is still below the pivot (uniform per wave)
+    const int kp = k + 1, kpt = kp >> 1;
+    const bool mine = h == (kp & 1);                     // this lane holds column k + 1
+    double q = 0.0, ss = 0.0, akp1 = 0.0;
+    if (live) {
+      double q0 = 0.0, q1 = 0.0, s0 = 0.0, s1 = 0.0;
+      double2 xb[2][RT_CHUNK / 2];
+#pragma unroll
+      for (int u = 0; u < RT_CHUNK / 2; ++u)
+        if (T0 + 2 * u < NH) xb[0][u] = *reinterpret_cast<const double2 *>(&X[h][T0 + 2 * u]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int u = 0; u < RT_CHUNK / 2; ++u)
+            if (T0 + (g + 1) * RT_CHUNK + 2 * u < NH)
+              xb[(g + 1) & 1][u] = *reinterpret_cast<const double2 *>(&X[h][T0 + (g + 1) * RT_CHUNK + 2 * u]);
+        }
+#pragma unroll
+        for (int u = 0; u < RT_CHUNK / 2; ++u) {
+          const int t = T0 + g * RT_CHUNK + 2 * u;
+          if (t < NH) {
+            const double2 xx = xb[g & 1][u];
+            q0 = fma(a[t], xx.x, q0);
+            q1 = fma(a[t + 1], xx.y, q1);
+            if (t < TP) {                        // compile-time: only these slots can be column k + 1
+              const bool hit = mine && t == kpt;
+              s0 = fma(hit ? 0.0 : xx.x, xx.x, s0);
+              akp1 = hit ? rt_val(a[t]) : akp1;
+            } else {
+              s0 = fma(xx.x, xx.x, s0);
+            }
+            if (t + 1 < TP) {
+              const bool hit = mine && t + 1 == kpt;
+              s1 = fma(hit ? 0.0 : xx.y, xx.y, s1);
+              akp1 = hit ? rt_val(a[t + 1]) : akp1;
+            } else {
+              s1 = fma(xx.y, xx.y, s1);
+            }
+          }
+        }
+      }
+      q = q0 + q1; ss = s0 + s1;
+      q += rt_partner(q);
+      ss += rt_partner(ss);                  // both lanes of a pair add the same two numbers: identical in every lane
+      akp1 += rt_partner(akp1);              // one of the two is zero
+    }
+    const double x0 = X[kp & 1][kpt];
+    // a finished wave needs no scalars: it writes p = 0 and v = x = 0 for its rows (already there from its last live step)
+    const Reflector hh = live ? rt_reflector(x0, ss) : Reflector{0.0, 0.0, 0.0};
+    if (row == kp && h == 0) od[k] = hh.alpha;           // row k + 1's wave is live at step k (row k's is not when k % 32 == 31)
+    const double vi = row == kp ? hh.v0 : X[row & 1][row >> 1];
+    // v = x - alpha e_{k+1}  ->  A v = A x - alpha A[:, k + 1];   tau = 0 (nothing to annihilate): p = 0, the step is a no-op
+    const double pi = (live && row > k) ? hh.tau * (q - hh.alpha * akp1) : 0.0;
+    if (h == 0) { sh.p[row & 1][row >> 1] = pi; sh.v[row & 1][row >> 1] = vi; }
+    __syncthreads();
+    if (live) {
+      double c0 = 0.0, c1 = 0.0;
+      double2 pb[2][RT_CHUNK / 2], vb[2][RT_CHUNK / 2];
+#pragma unroll
+      for (int u = 0; u < RT_CHUNK / 2; ++u)
+        if (T0 + 2 * u < NH) {
+          pb[0][u] = *reinterpret_cast<const double2 *>(&sh.p[h][T0 + 2 * u]);
+          vb[0][u] = *reinterpret_cast<const double2 *>(&sh.v[h][T0 + 2 * u]);
+        }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int u = 0; u < RT_CHUNK / 2; ++u)
+            if (T0 + (g + 1) * RT_CHUNK + 2 * u < NH) {
+              pb[(g + 1) & 1][u] = *reinterpret_cast<const double2 *>(&sh.p[h][T0 + (g + 1) * RT_CHUNK + 2 * u]);
+              vb[(g + 1) & 1][u] = *reinterpret_cast<const double2 *>(&sh.v[h][T0 + (g + 1) * RT_CHUNK + 2 * u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RT_CHUNK / 2; ++u)
+          if (T0 + g * RT_CHUNK + 2 * u < NH) {
+            c0 = fma(pb[g & 1][u].x, vb[g & 1][u].x, c0);
+            c1 = fma(pb[g & 1][u].y, vb[g & 1][u].y, c1);
+          }
+      }
+      double c = c0 + c1;
+      c += rt_partner(c);
+      c *= 0.5 * hh.tau;
+      const double ui = pi - 2.0 * c * vi, nvi = -vi, nui = -ui;
+#pragma unroll
+      for (int u = 0; u < RT_CHUNK / 2; ++u)
+        if (T0 + 2 * u < NH) {
+          pb[0][u] = *reinterpret_cast<const double2 *>(&sh.p[h][T0 + 2 * u]);
+          vb[0][u] = *reinterpret_cast<const double2 *>(&sh.v[h][T0 + 2 * u]);
+        }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int u = 0; u < RT_CHUNK / 2; ++u)
+            if (T0 + (g + 1) * RT_CHUNK + 2 * u < NH) {
+              pb[(g + 1) & 1][u] = *reinterpret_cast<const double2 *>(&sh.p[h][T0 + (g + 1) * RT_CHUNK + 2 * u]);
+              vb[(g + 1) & 1][u] = *reinterpret_cast<const double2 *>(&sh.v[h][T0 + (g + 1) * RT_CHUNK + 2 * u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RT_CHUNK / 2; ++u) {
+          const int t = T0 + g * RT_CHUNK + 2 * u;
+          if (t < NH) {
+            a[t] = fma(nui, vb[g & 1][u].x, fma(nvi, pb[g & 1][u].x, a[t]));
+            a[t + 1] = fma(nui, vb[g & 1][u].y, fma(nvi, pb[g & 1][u].y, a[t + 1]));
+          }
+        }
+      }
+    }
+    // (p / v are rewritten only after the next step's first barrier, x alternates between two buffers: no third barrier)
+  }
+}
+
+// NH = register slots per lane: 64 covers D <= 128, 52 covers D <= 104 (the config-2 width 100 with 19 % fewer FMAs and LDS
+// reads per step and fewer registers), 32 covers D <= 64.
+template <int NH, int JLO>
+__device__ __forceinline__ void rt_blocks(double (&a)[NH], int D, int tid, double *__restrict__ dg, double *__restrict__ od,
+                                          RtShared &sh) {
+  if constexpr (JLO < 2 * NH) {
+    rt_block<NH, JLO>(a, D, tid, dg, od, sh);
+    rt_blocks<NH, JLO + RT_BLK>(a, D, tid, dg, od, sh);
+  }
+}
+
+template <int NH>
+__global__ void __launch_bounds__(RT_THREADS, 2)
+tridiag_reg_kernel(const double *__restrict__ G, int D, double *__restrict__ diag, double *__restrict__ offd) {
+  __shared__ __attribute__((aligned(16))) RtShared sh;
+  const int p = blockIdx.x, tid = threadIdx.x, row = tid >> 1, h = tid & 1;
+  const double *Gp = G + (int64_t)p * D * D;
+  double *dg = diag + (int64_t)p * D, *od = offd + (int64_t)p * D;
+  double a[NH];
+#pragma unroll
+  for (int t = 0; t < NH; ++t) a[t] = (row < D && 2 * t + h < D) ? Gp[(int64_t)row * D + 2 * t + h] : 0.0;
+  for (int e = tid; e < (int)(sizeof(RtShared) / sizeof(double)); e += RT_THREADS) reinterpret_cast<double *>(&sh)[e] = 0.0;
+  __syncthreads();
+  rt_blocks<NH, 0>(a, D, tid, dg, od, sh);
+  // the last 2 x 2 block: A[D-2][D-2], A[D-2][D-1] (row D - 2) and A[D-1][D-1] (row D - 1)
+  double e2 = 0.0, e1 = 0.0;
+#pragma unroll
+  for (int t = 0; t < NH; ++t) {
+    e2 = (2 * t + h == D - 2) ? rt_val(a[t]) : e2;
+    e1 = (2 * t + h == D - 1) ? rt_val(a[t]) : e1;
+  }
+  e2 += rt_partner(e2);           // the other lane of the pair contributes 0
+  e1 += rt_partner(e1);
+  if (h == 0) {
+    if (D >= 2 && row == D - 2) { dg[D - 2] = e2; od[D - 2] = e1; }
+    if (row == D - 1) { dg[D - 1] = e1; od[D - 1] = 0.0; }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ bisection
 // Thread j of matrix p brackets the j-th smallest eigenvalue of the symmetric tridiagonal (d, e) with the
 // Sturm sequence of leading principal minors, division-free:
@@ -911,6 +1277,14 @@ IDIFF_API int idiff_centered_gram_f64(const float *S, const double *mean, int P,
     if (int rc = launch_status("centered_gram")) return rc;
     return idiff_symmetrize_upper_f64(G, D, stream);
   }
+  if (D > 48 && D <= SB_COLS && D % 4 == 0 && ((uintptr_t)S & 15) == 0 && !option(OPT_GRAM_SMALL_TILES)) {
+    // batched small matrices (config 2): one workgroup per matrix, S read once, operands centred once
+    static AttrGuard guard;
+    const void *fn = reinterpret_cast<const void *>(gram_small_batched_kernel);
+    if (int rc = set_dynamic_lds_once(guard, &fn, 1, (int)GRAM_SMALL_LDS, "centered_gram")) return rc;
+    hipLaunchKernelGGL(gram_small_batched_kernel, dim3(P), dim3(256), GRAM_SMALL_LDS, st, S, mean, M, D, G);
+    return launch_status("centered_gram");
+  }
   const int tiles = ceil_div(D, GT);
   hipLaunchKernelGGL(gram_kernel, dim3(tiles * (tiles + 1) / 2, P), dim3(256), 0, st, S, mean, M, D, tiles, G, 0, 1);
   hipLaunchKernelGGL(symmetrize_diag_tiles_kernel, dim3(tiles, P), dim3(256), 0, st, G, D);
@@ -979,6 +1353,14 @@ IDIFF_API int idiff_symtridiag_plan(int D) {
 IDIFF_API int idiff_symtridiag_f64(double *G, int P, int D, double *diag, double *offdiag, double *scratch, void *stream) {
   if (!G || !diag || !offdiag || P <= 0 || D <= 0) return fail("symtridiag: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  if (D <= RT_NP && !option(OPT_TRIDIAG_ONESTAGE)) {
+    // register-resident form (a lane pair per row); IDIFF_TRIDIAG_ONESTAGE keeps the LDS-resident kernel for A/B and as the
+    // fail-soft alternative
+    if (D <= 64) hipLaunchKernelGGL(tridiag_reg_kernel<32>, dim3(P), dim3(RT_THREADS), 0, st, G, D, diag, offdiag);
+    else if (D <= 104) hipLaunchKernelGGL(tridiag_reg_kernel<52>, dim3(P), dim3(RT_THREADS), 0, st, G, D, diag, offdiag);
+    else hipLaunchKernelGGL(tridiag_reg_kernel<64>, dim3(P), dim3(RT_THREADS), 0, st, G, D, diag, offdiag);
+    return launch_status("tridiag_reg");
+  }
   if (D <= SMALL_D_MAX) {
     const size_t lds = small_lds_bytes(D);
     if (lds > 64 * 1024) {

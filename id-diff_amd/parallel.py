@@ -60,11 +60,14 @@ def visible_devices():
 
 def check_world(requested, world, need_devices=True):
     """A world that is not the one asked for is an error, never a warning: a scaling run whose ``--gpus 8`` leg silently ran
-    one rank would report a one-GPU number under an eight-GPU label."""
+    one rank would report a one-GPU number under an eight-GPU label.  With ``need_devices`` this rank's device ordinal
+    (LOCAL_RANK) must exist -- except under IDIFF_DIST_BACKEND=gloo, the rehearsal mode in which several ranks share one card."""
     if world != requested:
         raise SystemExit(f"error: --gpus {requested} but the launcher started WORLD_SIZE {world} rank(s)")
-    if need_devices and visible_devices() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
-        raise SystemExit(f"error: {world} devices needed, {visible_devices()} visible")
+    local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    if need_devices and os.environ.get("IDIFF_DIST_BACKEND") != "gloo" and visible_devices() <= local_rank:
+        raise SystemExit(f"error: {int(os.environ.get('LOCAL_WORLD_SIZE', world))} devices needed, {visible_devices()} visible "
+                         f"(LOCAL_RANK {local_rank} has no device)")
 
 
 def launch_local_ranks(script, argv, n, need_devices=True, timeout=None):

@@ -338,6 +338,20 @@ def _bench_two_ranks_worker(rank, world, port, q):
     q.put((rank, line))
 
 
+def _get_from_live_workers(q, procs, timeout):
+    """q.get that fails as soon as a worker has died without an answer (a dead rank used to leave the test silent for the
+    whole timeout, which the GPU box reads as a hang)."""
+    import queue
+    t_end = time.monotonic() + timeout
+    while time.monotonic() < t_end:
+        try:
+            return q.get(timeout=2)
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"a worker exited with {dead} before answering"
+    raise AssertionError(f"no answer from the workers within {timeout} s")
+
+
 def test_bench_main_two_ranks_real_workload_one_gpu():
     """bench.main() with the REAL config-3 workload at world size 2 (two processes sharing this card, gloo moving the
     device tensors): barrier / timed region / exchange of spectra and int32 IDs / all-reduce-MAX of the time / rank-0-only
@@ -349,7 +363,7 @@ def test_bench_main_two_ranks_real_workload_one_gpu():
     procs = [ctx.Process(target=_bench_two_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=900) for _ in range(2))
+    got = dict(_get_from_live_workers(q, procs, 900) for _ in range(2))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

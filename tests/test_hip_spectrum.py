@@ -406,3 +406,63 @@ def test_row_sharded_pipeline_two_processes_one_gpu():
         assert err < 5e-6, (rank, err)
         assert err32 < 1e-4 and err64 < 1e-4 and same_id, (rank, err32, err64, same_id)
         assert err_t < 1e-4, (rank, err_t)
+
+
+def _batched_gram_and_tridiag(S):
+    """(mean, G, diag, offd) of a batch through the raw C entry points (the order idiff_spectrum_f32 runs them in)."""
+    P, M, D = S.shape
+    lib = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    mean = torch.empty(P, D, dtype=torch.float64, device=DEV)
+    scratch = torch.empty(P * 32 * D, dtype=torch.float64, device=DEV)
+    assert lib.idiff_colmean_f64(S.data_ptr(), P, M, D, mean.data_ptr(), scratch.data_ptr(), st) == 0
+    G = torch.empty(P, D, D, dtype=torch.float64, device=DEV)
+    assert lib.idiff_centered_gram_f64(S.data_ptr(), mean.data_ptr(), P, M, D, G.data_ptr(), st) == 0
+    diag, offd = torch.empty(P, D, dtype=torch.float64, device=DEV), torch.empty(P, D, dtype=torch.float64, device=DEV)
+    Gw = G.clone()                                                          # the tridiagonalisation consumes its input
+    assert lib.idiff_symtridiag_f64(Gw.data_ptr(), P, D, diag.data_ptr(), offd.data_ptr(), None, st) == 0
+    return mean, G, diag, offd
+
+
+@pytest.mark.parametrize("P,M,D", [(5, 1501, 100), (3, 333, 64), (4, 700, 112), (3, 90, 52), (2, 257, 128), (3, 50, 20), (2, 33, 96),
+                                   (2, 40, 31), (3, 9, 3), (2, 6, 2), (2, 5, 1)])
+def test_batched_small_kernels_vs_the_forms_they_replace(P, M, D):
+    """Config-2 kernels (round 4): gram_small_batched_kernel (one workgroup per matrix, operands centred once) must equal the
+    64 x 64-tile kernel BIT FOR BIT (same k-steps in the same order) and an fp64 matmul to rounding; tridiag_reg_kernel (rows in
+    registers, a lane pair per row) must give a tridiagonal with the eigenvalues of G (fp64 eigvalsh, 1e-13 of the largest) and
+    agree with the LDS-resident form it replaces to the same bar.  Shapes: the config-2 size, widths on both sides of every
+    block boundary of the two kernels (64, 112 | 52 -> the old Gram kernel, 128, 96 = six full blocks, 31 / 3 / 2 / 1: one
+    partly filled block and the degenerate ends), M not a multiple of the 32-row stage."""
+    g = torch.Generator().manual_seed(P * 1000 + M + D)
+    S = (torch.randn(P, M, D, generator=g) * torch.linspace(0.2, 3.0, D) + 0.7).to(DEV)
+    mean, G, diag, offd = _batched_gram_and_tridiag(S)
+    with _lib.thread_option("IDIFF_GRAM_SMALL_TILES", 1), _lib.thread_option("IDIFF_TRIDIAG_ONESTAGE", 1):
+        mean_o, G_o, diag_o, offd_o = _batched_gram_and_tridiag(S)
+    assert torch.equal(G, G_o) and torch.equal(G, G.transpose(1, 2))
+    c = S.double() - mean[:, None, :]
+    ref = c.transpose(1, 2) @ c
+    assert float((G - ref).abs().max() / ref.abs().max()) < 1e-13
+    assert bool(torch.isfinite(diag).all()) and bool(torch.isfinite(offd).all())
+    for p in range(P):
+        lam = np.linalg.eigvalsh(G[p].cpu().numpy())
+        scale = max(abs(lam).max(), 1e-300)
+        for d, o in ((diag[p], offd[p]), (diag_o[p], offd_o[p])):
+            d, o = d.cpu().numpy(), o.cpu().numpy()
+            T = np.diag(d) + np.diag(o[:D - 1], 1) + np.diag(o[:D - 1], -1)
+            assert np.abs(np.linalg.eigvalsh(T) - lam).max() < 1e-13 * scale
+
+
+def test_register_tridiag_on_matrices_that_need_no_reflection():
+    """tau = 0 steps (a column that is already tridiagonal) are no-ops with the same barrier count: a diagonal matrix, a
+    tridiagonal one and the zero matrix come back unchanged."""
+    D = 100
+    lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    dvals = torch.linspace(1.0, 7.0, D, dtype=torch.float64)
+    evals = torch.linspace(-0.5, 0.5, D - 1, dtype=torch.float64)
+    mats = torch.stack([torch.diag(dvals), torch.diag(dvals) + torch.diag(evals, 1) + torch.diag(evals, -1),
+                        torch.zeros(D, D, dtype=torch.float64)]).to(DEV)
+    diag, offd = torch.empty(3, D, dtype=torch.float64, device=DEV), torch.empty(3, D, dtype=torch.float64, device=DEV)
+    assert lib.idiff_symtridiag_f64(mats.clone().data_ptr(), 3, D, diag.data_ptr(), offd.data_ptr(), None, st) == 0
+    assert torch.equal(diag[0].cpu(), dvals) and float(offd[0].abs().max()) == 0.0
+    assert torch.equal(diag[1].cpu(), dvals) and torch.equal(offd[1, :D - 1].cpu().abs(), evals.abs())
+    assert float(diag[2].abs().max()) == 0.0 and float(offd[2].abs().max()) == 0.0
