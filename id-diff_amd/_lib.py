@@ -35,6 +35,10 @@ _SIGNATURES = {
     "idiff_set_thread_option": (c_i, [ctypes.c_char_p, c_i, c_i]),
     "idiff_upfirdn2d_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 14 + [c_p]),
     "idiff_fused_bias_act_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "idiff_upfirdn2d_f16": (c_i, [c_p, c_p, c_p] + [c_i] * 14 + [c_p]),
+    "idiff_upfirdn2d_f64": (c_i, [c_p, c_p, c_p] + [c_i] * 14 + [c_p]),
+    "idiff_fused_bias_act_f16": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
+    "idiff_fused_bias_act_f64": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "idiff_gemm_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i,
                              ctypes.POINTER(Epilogue), c_p]),
     "idiff_gemm_2src_f32": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_i64, c_p, c_i64, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),
@@ -205,10 +209,27 @@ def make_epilogue(bias=None, rowbias=None, rows_per_group=1, act=None, residual=
 
 
 # ------------------------------------------------------------------------------------------- native ops
+# the dtypes of the reference's native-op dispatch (AT_DISPATCH_FLOATING_TYPES_AND_HALF) -> entry-point suffix
+OP_DTYPES = {torch.float32: "f32", torch.float16: "f16", torch.float64: "f64"}
+
+
+def op_suffix(t, name):
+    """Entry-point suffix for a native-op tensor; any other dtype is refused as the reference's dispatch refuses it."""
+    try:
+        return OP_DTYPES[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"{name}: dtype {t.dtype} is not one of float32 / float16 / float64 (the reference's native ops "
+                           "dispatch on floating types and half, op/upfirdn2d_kernel.cu:311)") from None
+
+
 def upfirdn2d_raw(x, k, out, major, in_h, in_w, minor, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
     kh, kw = k.shape
-    _check(lib().idiff_upfirdn2d_f32(x.data_ptr(), k.data_ptr(), out.data_ptr(), major, in_h, in_w, minor, kh, kw,
-                                     up_x, up_y, down_x, down_y, px0, px1, py0, py1, _stream()), "idiff_upfirdn2d_f32")
+    sfx = op_suffix(x, "upfirdn2d")
+    if k.dtype != x.dtype or out.dtype != x.dtype:
+        raise RuntimeError(f"upfirdn2d: input {x.dtype}, kernel {k.dtype} and output {out.dtype} must share one dtype")
+    fn = getattr(lib(), "idiff_upfirdn2d_" + sfx)
+    _check(fn(x.data_ptr(), k.data_ptr(), out.data_ptr(), major, in_h, in_w, minor, kh, kw,
+              up_x, up_y, down_x, down_y, px0, px1, py0, py1, _stream()), "idiff_upfirdn2d_" + sfx)
 
 
 def upfirdn2d_out_size(in_size, up, down, pad0, pad1, k):
@@ -216,24 +237,25 @@ def upfirdn2d_out_size(in_size, up, down, pad0, pad1, k):
 
 
 def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
-    _dev(x, "input")
+    sfx = op_suffix(x, "fused_bias_act")
+    _dev(x, "input", dtype=x.dtype)
     out = torch.empty_like(x)
     has_b = bias is not None and bias.numel() > 0
     has_r = ref is not None and ref.numel() > 0
     if has_b:
-        _dev(bias, "bias")
+        _dev(bias, "bias", dtype=x.dtype)
         if x.ndim < 2 or bias.numel() != x.shape[1]:
             raise RuntimeError(f"bias has {bias.numel()} entries but input dim 1 is {tuple(x.shape)}")
     if has_r:
-        _dev(ref, "refer")
+        _dev(ref, "refer", dtype=x.dtype)
         if ref.shape != x.shape:
             raise RuntimeError("refer must have the shape of input")
     step_b = 1
     for d in x.shape[2:]:
         step_b *= d
-    _check(lib().idiff_fused_bias_act_f32(x.data_ptr(), _ptr(bias if has_b else None), _ptr(ref if has_r else None),
-                                          out.data_ptr(), x.numel(), step_b, bias.numel() if has_b else 0, act, grad,
-                                          alpha, scale, _stream()), "idiff_fused_bias_act_f32")
+    _check(getattr(lib(), "idiff_fused_bias_act_" + sfx)(x.data_ptr(), _ptr(bias if has_b else None), _ptr(ref if has_r else None),
+                                                         out.data_ptr(), x.numel(), step_b, bias.numel() if has_b else 0, act, grad,
+                                                         alpha, scale, _stream()), "idiff_fused_bias_act_" + sfx)
     return out
 
 

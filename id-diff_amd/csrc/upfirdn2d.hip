@@ -441,7 +441,83 @@ upfirdn2d_generic(const float *__restrict__ x, const float *__restrict__ k, floa
   }
 }
 
+// The same walk for the other two dtypes of the reference's dispatch (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// op/upfirdn2d_kernel.cu:311): T = _Float16 with fp32 products and accumulation, rounded ONCE to half on the way out, and
+// T = double with fp64 products and accumulation.  (The reference's CUDA kernels are not one arithmetic: its tiled kernels
+// stage samples and taps in `float` LDS arrays, .cu:115-116, and add each fp32 product to a scalar_t accumulator -- per-tap
+// rounding to half, fp32 products under an fp64 accumulator -- while its generic kernel multiplies in scalar_t, .cu:85.  The
+// parity target is the CPU path, upfirdn2d_native in the tensor's dtype, op/upfirdn2d.py:159-200, which this form matches to
+// the last half ulp / to fp64 rounding.)
+template <typename T, typename ACC>
+__global__ void __launch_bounds__(256)
+upfirdn2d_generic_t(const T *__restrict__ x, const T *__restrict__ k, T *__restrict__ out, UfdParams p, int64_t total) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(v % p.minor);
+    int64_t pix = v / p.minor;
+    int ox = (int)(pix % p.out_w);
+    int64_t t = pix / p.out_w;
+    int oy = (int)(t % p.out_h);
+    int64_t plane = t / p.out_h;
+    const int by = oy * p.down_y - p.pad_y0, bx = ox * p.down_x - p.pad_x0;
+    const int iy_lo = max(ceil_div_s(by, p.up_y), 0), iy_hi = min(floor_div(by + p.kh - 1, p.up_y), p.in_h - 1);
+    const int ix_lo = max(ceil_div_s(bx, p.up_x), 0), ix_hi = min(floor_div(bx + p.kw - 1, p.up_x), p.in_w - 1);
+    ACC acc = (ACC)0;
+    for (int iy = iy_lo; iy <= iy_hi; ++iy) {
+      const int ky = iy * p.up_y - by;
+      for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+        const int kx = ix * p.up_x - bx;
+        acc += (ACC)x[((plane * p.in_h + iy) * p.in_w + ix) * p.minor + c] * (ACC)k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+      }
+    }
+    out[v] = (T)acc;
+  }
+}
+
+// argument checks and output geometry shared by the three dtypes; returns 0 and fills p, or an error code
+int ufd_geometry(const void *x, const void *k, const void *out, int major, int in_h, int in_w, int minor, int kh, int kw, int up_x,
+                 int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, UfdParams &p) {
+  using namespace idiff;
+  if (!x || !k || !out) return fail("upfirdn2d: null pointer");
+  if (major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0)
+    return fail("upfirdn2d: bad shape major=%d in=%dx%d minor=%d k=%dx%d", major, in_h, in_w, minor, kh, kw);
+  if (up_x < 1 || up_y < 1 || down_x < 1 || down_y < 1) return fail("upfirdn2d: up/down factors must be >= 1");
+  p.major = major; p.in_h = in_h; p.in_w = in_w; p.minor = minor; p.kh = kh; p.kw = kw;
+  p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.pad_x0 = pad_x0; p.pad_y0 = pad_y0;
+  const int span_h = in_h * up_y + pad_y0 + pad_y1 - kh, span_w = in_w * up_x + pad_x0 + pad_x1 - kw;
+  if (span_h < 0 || span_w < 0) return fail("upfirdn2d: kernel larger than padded input");
+  p.out_h = span_h / down_y + 1;
+  p.out_w = span_w / down_x + 1;
+  return 0;
+}
+
+template <typename T, typename ACC>
+int ufd_launch_t(const void *x, const void *k, void *out, int major, int in_h, int in_w, int minor, int kh, int kw, int up_x, int up_y,
+                 int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void *stream, const char *what) {
+  UfdParams p;
+  if (int rc = ufd_geometry(x, k, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, p))
+    return rc;
+  if (major == 0) return 0;
+  const int64_t total = (int64_t)major * p.out_h * p.out_w * minor;
+  hipLaunchKernelGGL((upfirdn2d_generic_t<T, ACC>), dim3(idiff::streaming_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const T *)x, (const T *)k, (T *)out, p, total);
+  return idiff::launch_status(what);
+}
+
 }  // namespace
+
+IDIFF_API int idiff_upfirdn2d_f16(const void *x, const void *k, void *out, int major, int in_h, int in_w, int minor, int kh, int kw,
+                                  int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                  void *stream) {
+  return ufd_launch_t<_Float16, float>(x, k, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
+                                       pad_y1, stream, "upfirdn2d_f16");
+}
+
+IDIFF_API int idiff_upfirdn2d_f64(const double *x, const double *k, double *out, int major, int in_h, int in_w, int minor, int kh,
+                                  int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                  void *stream) {
+  return ufd_launch_t<double, double>(x, k, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
+                                      pad_y1, stream, "upfirdn2d_f64");
+}
 
 IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, int major, int in_h, int in_w,
                                   int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,

@@ -49,7 +49,8 @@ class FusedLeakyReLUFunction(Function):
 
 
 def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
-    _lib._dev(input, "input", contiguous=False)
+    _lib.op_suffix(input, "fused_leaky_relu")
+    _lib._dev(input, "input", dtype=input.dtype, contiguous=False)
     if not (torch.is_grad_enabled() and (input.requires_grad or (bias is not None and bias.requires_grad))):
         # nothing to differentiate (inference under no_grad, or plain tensors): the autograd.Function wrapper was most of
         # the 13 us host floor of this op on small tensors

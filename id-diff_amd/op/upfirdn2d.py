@@ -12,14 +12,14 @@ from .. import _lib
 
 
 def _launch(x4, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
-    """x4: [N, C, H, W] contiguous CUDA fp32 -> [N, C, out_h, out_w]."""
+    """x4: [N, C, H, W] contiguous CUDA fp32 / fp16 / fp64 -> [N, C, out_h, out_w] of the same dtype."""
     n, c, in_h, in_w = x4.shape
     kh, kw = kernel.shape
     out_h = _lib.upfirdn2d_out_size(in_h, up_y, down_y, pad_y0, pad_y1, kh)
     out_w = _lib.upfirdn2d_out_size(in_w, up_x, down_x, pad_x0, pad_x1, kw)
     if out_h <= 0 or out_w <= 0:
         raise RuntimeError("upfirdn2d: empty output")
-    out = torch.empty((n, c, out_h, out_w), device=x4.device, dtype=torch.float32)
+    out = torch.empty((n, c, out_h, out_w), device=x4.device, dtype=x4.dtype)
     _lib.upfirdn2d_raw(x4, kernel, out, n * c, in_h, in_w, 1, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
     return out
 
@@ -72,12 +72,14 @@ class UpFirDn2d(Function):
 
 def upfirdn2d_xy(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
     """Separate x/y factors, as the native entry point takes them (op/upfirdn2d.cpp:12-19)."""
-    _lib._dev(input, "input", contiguous=False)
+    _lib.op_suffix(input, "upfirdn2d")
+    _lib._dev(input, "input", dtype=input.dtype, contiguous=False)
     if input.ndim != 4:
         raise RuntimeError(f"upfirdn2d: expected [N, C, H, W], got {tuple(input.shape)}")
     if kernel.ndim != 2:
         raise RuntimeError(f"upfirdn2d: expected a 2-D FIR kernel, got {tuple(kernel.shape)}")
-    kernel = _lib._dev(kernel.detach().to(device=input.device, dtype=torch.float32).contiguous(), "kernel")
+    # the reference reads the FIR kernel through data_ptr<scalar_t>() of the INPUT's dtype (op/upfirdn2d_kernel.cu:315-317)
+    kernel = _lib._dev(kernel.detach().to(device=input.device, dtype=input.dtype).contiguous(), "kernel", dtype=input.dtype)
     if not (torch.is_grad_enabled() and input.requires_grad):
         # nothing to differentiate: one native call, no autograd.Function around it (host time matters on small tensors)
         return _launch(input.contiguous(), kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)

@@ -73,6 +73,24 @@ int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, int major, i
 int idiff_fused_bias_act_f32(const float *x, const float *b, const float *ref, float *out, int64_t n,
                              int step_b, int size_b, int act, int grad, float alpha, float scale, void *stream);
 
+/* The other two dtypes of the reference's native-op dispatch (AT_DISPATCH_FLOATING_TYPES_AND_HALF: op/upfirdn2d_kernel.cu:311,
+ * op/fused_bias_act_kernel.cu:79).  Same arguments and geometry as the _f32 entry points; the FIR kernel / bias / ref tensors carry
+ * the input's dtype, as the reference's `data_ptr<scalar_t>()` calls require.  f16 pointers are IEEE binary16 (torch.float16).
+ *   upfirdn2d:      f16 = fp32 products and accumulation, rounded once to half (the CPU path's arithmetic, op/upfirdn2d.py:159-200;
+ *                   the reference's CUDA kernels round per tap in one of two ways depending on the kernel chosen); f64 = fp64
+ *                   products and accumulation (its tiled kernels form fp32 products under an fp64 accumulator, .cu:115-116,198).
+ *   fused_bias_act: the reference kernel's scalar_t arithmetic operation by operation: alpha and scale are converted to the
+ *                   tensor's dtype first (.cu:19), then x = r(x + b), y = x > 0 ? x : r(x * alpha), out = r(y * scale) with r =
+ *                   rounding to the dtype. */
+int idiff_upfirdn2d_f16(const void *x, const void *k, void *out, int major, int in_h, int in_w, int minor, int kh, int kw,
+                        int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void *stream);
+int idiff_upfirdn2d_f64(const double *x, const double *k, double *out, int major, int in_h, int in_w, int minor, int kh, int kw,
+                        int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void *stream);
+int idiff_fused_bias_act_f16(const void *x, const void *b, const void *ref, void *out, int64_t n, int step_b, int size_b,
+                             int act, int grad, float alpha, float scale, void *stream);
+int idiff_fused_bias_act_f64(const double *x, const double *b, const double *ref, double *out, int64_t n, int step_b,
+                             int size_b, int act, int grad, float alpha, float scale, void *stream);
+
 /* ------------------------------------------------------------------ dense contractions (fp32 in, fp32 out) */
 
 /* Activation codes shared by the epilogues below. */

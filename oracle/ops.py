@@ -70,3 +70,34 @@ def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
     ``negative_slope`` (fused_act.py:91); the CUDA branch honours it.
     """
     return fused_bias_act_ref(x, bias, None, act=3, grad=0, alpha=0.2, scale=scale)
+
+
+def fused_bias_act_native(x, bias=None, ref=None, act=3, grad=0, alpha=0.2, scale=2 ** 0.5):
+    """The CUDA kernel's arithmetic for ANY dtype of its dispatch (float16 / float32 / float64), in numpy.
+
+    /root/reference/op/fused_bias_act_kernel.cu:18-49 computes in ``scalar_t``; the op's ``float alpha, float scale``
+    arguments (fused_bias_act.cpp:11-12) are converted to scalar_t at the launch (:80-93), so alpha and scale are
+    first rounded to fp32 and then to the tensor's dtype.  Every operation rounds to the dtype (c10::Half's operators
+    widen to fp32, operate, round back -- which is what numpy's float16 arithmetic does too):
+    x = r(x + b);  y = x > 0 ? x : r(x * alpha)  (``ref > 0`` for grad = 1);  out = r(y * scale).
+    Takes and returns numpy arrays (or torch CPU tensors, converted)."""
+    import numpy as np
+    as_np = lambda t: None if t is None else (t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t))
+    x, bias, ref = as_np(x), as_np(bias), as_np(ref)
+    dt = x.dtype
+    a, s = np.float32(alpha).astype(dt), np.float32(scale).astype(dt)
+    y = x
+    if bias is not None and bias.size > 0:
+        y = (y + bias.astype(dt).reshape([1, bias.size] + [1] * (x.ndim - 2))).astype(dt)
+    mode = act * 10 + grad
+    if mode in (10, 11):
+        pass
+    elif mode == 30:
+        y = np.where(y > 0, y, (y * a).astype(dt))
+    elif mode == 31:
+        y = np.where(ref > 0, y, (y * a).astype(dt))
+    elif mode in (12, 32):
+        y = np.zeros_like(y)
+    else:
+        raise ValueError(f"unsupported act/grad {act}/{grad}")
+    return (y * s).astype(dt)

@@ -182,6 +182,46 @@ def gen_fused_act():
     save("fused_act.npz", **out)
 
 
+def gen_ops_dtypes():
+    """The two native ops in the other dtypes of the reference's dispatch (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+    op/upfirdn2d_kernel.cu:311, op/fused_bias_act_kernel.cu:79), produced by the reference's CPU branches run in that dtype:
+    upfirdn2d_native (op/upfirdn2d.py:159-200) on float64 and on float16 tensors, fused_leaky_relu's CPU branch
+    (op/fused_act.py:87-94) likewise.  Inputs are drawn in fp32 and rounded to the dtype, so the fixtures hold exactly
+    representable values."""
+    g = torch.Generator().manual_seed(4321)
+    fir = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float64)
+    fir /= fir.sum()
+    asym4 = torch.randn(4, 4, generator=g).numpy().astype(np.float64)
+    asym3 = torch.randn(3, 3, generator=g).numpy().astype(np.float64)
+    spec = [
+        (2, 3, 8, 8, fir, 1, 2, 1, 1),          # downsample_2d family
+        (2, 3, 8, 8, fir, 1, 1, 2, 2),          # FIR before the stride-2 conv
+        (2, 3, 4, 4, fir * 4, 2, 1, 2, 1),      # upsample_2d family
+        (1, 2, 7, 5, asym4, 1, 1, 0, 0),        # asymmetric kernel: the flip
+        (1, 2, 9, 6, asym3, 1, 2, 0, 1),
+        (2, 2, 5, 7, asym4, 2, 2, 2, 1),
+        (1, 2, 8, 9, asym3, 1, 1, -1, -2),      # negative pads crop
+        (1, 4, 33, 17, fir, 1, 2, 1, 1),        # odd sizes
+    ]
+    out = {"n_cases": np.array(len(spec))}
+    for name, dt in (("f64", torch.float64), ("f16", torch.float16)):
+        for i, (n, c, h, w, k, up, down, p0, p1) in enumerate(spec):
+            x = torch.randn(n, c, h, w, generator=g).to(dt)
+            kt = torch.from_numpy(np.ascontiguousarray(k)).to(dt)
+            y = upfirdn2d_native(x, kt, up, up, down, down, p0, p1, p0, p1)
+            assert y.dtype == dt and torch.equal(y, ref_op.upfirdn2d(x, kt, up=up, down=down, pad=(p0, p1)))
+            out[f"ufd::{name}::c{i}::x"], out[f"ufd::{name}::c{i}::k"], out[f"ufd::{name}::c{i}::y"] = x.numpy(), kt.numpy(), y.numpy()
+            out[f"ufd::c{i}::params"] = np.array([up, down, p0, p1], dtype=np.int64)
+        for i, shp in enumerate([(2, 5, 7, 3), (4, 8), (3, 8, 4), (1, 1, 1, 1)]):
+            x = (torch.randn(*shp, generator=g) * 3).to(dt)
+            b = torch.randn(shp[1], generator=g).to(dt)
+            y = ref_op.fused_leaky_relu(x, b, negative_slope=0.2, scale=1.25)
+            assert y.dtype == dt
+            out[f"fba::{name}::c{i}::x"], out[f"fba::{name}::c{i}::b"], out[f"fba::{name}::c{i}::y_scale1.25"] = x.numpy(), b.numpy(), y.numpy()
+        out["fba::n_cases"] = np.array(4)
+    save("ops_dtypes.npz", **out)
+
+
 def gen_sde_extra():
     """The two other SDEs configure_sde can build (BaseSdeGenerativeModel.py:33-35, 44-46): subVPSDE takes the VP branch of
     get_score_fn (models/utils.py:238-255); SNRSDE has a branch of its own (:270-277, fixture: gen_snr)."""
@@ -683,8 +723,8 @@ def gen_conditional():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "sde", "sde_extra", "fcn", "ncsnpp", "ksphere", "svd", "beatgans", "ddpm", "vp", "snr", "wide", "conditional"]
-    table = {"upfirdn2d": gen_upfirdn2d, "fused_act": gen_fused_act, "sde": gen_sde, "fcn": gen_fcn,
+    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "ops_dtypes", "sde", "sde_extra", "fcn", "ncsnpp", "ksphere", "svd", "beatgans", "ddpm", "vp", "snr", "wide", "conditional"]
+    table = {"upfirdn2d": gen_upfirdn2d, "fused_act": gen_fused_act, "ops_dtypes": gen_ops_dtypes, "sde": gen_sde, "fcn": gen_fcn,
              "sde_extra": gen_sde_extra, "ncsnpp": gen_ncsnpp, "ksphere": gen_ksphere, "svd": gen_svd_and_rule, "beatgans": gen_beatgans, "ddpm": gen_ddpm, "vp": gen_vp, "snr": gen_snr, "wide": gen_wide,
              "conditional": gen_conditional}
     for w in which:

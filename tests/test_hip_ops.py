@@ -625,3 +625,70 @@ def test_fused_leaky_relu_backward():
     m = op.FusedLeakyReLU(6).to(DEV)
     m(xd).sum().backward()
     assert m.bias.grad is not None and m.bias.grad.shape == (6,)
+
+
+# ---- the other dtypes of the reference's native-op dispatch (AT_DISPATCH_FLOATING_TYPES_AND_HALF), round 4
+@pytest.mark.parametrize("name,dtype", [("f64", torch.float64), ("f16", torch.float16)])
+def test_native_ops_other_dtypes_golden(golden, name, dtype):
+    """op.upfirdn2d / op.fused_leaky_relu on float64 and float16 tensors against the REFERENCE's CPU branches run in that
+    dtype (tests/golden/ops_dtypes.npz).  upfirdn2d: fp64 to rounding; fp16 = fp32 accumulation rounded once, the CPU path's
+    arithmetic, equal to the last half ulp (1e-3).  fused_leaky_relu follows the reference's CUDA kernel (alpha and scale
+    reach it as `float` and are converted to the tensor's dtype, op/fused_bias_act_kernel.cu:19,80-93): BIT-equal to the numpy
+    restatement of that arithmetic (oracle.ops.fused_bias_act_native), and within the rounding of alpha of the CPU branch."""
+    z = golden("ops_dtypes.npz")
+    for i in range(int(z["n_cases"])):
+        up, down, p0, p1 = [int(v) for v in z[f"ufd::c{i}::params"]]
+        x, k = torch.from_numpy(z[f"ufd::{name}::c{i}::x"]), torch.from_numpy(z[f"ufd::{name}::c{i}::k"])
+        y = op.upfirdn2d(x.to(DEV), k.to(DEV), up=up, down=down, pad=(p0, p1))
+        ref = torch.from_numpy(z[f"ufd::{name}::c{i}::y"])
+        assert y.dtype == dtype and y.shape == ref.shape
+        if dtype == torch.float64:
+            torch.testing.assert_close(y.cpu(), ref, rtol=1e-13, atol=1e-14)
+        else:
+            torch.testing.assert_close(y.cpu().float(), ref.float(), rtol=1e-3, atol=1e-3 * float(ref.float().abs().max()) * 0.5)
+    for i in range(int(z["fba::n_cases"])):
+        x, b = torch.from_numpy(z[f"fba::{name}::c{i}::x"]), torch.from_numpy(z[f"fba::{name}::c{i}::b"])
+        y = op.fused_leaky_relu(x.to(DEV), b.to(DEV), 0.2, 1.25)
+        assert y.dtype == dtype
+        nat = oops.fused_bias_act_native(x, b, None, 3, 0, 0.2, 1.25)
+        assert np.array_equal(y.cpu().numpy(), nat), f"{name} case {i}: not the CUDA kernel's arithmetic"
+        tol = 2e-8 if dtype == torch.float64 else 2.5e-3
+        np.testing.assert_allclose(y.cpu().numpy().astype(np.float64), z[f"fba::{name}::c{i}::y_scale1.25"].astype(np.float64),
+                                   rtol=tol, atol=tol * 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float16])
+@pytest.mark.parametrize("shape,act,grad", [((3, 8, 5, 8), 3, 0), ((3, 8, 5, 8), 3, 1), ((2, 7, 3), 3, 0), ((5, 6), 1, 0), ((3, 8, 16), 3, 2),
+                                            ((128, 128, 32, 32), 3, 0)])
+def test_fused_bias_act_other_dtypes_every_mode(dtype, shape, act, grad):
+    """Every act/grad mode, vector (16 bytes per lane) and scalar geometries, and the SURVEY 8(a7) activation size, bit for
+    bit against the numpy restatement of the reference kernel's scalar_t arithmetic."""
+    g = torch.Generator().manual_seed(len(shape) * 10 + act + grad)
+    x = (torch.randn(*shape, generator=g) * 2).to(dtype)
+    b = torch.randn(shape[1], generator=g).to(dtype)
+    ref = torch.randn(*shape, generator=g).to(dtype)
+    y = _lib.fused_bias_act(x.to(DEV), b.to(DEV), ref.to(DEV) if grad == 1 else None, act, grad, 0.17, 1.3)
+    want = oops.fused_bias_act_native(x, b, ref if grad == 1 else None, act, grad, 0.17, 1.3)
+    assert y.dtype == dtype and np.array_equal(y.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float16])
+@pytest.mark.parametrize("shape,up,down,pad", [((128, 128, 32, 32), 1, 2, (1, 1)), ((16, 256, 16, 16), 2, 1, (2, 1)),
+                                               ((3, 5, 70, 130), 1, 2, (1, 1)), ((2, 3, 37, 129), 2, 3, (3, 0))])
+def test_upfirdn2d_other_dtypes_vs_oracle(dtype, shape, up, down, pad):
+    """SURVEY 8(a5) shape families and ragged planes in float64 / float16 against the oracle (the reference's CPU recipe in the
+    same dtype); wrong dtypes are refused, mixed dtypes of input and FIR kernel follow the input as in the reference."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g).to(dtype)
+    k = torch.randn(4, 4, generator=g).to(dtype)
+    if dtype == torch.float16 and shape[0] * shape[1] > 4096:
+        x = x[:8]                                   # the CPU half convolution of the oracle is slow: a slice is enough
+    ref = oops.upfirdn2d(x, k, up=up, down=down, pad=pad)
+    y = op.upfirdn2d(x.to(DEV), k.float().to(DEV), up=up, down=down, pad=pad)      # the kernel is converted to the input's dtype
+    assert y.dtype == dtype
+    if dtype == torch.float64:
+        assert rel_err(y.cpu(), ref) < 1e-14
+    else:
+        torch.testing.assert_close(y.cpu().float(), ref.float(), rtol=2e-3, atol=2e-3 * float(ref.float().abs().max()))
+    with pytest.raises(RuntimeError, match="not one of float32"):
+        op.upfirdn2d(x.to(DEV).to(torch.bfloat16), k.to(DEV), up=up, down=down, pad=pad)

@@ -300,3 +300,25 @@ def test_conditional_manifold_dimension(golden):
         np.testing.assert_array_equal(lv["images"], z["images_pkl"])
         # same draws, same ATen kernels; gesdd of a matrix that differs in the last bits
         np.testing.assert_allclose(np.array(lv["singular_values"]), z["singular_values"][i], rtol=2e-5)
+
+
+def test_native_ops_in_float64_and_float16(golden):
+    """The oracle's restatements of the two ops in the other dtypes of the reference's dispatch against the reference's own
+    CPU branches run in that dtype (tests/golden/ops_dtypes.npz): upfirdn2d bit for bit (the same ATen convolution), the
+    fused op's CPU branch bit for bit, and the numpy restatement of the CUDA kernel's arithmetic (alpha / scale rounded to
+    fp32 and then to the dtype, every operation rounded) within the difference that rounding of alpha makes: one half ulp
+    in float16, 2e-8 relative in float64."""
+    z = golden("ops_dtypes.npz")
+    for name, tol in (("f64", 2e-8), ("f16", 2.5e-3)):
+        for i in range(int(z["n_cases"])):
+            up, down, p0, p1 = [int(v) for v in z[f"ufd::c{i}::params"]]
+            x, k = torch.from_numpy(z[f"ufd::{name}::c{i}::x"]), torch.from_numpy(z[f"ufd::{name}::c{i}::k"])
+            y = oops.upfirdn2d(x, k, up=up, down=down, pad=(p0, p1))
+            assert y.dtype == x.dtype and torch.equal(y, torch.from_numpy(z[f"ufd::{name}::c{i}::y"]))
+        for i in range(int(z["fba::n_cases"])):
+            x, b = torch.from_numpy(z[f"fba::{name}::c{i}::x"]), torch.from_numpy(z[f"fba::{name}::c{i}::b"])
+            ref = z[f"fba::{name}::c{i}::y_scale1.25"]
+            assert torch.equal(oops.fused_leaky_relu(x, b, 0.2, 1.25), torch.from_numpy(ref))
+            nat = oops.fused_bias_act_native(x, b, None, 3, 0, 0.2, 1.25)
+            assert nat.dtype == ref.dtype
+            np.testing.assert_allclose(nat.astype(np.float64), ref.astype(np.float64), rtol=tol, atol=tol * 1e-3)
