@@ -51,7 +51,7 @@ HBM_PEAK_GBS = 8000.0
 # >= 2^-16) run on the bf16 matrix cores with fp32 accumulation -- 1.7e-7 against an fp64 contraction where the fp32 MFMA
 # chain gives 2.0e-7 (scripts/bf16x6_probe.hip); every parity bar of tests/ is unchanged.  IDIFF_NO_SPLIT=1 selects fp32 MFMAs.
 DTYPE = "f32" if os.environ.get("IDIFF_NO_SPLIT") else \
-    "f32 (3x3 convs: fp32 MFMA; 1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate)"
+    "f32 (3x3 convs: fp32 MFMA, Winograd F(4x4,3x3) / F(2x2,3x3); 1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate)"
 WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=1e-5, B=128 -> S 4480x3072 + centred spectrum + ID"
 TRAFFIC_TABLE = os.path.join("profiles", "r03_wino_traffic.json")
 WINOGRAD_SOURCE = os.path.join("id-diff_amd", "csrc", "winograd.hip")
@@ -105,6 +105,10 @@ class KernelProbe:
             # executed flops of F(2x2,3x3): 16 positions x [tiles x Cin] x [Cin x Cout]; the implicit GEMM would be 2.25x that
             return "winograd_kernel", 2.0 * 16 * (B * H * W // 4) * Cin * Cout, f"{B}x{H}x{W}x{Cin}->{Cout}"
 
+        def wino43(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+            # executed flops of F(4x4,3x3): 36 positions x [tiles x Cin] x [Cin x Cout]; the implicit GEMM would be 4x that
+            return "winograd43_kernel", 2.0 * 36 * (B * H * W // 16) * Cin * Cout, f"{B}x{H}x{W}x{Cin}->{Cout}"
+
         def gn_apply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None):
             return "gn_apply_rows", 8.0 * B * HW * (C + (C2 or 0)), f"{B}x{HW}x{C + (C2 or 0)}"
 
@@ -134,7 +138,7 @@ class KernelProbe:
         def softmax(x, y, rows, cols, scale):
             return "softmax_rows", 8.0 * rows * cols, f"{rows}x{cols}"
 
-        for name, fn in (("conv2d_winograd", wino), ("groupnorm_apply", gn_apply), ("groupnorm_apply_colstats", gn_apply_cs),
+        for name, fn in (("conv2d_winograd", wino), ("conv2d_winograd43", wino43), ("groupnorm_apply", gn_apply), ("groupnorm_apply_colstats", gn_apply_cs),
                          ("gemm", gemm), ("gemm_2src", gemm_2src),
                          ("upfirdn2d_raw", ufd), ("softmax_rows", softmax)):
             self._wrap(name, fn)
@@ -175,12 +179,19 @@ def winograd_traffic(keys):
 
 
 def roofline_report(probe):
-    dom = probe.group("winograd_kernel")
+    dom43, dom22 = probe.group("winograd43_kernel"), probe.group("winograd_kernel")
+    dom = dom43 or dom22
     if dom is None:
         return None
     tfl = dom["rate"] / 1e12
-    traffic = winograd_traffic(dom["keys"])
+    # the PMC traffic table was measured on the F(2x2,3x3) kernel; the F(4x4,3x3) kernel has none yet
+    traffic = winograd_traffic(dom["keys"]) if dom43 is None else None
     kernels = []
+    if dom43 is not None and dom22 is not None:
+        t22 = dom22["rate"] / 1e12
+        kernels.append({"kernel": "winograd_kernel (F(2x2,3x3): the 4x4 maps and launches too small for the 4x4 form)", "bound": "mfma",
+                        "achieved": t22, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": t22 / FP32_MFMA_PEAK_TFLOPS,
+                        "launches_sampled": dom22["launches"], "avg_launch_us": dom22["avg_us"]})
     for name in ("gn_apply_rows", "igemm_pipe_kernel K<=128 (1x1 / NIN)", "igemm_pipe_kernel K>=256 (1x1 / NIN / attention products)",
                  "igemm_pipe_kernel two-source shortcut", "upfirdn2d_nhwc", "softmax_rows"):
         g = probe.group(name)
@@ -205,11 +216,18 @@ def roofline_report(probe):
         else:
             kernels.append({"kernel": name, "bound": "hbm", "achieved": g["rate"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": g["rate"] / 1e9 / HBM_PEAK_GBS, "launches_sampled": g["launches"], "avg_launch_us": g["avg_us"]})
-    return {"bound": "mfma", "kernel": "winograd_kernel (3x3 conv as F(2x2,3x3): 16 [tiles x Cin] x [Cin x Cout] contractions per launch, "
-                                       "v_mfma_f32_32x32x2_f32)",
+    if dom43 is not None:
+        name = ("winograd43_kernel (3x3 conv as F(4x4,3x3): 36 [tiles x Cin] x [Cin x Cout] contractions per launch, "
+                "v_mfma_f32_32x32x2_f32)")
+        counted, ratio = "executed Winograd-domain multiply-adds (the implicit GEMM of the same conv is 4x more)", 4.0
+    else:
+        name = ("winograd_kernel (3x3 conv as F(2x2,3x3): 16 [tiles x Cin] x [Cin x Cout] contractions per launch, "
+                "v_mfma_f32_32x32x2_f32)")
+        counted, ratio = "executed Winograd-domain multiply-adds (the implicit GEMM of the same conv is 2.25x more)", 2.25
+    return {"bound": "mfma", "kernel": name,
             "achieved": tfl, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP32_MFMA_PEAK_TFLOPS,
-            "flops_counted": "executed Winograd-domain multiply-adds (the implicit GEMM of the same conv is 2.25x more)",
-            "direct_conv_equivalent_tflops": tfl * 2.25,
+            "flops_counted": counted,
+            "direct_conv_equivalent_tflops": tfl * ratio,
             "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
             "launches_sampled": dom["launches"], "avg_launch_us": dom["avg_us"],
             "sampled_in": "a second, untimed pass over the same points (spectrum overlap on, as in the timed region)",
@@ -592,12 +610,9 @@ def main(argv=None, workload_factory=Workload):
                        "launched_by": ("bench.py (self-launched rank processes)" if os.environ.get("IDIFF_SELF_LAUNCHED")
                                        else "external launcher" if parallel.launched() else "single process")},
             "id_estimates": ids, "id_estimates_all_ranks": alldims.tolist(),
-            # SURVEY 8(d)'s 21.79 GFLOP/eval counts the 3x3 convs as direct convolutions; the Winograd kernels EXECUTE 2.25x
-            # fewer multiply-adds on them (10.87 GFLOP/eval), which is why the first figure can exceed the fp32 MFMA peak
         }
         if dev.type == "cuda":
             line["model_tflops_per_gpu_direct_conv_equivalent"] = rows * args.steps * 21.79e9 / elapsed / 1e12
-            line["model_tflops_per_gpu_executed"] = rows * args.steps * 10.87e9 / elapsed / 1e12
             line["svd_wall_clock_ms_per_point"] = svd_ms
             line["roofline"] = roofline
             if world == 1 and not args.no_extras:

@@ -1,0 +1,508 @@
+// 3x3 / stride 1 / pad 1 convolutions by Winograd's F(4x4, 3x3) on the fp32 matrix cores of gfx950: 36 multiplications per
+// 4x4 output tile and (cin, cout) pair = 2.25 per output, where F(2x2, 3x3) (winograd.hip) spends 4 and the implicit GEMM 9.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      d: 6x6 input patch at (4ty-1, 4tx-1), Y: 4x4 outputs at (4ty, 4tx)
+//
+// Interpolation points 0, +-1/2, +-2, infinity.  Measured before this file was written (scripts/f43_emulation.py, CPU emulation of
+// the whole nf = 128 NCSN++ with every eligible convolution in this form, fp32 transforms and contraction): per layer 1.0-1.5e-6
+// against an fp64 convolution (F(2x2,3x3): 3e-7; Lavin's points 0, +-1, +-2: 2.2e-6), rel_err(S) 5e-6 against an fp64 network (bar
+// 2e-5), every singular value above 2e-5 sigma_max within 1e-4 -- the round-1 estimate "loses two decimal digits" was wrong.  All
+// transform constants are dyadic (1/8 ... 8, 4.25): the transforms round like plain fp32 additions.
+//
+//   B^T rows (input transform, t = B^T d):            A^T rows (output transform, y = A^T m):
+//     t0 = d0 - 4.25 d2 + d4                              y0 = m0 + (m1 + m2) + (m3 + m4)
+//     t1 = (d4 - 4 d2) + (0.5 d3 - 2 d1)                  y1 = 0.5 (m1 - m2) + 2 (m3 - m4)
+//     t2 = (d4 - 4 d2) - (0.5 d3 - 2 d1)                  y2 = 0.25 (m1 + m2) + 4 (m3 + m4)
+//     t3 = (d4 - 0.25 d2) + (2 d3 - 0.5 d1)               y3 = 0.125 (m1 - m2) + 8 (m3 - m4) + m5
+//     t4 = (d4 - 0.25 d2) - (2 d3 - 0.5 d1)
+//     t5 = d1 - 4.25 d3 + d5                           G rows: (1,0,0), (-8,-4,-2)/15, (-8,4,-2)/15, (1,2,4)/30, (1,-2,4)/30, (0,0,1)
+//
+//   U = G g G^T is packed once per layer (idiff_winograd43_pack_f32, fp64, rounded once) as [Cin/8][Cout/64][36 slots][64 cout]
+//   [8 cin]; V = B^T d B is formed by the loader between L2 and LDS; M_p = V_p U_p^T for the 36 positions p = (i, j) (slot 6 i + j)
+//   are 36 independent [tiles x Cin] x [Cin x Cout] contractions on v_mfma_f32_32x32x2_f32.
+//
+// Workgroup: 512 threads = 8 waves, 32 tiles x 64 output channels of ALL 36 positions (73,728 accumulators: more than half of a
+//   CU's register file, so ONE workgroup per CU, two waves per SIMD).  Wave (h, q): output-channel half h and the 3x3 block of
+//   positions rows 3 (q >> 1) .., columns 3 (q & 1) ..: 9 positions x [32 tiles x 32 channels] = 144 accumulators.
+// K loop: 8 input channels per step; per wave 36 MFMAs from 9 sixteen-byte LDS reads of V and 9 sixteen-byte global loads of U
+//   (a ring of three register sets, each re-requested three positions ahead), two LDS stages of V, one barrier per step.
+// Loader (all 8 waves): lanes in groups of 8 = the rows r of the 6x6 patch of one (tile, 4-channel quad) unit (lanes 6, 7 of a
+//   group idle): six 16-byte loads (the row), the 6-point transform along x in registers (14 ops per component), the x-mixed row
+//   to a wave-private LDS scratch, then lane c of the group reads COLUMN c of the unit back (6 x 16 bytes), transforms along y
+//   and writes V(0..5, c) to the stage.  The scratch exchange needs no workgroup barrier: DS operations of a wave are in order.
+//   Waves w and w + 4 share a SIMD: the first four transform at the start of a step, the others before their last positions.
+// Tail: a wave's block holds 3 of the 6 columns of a transform row, so the row mixing z_{i,b} = sum_j A^T[b][j] m_{i,j} is done in
+//   two parts: the waves of column block 1 park their part in LDS, those of block 0 add theirs on top ([6 i][32 tiles][2 b][64 cout]
+//   fp32 = 96 KB per pass over the dead stages, two passes: output columns b = 0, 1 and b = 2, 3); then every thread owns one
+//   (tile, 4-channel group) and finishes y_{a,b} = sum_i A^T[a][i] z_{i,b} with the fused epilogue and 16-byte stores.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+
+constexpr int F4_TILES = 32;
+constexpr int F4_THREADS = 512;
+constexpr int F4_COUT = 64;
+constexpr int F4_KC = 8;
+constexpr int F4_NPOS = 36;
+constexpr int F4_OPER_FLOATS = F4_NPOS * 64 * F4_KC;     // one 8-channel slab of U for 64 output channels: 18432 floats = 72 KB
+constexpr int F4_VSLOT = F4_TILES * F4_KC + 4;           // 260 = 4 mod 32: the six columns a lane group writes fall on distinct banks
+constexpr int F4_STAGE = F4_NPOS * F4_VSLOT;             // 9360 floats
+constexpr int F4_SCR_ROW = 7 * 4;                        // scratch row: 6 float4 + one of padding (28 dwords: rows on distinct banks)
+constexpr int F4_SCR_UNIT = 6 * F4_SCR_ROW;              // 168 floats
+constexpr int F4_SCR_WAVE = 8 * F4_SCR_UNIT;             // 1344 floats per wave
+constexpr int F4_SCRATCH = 8 * F4_SCR_WAVE;              // 10752 floats
+constexpr int F4_Z_FLOATS = 6 * F4_TILES * 2 * F4_COUT;  // the tail's exchange: [6 rows][tiles][2 columns][64 cout] = 24576 floats
+constexpr int F4_LOOP_FLOATS = 2 * F4_STAGE + F4_SCRATCH + 8;   // + 8: lane 7 of the last group reads one float4 past its unit
+constexpr size_t F4_LDS_BYTES = sizeof(float) * (size_t)(F4_LOOP_FLOATS > F4_Z_FLOATS ? F4_LOOP_FLOATS : F4_Z_FLOATS);   // 117,888 B
+constexpr int64_t F4_X_LIMIT = 0xFFFF0000ll;
+constexpr uint32_t F4_INVALID = 0xFFFF8000u;             // beyond any valid extent (the scalar step offset is not range-checked)
+
+struct Wino43Params {
+  const float *x;
+  const float *u;
+  float *out;
+  int B, H, W, Cin, Cout;
+  int tiles_x, tiles_y, tiles_per_img, total_tiles;
+  int tx_shift, tpi_shift;        // log2 of tiles_x / tiles_per_img when both are powers of two, else -1 (division)
+  int tiles_m, tiles_n, ngroup;
+  uint32_t x_bytes, u_bytes, out_bytes, res_bytes;
+  idiff_epilogue ep;
+  int has_ep;
+};
+
+__device__ __forceinline__ void f4_split_tile(const Wino43Params &p, int T, int &img, int &ty, int &tx) {
+  if (p.tx_shift >= 0) {
+    img = T >> p.tpi_shift;
+    const int rem = T & (p.tiles_per_img - 1);
+    ty = rem >> p.tx_shift; tx = rem & (p.tiles_x - 1);
+  } else {
+    img = T / p.tiles_per_img;
+    const int rem = T - img * p.tiles_per_img;
+    ty = rem / p.tiles_x; tx = rem - ty * p.tiles_x;
+  }
+}
+
+// the 6-point input transform t = B^T d on one component (14 operations)
+__device__ __forceinline__ void f4_bt(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
+                                      float &t0, float &t1, float &t2, float &t3, float &t4, float &t5) {
+  const float pe = fmaf(-4.f, d2, d4), po = fmaf(0.5f, d3, -2.f * d1);
+  const float re = fmaf(-0.25f, d2, d4), ro = fmaf(2.f, d3, -0.5f * d1);
+  t0 = fmaf(-4.25f, d2, d0 + d4);
+  t1 = pe + po; t2 = pe - po;
+  t3 = re + ro; t4 = re - ro;
+  t5 = fmaf(-4.25f, d3, d1 + d5);
+}
+__device__ __forceinline__ void f4_bt4(const float4 (&d)[6], float4 (&t)[6]) {
+  f4_bt(d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x, t[0].x, t[1].x, t[2].x, t[3].x, t[4].x, t[5].x);
+  f4_bt(d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y, t[0].y, t[1].y, t[2].y, t[3].y, t[4].y, t[5].y);
+  f4_bt(d[0].z, d[1].z, d[2].z, d[3].z, d[4].z, d[5].z, t[0].z, t[1].z, t[2].z, t[3].z, t[4].z, t[5].z);
+  f4_bt(d[0].w, d[1].w, d[2].w, d[3].w, d[4].w, d[5].w, t[0].w, t[1].w, t[2].w, t[3].w, t[4].w, t[5].w);
+}
+
+// one wave exchanging data through LDS with itself: DS operations of a wave execute in order; the compiler must neither
+// reorder nor cache across this point
+__device__ __forceinline__ void f4_wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ void __launch_bounds__(F4_THREADS, 2)   // two waves per SIMD: one 512-thread workgroup per CU
+winograd43_kernel(const Wino43Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int per_group = p.tiles_m * p.ngroup;
+  const int grp = bid / per_group, in_grp = bid - grp * per_group;
+  const int tile_n = grp * p.ngroup + in_grp % p.ngroup, tile_m = in_grp / p.ngroup;
+  const int tile0 = tile_m * F4_TILES, n0 = tile_n * F4_COUT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wh = wave >> 2, wq = wave & 3, wa = wq >> 1, wb = wq & 1;     // cout half, row block, column block
+
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
+
+  // ---------------------------------------------------------------- loader state
+  const int lr = lane & 7, lg = lane >> 3;            // patch row / column index, unit within the wave
+  const bool lact = lr < 6;
+  const int unit = wave * 8 + lg, ltile = unit >> 1, lq = unit & 1;
+  uint32_t v_src[6];
+  {
+    const int T = tile0 + ltile;
+    const bool tv = lact && T < p.total_tiles;
+    int img, ty, tx;
+    f4_split_tile(p, tv ? T : 0, img, ty, tx);
+    const int y = 4 * ty - 1 + lr, x0 = 4 * tx - 1;
+    const bool yok = tv && y >= 0 && y < p.H;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int xx = x0 + c;
+      v_src[c] = (yok && xx >= 0 && xx < p.W) ? (uint32_t)(((img * p.H + y) * p.W + xx) * p.Cin + lq * 4) * 4u : F4_INVALID;
+    }
+  }
+  float *scr_row = lds + 2 * F4_STAGE + wave * F4_SCR_WAVE + lg * F4_SCR_UNIT + lr * F4_SCR_ROW;   // my row, as the writer
+  const float *scr_col = lds + 2 * F4_STAGE + wave * F4_SCR_WAVE + lg * F4_SCR_UNIT + lr * 4;       // my column, as the reader
+  // V(i, c = lr) of (ltile, quad lq): slot 6 i + lr, row ltile, 16-byte half lq swapped when bit 3 of the tile is set
+  const int v_dst = lr * F4_VSLOT + ltile * F4_KC + 4 * (lq ^ ((ltile >> 3) & 1));
+
+  float4 ldv[6];
+  const int nsteps = p.Cin / F4_KC;
+  int f_step = 0;
+  auto fetch = [&]() {
+    const int choff = min(f_step, nsteps - 1) * (F4_KC * 4);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ldv[c] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)v_src[c], choff, 0));
+    ++f_step;
+  };
+  auto stage = [&](int buf) {
+    float4 t[6];
+    f4_bt4(ldv, t);                                   // along x
+    if (lact) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) *reinterpret_cast<float4 *>(scr_row + 4 * c) = t[c];
+    }
+    f4_wave_lds_sync();
+    float4 d[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const float4 *>(scr_col + r * F4_SCR_ROW);
+    f4_bt4(d, t);                                     // along y
+    f4_wave_lds_sync();                               // the scratch is free again before this wave's next stage()
+    if (lact) {
+      float *Vd = lds + buf * F4_STAGE + v_dst;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) *reinterpret_cast<float4 *>(Vd + 6 * i * F4_VSLOT) = t[i];
+    }
+  };
+
+  floatx16 acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int frag = fr * F4_KC + 4 * (fh ^ ((fr >> 3) & 1));
+  const int pos0 = (3 * wa) * 6 + 3 * wb;            // slot of this wave's first position
+  const int a_frag = pos0 * F4_VSLOT + frag;
+  // U: [step][cout tile][slot][64 cout][8 cin]; lane (fr, fh) takes cout wh * 32 + fr, the 16-byte half fh (swapped like V)
+  const uint32_t u_lane = (uint32_t)(((wh * 32 + fr) * 8 + 4 * (fh ^ ((fr >> 3) & 1))) * 4);
+  float4 bfr[3];
+  auto load_b = [&](int pp, int step) {              // pp = 0 .. 8: position (pp / 3, pp % 3) of the block
+    const int slot = pos0 + (pp / 3) * 6 + (pp % 3);
+    const int soff = ((step * p.tiles_n + tile_n) * F4_NPOS + slot) * (64 * F4_KC * 4);
+    bfr[pp % 3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane, soff, 0));
+  };
+  auto mfma4 = [&](int pp, const float4 a) {
+    const float4 b = bfr[pp % 3];
+    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[pp], 0, 0, 0);
+    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[pp], 0, 0, 0);
+    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[pp], 0, 0, 0);
+    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[pp], 0, 0, 0);
+  };
+  auto v_at = [&](const float *S, int pp) { return *reinterpret_cast<const float4 *>(S + ((pp / 3) * 6 + (pp % 3)) * F4_VSLOT); };
+  auto compute = [&](int buf, int s, auto before_last) {
+    const float *S = lds + buf * F4_STAGE + a_frag;
+    const int snext = min(s + 1, nsteps - 1);
+    float4 f0 = v_at(S, 0), f1 = v_at(S, 1);
+#pragma unroll
+    for (int pp = 0; pp < 9; ++pp) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (pp == 6) { before_last(); __builtin_amdgcn_sched_barrier(0); }
+      mfma4(pp, (pp & 1) ? f1 : f0);
+      // the register set is free once these MFMAs have read it: request the position three ahead (of the next step beyond 8;
+      // the last step re-requests its own slab: clamped, not skipped -- the scalar offset of a raw buffer is not range-checked)
+      if (pp + 3 < 9) load_b(pp + 3, s); else load_b(pp + 3 - 9, snext);
+      if (pp + 2 < 9) { if (pp & 1) f1 = v_at(S, pp + 2); else f0 = v_at(S, pp + 2); }
+    }
+  };
+  auto step = [&](int s, auto is_early) {
+    const int buf = s & 1;
+    if constexpr (decltype(is_early)::value) {
+      stage(buf ^ 1); fetch();
+      compute(buf, s, [] {});
+    } else {
+      compute(buf, s, [&] { stage(buf ^ 1); fetch(); });
+    }
+    __syncthreads();
+  };
+
+  load_b(0, 0); load_b(1, 0); load_b(2, 0);
+  fetch();
+  stage(0);
+  fetch();
+  __syncthreads();
+  if (wave < 4) { for (int s = 0; s < nsteps; ++s) step(s, std::true_type()); }
+  else { for (int s = 0; s < nsteps; ++s) step(s, std::false_type()); }
+
+  // ---------------------------------------------------------------- tail
+  const idiff_epilogue &ep = p.ep;
+  const bool has_ep = p.has_ep != 0;
+  const int cq = tid & 15, tl = tid >> 4;            // this thread finishes channels n .. n + 3 of tile tl
+  const int n = n0 + 4 * cq;
+  const bool has_res = has_ep && ep.residual != nullptr;
+  const bool scaled = has_ep && (ep.out_scale != 1.f || ep.rowscale != nullptr);
+  const int act = has_ep ? ep.act : (int)IDIFF_ACT_NONE;
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)ep.residual, 0, (int)p.res_bytes, 0x00020000);
+  const int ld_res = (int)ep.ld_residual;
+  // this thread's output addresses and per-tile epilogue operands: formed again at the start of each output phase (about 30
+  // instructions) rather than kept in registers under the accumulators
+  uint32_t ooff, roff;
+  float4 badd;
+  float sc;
+  auto prep = [&]() {
+    badd = make_float4(0.f, 0.f, 0.f, 0.f);
+    sc = has_ep ? ep.out_scale : 1.f;
+    const int T = tile0 + tl;
+    const bool ok = T < p.total_tiles;
+    int img, ty, tx;
+    f4_split_tile(p, ok ? T : 0, img, ty, tx);
+    const int m00 = (img * p.H + 4 * ty) * p.W + 4 * tx;
+    ooff = ok ? ((uint32_t)m00 * (uint32_t)p.Cout + (uint32_t)n) * 4u : F4_INVALID;
+    roff = ok ? ((uint32_t)m00 * (uint32_t)ld_res + (uint32_t)n) * 4u : F4_INVALID;
+    if (has_ep && ep.bias) badd = *reinterpret_cast<const float4 *>(ep.bias + n);
+    if (has_ep && ok) {
+      if (ep.rowbias) {
+        const float4 rb = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)img * ep.ld_rowbias + n);
+        badd.x += rb.x; badd.y += rb.y; badd.z += rb.z; badd.w += rb.w;
+      }
+      if (ep.rowscale) sc *= ep.rowscale[img];
+    }
+  };
+
+  const bool want_stats = has_ep && ep.colstats != nullptr;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};    // column sums of this thread's 16 pixels x 4 channels
+  // accumulator register `reg` of lane l is tile row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), cout wh * 32 + (l & 31)
+  float *zbase = lds + (size_t)(4 * (lane >> 5)) * 2 * F4_COUT + wh * 32 + (lane & 31);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    // z_{i,b} for b = 2 pass, 2 pass + 1 and the three rows i of this wave's block: column block 1 parks, block 0 adds
+    if (pass) __syncthreads();                       // every z of the first pass has been read
+    if (wb == 1) {
+#pragma unroll
+      for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const float m3 = acc[ii * 3][reg], m4 = acc[ii * 3 + 1][reg], m5 = acc[ii * 3 + 2][reg];
+          const int trow = (reg & 3) + 8 * (reg >> 2);
+          float *zp = zbase + (((3 * wa + ii) * F4_TILES + trow) * 2) * F4_COUT;
+          if (pass == 0) { zp[0] = m3 + m4; zp[F4_COUT] = 2.f * (m3 - m4); }
+          else { zp[0] = 4.f * (m3 + m4); zp[F4_COUT] = fmaf(8.f, m3 - m4, m5); }
+        }
+    }
+    __syncthreads();
+    if (wb == 0) {
+#pragma unroll
+      for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const float m0 = acc[ii * 3][reg], m1 = acc[ii * 3 + 1][reg], m2 = acc[ii * 3 + 2][reg];
+          const int trow = (reg & 3) + 8 * (reg >> 2);
+          float *zp = zbase + (((3 * wa + ii) * F4_TILES + trow) * 2) * F4_COUT;
+          if (pass == 0) { zp[0] += m0 + (m1 + m2); zp[F4_COUT] = fmaf(0.5f, m1 - m2, zp[F4_COUT]); }
+          else { zp[0] = fmaf(0.25f, m1 + m2, zp[0]); zp[F4_COUT] = fmaf(0.125f, m1 - m2, zp[F4_COUT]); }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    prep();
+#pragma unroll 1
+    for (int bb = 0; bb < 2; ++bb) {                 // rolled: the two columns do not need their operands in flight together
+      const float *zr = lds + (tl * 2 + bb) * F4_COUT + 4 * cq;
+      float4 z[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) z[i] = *reinterpret_cast<const float4 *>(zr + i * (F4_TILES * 2 * F4_COUT));
+      float4 res[4];
+      const int b = 2 * pass + bb;
+      if (has_res) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          res[a] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)roff, (a * p.W + b) * ld_res * 4, 0));
+      }
+      float y[4][4];
+#define IDIFF_F4_AT(cmp, e)                                                                                  \
+      {                                                                                                      \
+        const float s12 = z[1].cmp + z[2].cmp, d12 = z[1].cmp - z[2].cmp, s34 = z[3].cmp + z[4].cmp, d34 = z[3].cmp - z[4].cmp; \
+        y[0][e] = z[0].cmp + (s12 + s34);                                                                     \
+        y[1][e] = fmaf(2.f, d34, 0.5f * d12);                                                                 \
+        y[2][e] = fmaf(4.f, s34, 0.25f * s12);                                                                \
+        y[3][e] = fmaf(8.f, d34, fmaf(0.125f, d12, z[5].cmp));                                                \
+      }
+      IDIFF_F4_AT(x, 0) IDIFF_F4_AT(y, 1) IDIFF_F4_AT(z, 2) IDIFF_F4_AT(w, 3)
+#undef IDIFF_F4_AT
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        y[a][0] += badd.x; y[a][1] += badd.y; y[a][2] += badd.z; y[a][3] += badd.w;
+        if (act != IDIFF_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[a][e] = idiff::act_apply(y[a][e], act);
+        }
+        if (has_res) { y[a][0] += res[a].x; y[a][1] += res[a].y; y[a][2] += res[a].z; y[a][3] += res[a].w; }
+        if (scaled) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[a][e] *= sc;
+        }
+      }
+      if (want_stats) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1[e] += (double)y[a][e]; s2[e] += (double)y[a][e] * (double)y[a][e]; }
+      }
+      // the four rows are stored together from registers nothing writes again before the next column: a store whose data
+      // registers were recomputed for the next row a few instructions later wrote that row's first component in some lanes
+      const int so = b * p.Cout * 4, rp = p.W * p.Cout * 4;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, make_float4(y[a][0], y[a][1], y[a][2], y[a][3])), rO, (int)ooff,
+                                               so + a * rp, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (want_stats) {
+    // Per-tile partial sums meet in LDS ([32 tiles][64 channels][2] fp64 = 32 KB over the dead z area); one thread per (sample
+    // or workgroup, channel) adds the tiles up in a fixed order.  Layout of epilogue.colstats as for the 2x2 form:
+    // [samples][nsplit][Cout][2], nsplit = tiles_per_img / 32 workgroups per sample, or -- maps of fewer than 32 tiles -- one slot
+    // per sample with 32 / tiles_per_img whole samples per workgroup.
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(lds);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[((tl * F4_COUT) + 4 * cq + e) * 2] = s1[e];
+      red[((tl * F4_COUT) + 4 * cq + e) * 2 + 1] = s2[e];
+    }
+    __syncthreads();
+    const int per = p.tiles_per_img < F4_TILES ? p.tiles_per_img : F4_TILES;      // tiles added up per slot
+    const int slots = F4_TILES / per;
+    for (int o = tid; o < slots * F4_COUT; o += F4_THREADS) {
+      const int smp = o / F4_COUT, ch = o - smp * F4_COUT;
+      const int64_t slot = (int64_t)tile_m * slots + smp;                           // sample, or (sample, split) = workgroup row
+      if (slots > 1 && slot >= p.B) continue;
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < per; ++k) { a += red[((smp * per + k) * F4_COUT + ch) * 2]; b += red[((smp * per + k) * F4_COUT + ch) * 2 + 1]; }
+      double *dst = ep.colstats + (slot * p.Cout + n0 + ch) * 2;
+      dst[0] = a; dst[1] = b;
+    }
+  }
+}
+
+// U = G g G^T in fp64, rounded once; g[ky][kx] = wt[cout][ky][kx][cin] (the K-contiguous panel of the direct kernel)
+__global__ void winograd43_pack_kernel(const float *wt, float *u, int Cin, int Cout) {
+  const double G[6][3] = {{1.0, 0.0, 0.0},
+                          {-8.0 / 15.0, -4.0 / 15.0, -2.0 / 15.0},
+                          {-8.0 / 15.0, 4.0 / 15.0, -2.0 / 15.0},
+                          {1.0 / 30.0, 2.0 / 30.0, 4.0 / 30.0},
+                          {1.0 / 30.0, -2.0 / 30.0, 4.0 / 30.0},
+                          {0.0, 0.0, 1.0}};
+  const int64_t total = (int64_t)Cin * Cout;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cin = (int)(idx % Cin), cout = (int)(idx / Cin);
+    double g[3][3];
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)wt[((int64_t)cout * 9 + ky * 3 + kx) * Cin + cin];
+    double gg[6][3];   // G g
+    for (int i = 0; i < 6; ++i)
+      for (int kx = 0; kx < 3; ++kx) gg[i][kx] = G[i][0] * g[0][kx] + G[i][1] * g[1][kx] + G[i][2] * g[2][kx];
+    const int s = cin / F4_KC, c8 = cin % F4_KC, nt = cout / F4_COUT, co = cout % F4_COUT;
+    const int slot8 = 4 * ((c8 >> 2) ^ ((co >> 3) & 1)) + (c8 & 3);
+    float *dst = u + ((int64_t)(s * (Cout / F4_COUT) + nt) * F4_NPOS * 64 + co) * F4_KC + slot8;
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        const double v = gg[i][0] * G[j][0] + gg[i][1] * G[j][1] + gg[i][2] * G[j][2];
+        dst[(int64_t)(6 * i + j) * 64 * F4_KC] = (float)v;
+      }
+  }
+}
+
+bool f4_geometry_ok(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return false;
+  if (H % 4 || W % 4 || Cin % F4_KC || Cout % F4_COUT) return false;
+  if ((int64_t)Cin * 4 > 0x7000) return false;                               // channel offset must stay below the invalid-pixel bias
+  if ((int64_t)36 * Cin * Cout * 4 >= F4_X_LIMIT) return false;
+  if ((int64_t)B * (H / 4) * (W / 4) > 0x7fffffff / 4) return false;
+  if ((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) * 4 >= F4_X_LIMIT) return false;   // one buffer descriptor per tensor
+  return true;
+}
+
+}  // namespace
+
+IDIFF_API int idiff_conv2d_winograd43_ok(int B, int H, int W, int Cin, int Cout) {
+  if (idiff::option(idiff::OPT_NO_WINOGRAD) || idiff::option(idiff::OPT_NO_WINO43)) return 0;
+  return f4_geometry_ok(B, H, W, Cin, Cout) ? 1 : 0;
+}
+
+// nsplit of epilogue.colstats ([samples, nsplit, Cout, 2]) or 0 when this form cannot produce the statistics
+IDIFF_API int idiff_conv2d_winograd43_colstats_split(int B, int H, int W, int Cin, int Cout) {
+  if (!idiff_conv2d_winograd43_ok(B, H, W, Cin, Cout) || idiff::option(idiff::OPT_NO_COLSTATS)) return 0;
+  const int tpi = (H / 4) * (W / 4);
+  if (tpi % F4_TILES == 0) return tpi / F4_TILES;
+  return (F4_TILES % tpi == 0) ? 1 : 0;              // whole samples per workgroup
+}
+
+IDIFF_API int64_t idiff_winograd43_weight_floats(int Cin, int Cout) { return (int64_t)36 * Cin * Cout; }
+
+IDIFF_API int idiff_winograd43_pack_f32(const float *wt, float *u, int Cin, int Cout, void *stream) {
+  using namespace idiff;
+  if (Cin <= 0 || Cout <= 0 || Cin % F4_KC || Cout % F4_COUT)
+    return fail("winograd43_pack: Cin must be a multiple of %d and Cout of %d (got %d, %d)", F4_KC, F4_COUT, Cin, Cout);
+  if (!wt || !u) return fail("winograd43_pack: null pointer");
+  const int64_t total = (int64_t)Cin * Cout;
+  hipLaunchKernelGGL(winograd43_pack_kernel, dim3(streaming_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, wt, u, Cin, Cout);
+  return launch_status("winograd43_pack");
+}
+
+IDIFF_API int idiff_conv2d_winograd43_colstats_split(int B, int H, int W, int Cin, int Cout);
+IDIFF_API int idiff_conv2d_winograd43_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
+                                          const idiff_epilogue *ep, void *stream) {
+  using namespace idiff;
+  if (B == 0) return 0;
+  if (!f4_geometry_ok(B, H, W, Cin, Cout))
+    return fail("conv2d_winograd43: geometry B=%d H=%d W=%d Cin=%d Cout=%d not supported (ask idiff_conv2d_winograd43_ok)", B, H, W, Cin, Cout);
+  if (!x || !u || !out) return fail("conv2d_winograd43: null pointer");
+  if (((uintptr_t)x & 15) || ((uintptr_t)u & 15) || ((uintptr_t)out & 15)) return fail("conv2d_winograd43: x, u and out must be 16-byte aligned");
+  if (ep && ep->colstats && idiff_conv2d_winograd43_colstats_split(B, H, W, Cin, Cout) <= 0)
+    return fail("conv2d_winograd43: colstats needs whole workgroups per sample or whole samples per workgroup "
+                "(ask idiff_conv2d_winograd43_colstats_split)");
+  if (ep && (ep->rowbias || ep->rowscale) && ep->rows_per_group != H * W)
+    return fail("conv2d_winograd43: per-row-group bias / scale only per image (rows_per_group = H * W = %d, got %d)", H * W, ep->rows_per_group);
+  if (ep && ep->residual && (((uintptr_t)ep->residual & 15) || ep->ld_residual % 4 || ep->ld_residual < Cout || ep->ld_residual > 0x7fffffff / 4))
+    return fail("conv2d_winograd43: residual must be 16-byte aligned with a row pitch >= Cout that is a multiple of 4");
+  const int64_t res_bytes = (ep && ep->residual) ? (int64_t)B * H * W * ep->ld_residual * 4 : 0;
+  if (res_bytes >= F4_X_LIMIT) return fail("conv2d_winograd43: residual beyond one buffer descriptor");
+  Wino43Params p = {};
+  p.x = x; p.u = u; p.out = out; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.tiles_x = W / 4; p.tiles_y = H / 4; p.tiles_per_img = p.tiles_x * p.tiles_y; p.total_tiles = B * p.tiles_per_img;
+  p.tx_shift = p.tpi_shift = -1;
+  if ((p.tiles_x & (p.tiles_x - 1)) == 0 && (p.tiles_per_img & (p.tiles_per_img - 1)) == 0) {
+    p.tx_shift = __builtin_ctz((unsigned)p.tiles_x); p.tpi_shift = __builtin_ctz((unsigned)p.tiles_per_img);
+  }
+  p.tiles_m = ceil_div(p.total_tiles, F4_TILES); p.tiles_n = Cout / F4_COUT;
+  {
+    const int want = option_value(OPT_WINO_NGROUP);
+    p.ngroup = (want > 0 && p.tiles_n % want == 0) ? want : ((p.tiles_n > 2 && p.tiles_n % 2 == 0) ? 2 : p.tiles_n);
+  }
+  p.x_bytes = (uint32_t)((int64_t)B * H * W * Cin * 4); p.u_bytes = (uint32_t)((int64_t)36 * Cin * Cout * 4);
+  p.out_bytes = (uint32_t)((int64_t)B * H * W * Cout * 4); p.res_bytes = (uint32_t)res_bytes;
+  if (ep) {
+    p.ep = *ep; p.has_ep = 1;
+    if (p.ep.rows_per_group <= 0) p.ep.rows_per_group = 1;
+  } else {
+    p.has_ep = 0; p.ep.rows_per_group = 1; p.ep.out_scale = 1.f;
+  }
+  static AttrGuard guard;
+  const void *fn = reinterpret_cast<const void *>(winograd43_kernel);
+  if (int rc = set_dynamic_lds_once(guard, &fn, 1, (int)F4_LDS_BYTES, "conv2d_winograd43")) return rc;
+  hipLaunchKernelGGL(winograd43_kernel, dim3(p.tiles_m * p.tiles_n), dim3(F4_THREADS), F4_LDS_BYTES, (hipStream_t)stream, p);
+  return launch_status("conv2d_winograd43");
+}

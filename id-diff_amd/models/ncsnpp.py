@@ -166,6 +166,19 @@ class _T:
 
 
 # ------------------------------------------------------------------------------------------------------------
+# launches of fewer workgroups than this stay on the F(2x2, 3x3) kernel (tests set it to 1 to send small batches through F(4x4, 3x3))
+WINO43_MIN_WORKGROUPS = 512
+
+
+def _winograd43_pays(B, H, W, cin, cout):
+    """F(4x4, 3x3) where it is served AND faster than F(2x2, 3x3): a workgroup takes 32 tiles of 4x4 pixels x 64 channels and a
+    CU holds one, so maps of 4x4 pixels (one tile per sample) or launches of fewer than two workgroups per CU stay on the 2x2
+    form (measured 0.87x there, 1.2-1.33x elsewhere: profiles/r04_wino43_time.txt)."""
+    if H < 8 or W < 8 or not _lib.conv2d_winograd43_ok(B, H, W, cin, cout):
+        return False
+    return ((B * (H // 4) * (W // 4) + 31) // 32) * (cout // 64) >= WINO43_MIN_WORKGROUPS
+
+
 @utils.register_model(name='ncsnpp')
 class NCSNpp(HipScoreModel):
     def __init__(self, config):
@@ -371,6 +384,18 @@ class NCSNpp(HipScoreModel):
         y = self._new(B, OH, OW, cout, x.buf)
         if "rows_per_group" not in ep:
             ep["rows_per_group"] = OH * OW
+        if (kh, kw, stride, pad, ph) == (3, 3, 1, 1, 1) and ep["rows_per_group"] == OH * OW and _winograd43_pays(B, x.H, x.W, cin, cout):
+            # Winograd F(4x4, 3x3): 2.25 multiplications per output (F(2x2, 3x3) below: 4, the implicit GEMM: 9)
+            bank = self._packed.setdefault("wino43", {})
+            if id(wt) not in bank:
+                bank[id(wt)] = (wt, _lib.winograd43_pack(wt, cin, cout))
+            if stats:
+                ns = _lib.conv2d_winograd43_colstats_split(B, x.H, x.W, cin, cout)
+                if ns > 0:
+                    y.stats = (torch.empty(B * ns * cout * 2, device=x.buf.device, dtype=torch.float64), ns)
+                    ep["colstats"] = y.stats[0]
+            _lib.conv2d_winograd43(x.buf, bank[id(wt)][1], y.buf, B, x.H, x.W, cin, cout, epilogue=_lib.make_epilogue(bias=bias, **ep))
+            return y
         if (kh, kw, stride, pad, ph) == (3, 3, 1, 1, 1) and _lib.conv2d_winograd_ok(B, x.H, x.W, cin, cout):
             # Winograd F(2x2, 3x3): 2.25x fewer MFMA flops; the transformed filter bank is cached beside the panel
             # (keyed by the kernel form too: the split-precision form is asked for per call, so a switch flipped later or

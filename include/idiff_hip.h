@@ -44,7 +44,8 @@ const char *idiff_source_stamp(void);
  * split-precision products described there), IDIFF_WINO_SPLIT (opt-in: the split-precision Winograd kernel),
  * IDIFF_SBR_LOOKAHEAD (opt-in: band reduction with the look-ahead -- the bulk of a panel's trailing update on a helper
  * stream beside the next panel's factorisation; 5 % at D = 12288 when the helper gets a hardware queue of its own, 50 %
- * SLOWER when the runtime maps it onto the caller's queue, which happens once a process has made a few streams).
+ * SLOWER when the runtime maps it onto the caller's queue, which happens once a process has made a few streams),
+ * IDIFF_NO_WINO43 (3x3 convolutions on the F(2x2,3x3) kernel instead of F(4x4,3x3)).
  * Returns the previous value, -1 for an unknown name.  No reference counterpart. */
 int idiff_set_option(const char *name, int value);
 
@@ -181,6 +182,27 @@ int idiff_winograd_pack_f32(const float *wt, float *u, int Cin, int Cout, void *
 int idiff_conv2d_winograd_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
                               const idiff_epilogue *ep, void *stream);
 int idiff_conv2d_winograd_colstats_split(int B, int H, int W, int Cin, int Cout);
+/* F(4x4, 3x3): the same convolution with 36 multiplications per 4x4 output tile (2.25 per output; the F(2x2, 3x3) form above
+ * spends 4), interpolation points 0, +-1/2, +-2, infinity, all arithmetic fp32 on v_mfma_f32_32x32x2_f32 (csrc/winograd43.hip).
+ * Per layer 1-1.5e-6 against an fp64 convolution where the 2x2 form gives 3-9e-7; measured on the whole nf = 128 NCSN++ before
+ * the kernel was written (scripts/f43_emulation.py): rel_err(S) 5e-6 against an fp64 network, singular values within 1e-4.
+ *   idiff_conv2d_winograd43_ok      1 when served: H % 4 == 0, W % 4 == 0, Cin % 8 == 0, Cout % 64 == 0, every tensor within one
+ *                                   buffer descriptor (4 GiB), and neither IDIFF_NO_WINOGRAD nor IDIFF_NO_WINO43 set.
+ *   idiff_winograd43_weight_floats  size of the transformed filter bank (36 * Cin * Cout floats).
+ *   idiff_winograd43_pack_f32       wt [Cout, 3, 3, Cin] -> U = G g G^T (fp64, rounded once), once per layer.
+ *   idiff_conv2d_winograd43_f32     x [B, H, W, Cin] -> out [B, H, W, Cout] with the epilogue of idiff_conv2d_nhwc_f32; a per-row-group
+ *                                   bias / scale only per image (rows_per_group = H * W).
+ *   idiff_conv2d_winograd43_colstats_split   nsplit of epilogue.colstats ([samples, nsplit, Cout, 2]) or 0 when the statistics cannot
+ *                                   be produced (a workgroup covers 32 tiles of 4x4 pixels: whole workgroups per sample, or whole
+ *                                   samples per workgroup).
+ * Replaces F.conv2d behind ddpm_conv3x3 (models/layers.py:119-132) like the 2x2 form. */
+int idiff_conv2d_winograd43_ok(int B, int H, int W, int Cin, int Cout);
+int idiff_conv2d_winograd43_colstats_split(int B, int H, int W, int Cin, int Cout);
+int64_t idiff_winograd43_weight_floats(int Cin, int Cout);
+int idiff_winograd43_pack_f32(const float *wt, float *u, int Cin, int Cout, void *stream);
+int idiff_conv2d_winograd43_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
+                                const idiff_epilogue *ep, void *stream);
+
 /* Split-precision form of the same convolution: the 16 position-wise contractions run on the bf16 matrix cores with every
  * fp32 operand cut exactly into three bf16 pieces and six of the nine partial products kept (fp32 accumulation; what is
  * dropped is < 2^-23 of a product, one fp32 rounding -- the result meets the same parity bars as the fp32 form).

@@ -381,6 +381,73 @@ def test_wide_ncsnpp_golden(golden):
     assert rel_err(y.cpu(), z["score"]) < NET_RTOL
 
 
+@pytest.fixture
+def wino43_everywhere(monkeypatch):
+    """Send every eligible 3x3 convolution of 8x8 maps and larger through the F(4x4, 3x3) kernel, also at test batch sizes (the
+    executor keeps launches of fewer than 512 workgroups on the 2x2 form: a speed rule, not a correctness one)."""
+    from id_diff_amd.models import ncsnpp as hip_ncsnpp
+    monkeypatch.setattr(hip_ncsnpp, "WINO43_MIN_WORKGROUPS", 1)
+    calls = {"n": 0}
+    orig = _lib.conv2d_winograd43
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(_lib, "conv2d_winograd43", counted)
+    return calls
+
+
+def test_wide_ncsnpp_golden_through_winograd43(golden, wino43_everywhere):
+    """The nf = 128 NCSN++ against the REFERENCE's output with every eligible convolution on F(4x4, 3x3) (the form the benchmark
+    runs): same NET_RTOL as the 2x2 form -- the gate of DESIGN.md 7.3 (rel_err(S) <= 2e-5), measured ~5e-6."""
+    z = golden("ncsnpp_wide.npz")
+    model = mutils.create_model(ncsnpp_config(**overrides_from_golden(z)))
+    fill_from_seed(model, int(z["seed"]))
+    model.to(DEV)
+    model._invalidate()
+    x, t = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV)
+    raw = model(x, t * 999)
+    assert wino43_everywhere["n"] >= 40, wino43_everywhere           # the 3x3 convs of the 32x32, 16x16 and 8x8 levels
+    assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
+    y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x, t)
+    assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+
+
+def test_wide_beatgans_golden_through_winograd43(golden, wino43_everywhere):
+    z = golden("beatgans_wide.npz")
+    model = mutils.create_model(beatgans_config(**overrides_from_golden(z)))
+    fill_from_seed(model, int(z["seed"]))
+    model.to(DEV)
+    model._invalidate()
+    x, t = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV)
+    raw = model(x, t * 999)
+    assert wino43_everywhere["n"] >= 10, wino43_everywhere
+    assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
+
+
+def test_score_matrix_spectrum_and_id_through_winograd43(wino43_everywhere):
+    """One whole point of the image recipe at nf = 64 (Winograd-eligible widths), 16x16 images, B = 100 -> S 1156 x 768, with the
+    3x3 convolutions on F(4x4, 3x3): S against the oracle network on identical noise (NET_RTOL), spectrum against the oracle's
+    fp32 SVD of the GPU's S at 1e-4, same integer ID as the oracle end to end."""
+    cfg = ncsnpp_config(**{"model.init_scale": 1.0, "model.nf": 64, "model.attn_resolutions": (8,), "data.image_size": 16,
+                           "data.effective_image_size": 16, "data.shape": [3, 16, 16], "model.num_res_blocks": 1})
+    torch.manual_seed(0)
+    ref_model = omodels.create_model(cfg)
+    model = mutils.create_model(cfg)
+    model.load_state_dict(ref_model.state_dict())
+    model.to(DEV)
+    x = torch.rand(3, 16, 16, generator=torch.Generator().manual_seed(1))
+    sde_c, sde_h = osde.VESDE(0.01, 50, 1000), sde_lib.VESDE(0.01, 50, 1000)
+    S, S_ref = _pipeline_pair(mutils.get_score_fn(sde_h, model), osde.get_score_fn(sde_c, ref_model), sde_h, sde_c, x, 100, 1e-5)
+    assert wino43_everywhere["n"] > 0
+    assert S.shape == (1156, 768) and rel_err(S.cpu(), S_ref) < NET_RTOL
+    sv = _lib.spectrum(S).cpu()
+    ref64 = odim.spectrum_f64(S.cpu())
+    keep = ref64 > 2e-5 * ref64[0]
+    np.testing.assert_allclose(sv.numpy()[keep], odim.spectrum(S.cpu()).numpy()[keep], rtol=1e-4)
+    assert plot_utils.estimate_dim(sv.tolist()) == odim.estimate_dim(odim.spectrum(S_ref).tolist())
+
+
 def test_wide_beatgans_golden(golden):
     z = golden("beatgans_wide.npz")
     model = mutils.create_model(beatgans_config(**overrides_from_golden(z)))

@@ -692,3 +692,83 @@ def test_upfirdn2d_other_dtypes_vs_oracle(dtype, shape, up, down, pad):
         torch.testing.assert_close(y.cpu().float(), ref.float(), rtol=2e-3, atol=2e-3 * float(ref.float().abs().max()))
     with pytest.raises(RuntimeError, match="not one of float32"):
         op.upfirdn2d(x.to(DEV).to(torch.bfloat16), k.to(DEV), up=up, down=down, pad=pad)
+
+
+# ---- Winograd F(4x4, 3x3) (round 4)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 32, 32, 128, 128), (3, 8, 8, 256, 64), (5, 8, 12, 24, 64), (2, 16, 16, 512, 256), (130, 4, 4, 48, 64),
+                                            (1, 64, 64, 16, 64), (2, 8, 8, 8, 64), (33, 8, 8, 256, 256)])
+def test_conv2d_winograd43_vs_cpu(B, H, W, Cin, Cout):
+    """F(4x4, 3x3) conv (points 0, +-1/2, +-2, infinity; fp32 transforms, fp32 MFMA contraction) against the fp64 CPU convolution with
+    every epilogue term; tile counts that do not fill a workgroup's 32 tiles, maps of one tile per sample, several output-channel
+    tiles, 1 to 64 K steps.  Bar 3e-6, the bar of the 2x2 form: the 4x4 transforms cost a factor ~4 in rounding (measured
+    0.4-2.0e-6 here, 1-5e-7 for the 2x2 form), still inside it; against the direct kernel likewise."""
+    g = torch.Generator().manual_seed(B * H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    temb = torch.randn(B, Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    rsc = torch.rand(B, generator=g) + 0.5
+    assert _lib.conv2d_winograd43_ok(B, H, W, Cin, Cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wt = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    u = _lib.winograd43_pack(wt, Cin, Cout)
+    assert u.numel() == 36 * Cin * Cout
+    out = torch.full((B, H, W, Cout), float("nan"), device=DEV)          # every output must be written
+    _lib.conv2d_winograd43(xd, u, out, B, H, W, Cin, Cout, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 3e-6
+    # elementwise too: a misplaced store moves single entries by O(1) while the norm moves by 1e-2
+    assert float((out.permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    direct = torch.empty_like(out)
+    _lib.conv2d_nhwc(xd, wt, direct, B, H, W, Cin, Cout, 3, 3, 1, 1, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
+    assert rel_err(out.cpu(), direct.double().cpu()) < 3e-6
+    resd = res.permute(0, 2, 3, 1).contiguous().to(DEV)
+    _lib.conv2d_winograd43(xd, u, out, B, H, W, Cin, Cout,
+                           epilogue=_lib.make_epilogue(bias=b.to(DEV), rowbias=temb.to(DEV), rows_per_group=H * W, act="silu",
+                                                       residual=resd, out_scale=0.7071, rowscale=rsc.to(DEV)))
+    ref2 = (F.silu(ref + temb.double()[:, :, None, None]) + res.double()) * 0.7071 * rsc.double()[:, None, None, None]
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref2) < 3e-6
+    assert float((out.permute(0, 3, 1, 2).cpu().double() - ref2).abs().max()) < 1e-4 * float(ref2.abs().max())
+
+
+def test_conv2d_winograd43_rejects_what_it_cannot_take():
+    assert not _lib.conv2d_winograd43_ok(2, 6, 8, 32, 64)       # height not a multiple of 4
+    assert not _lib.conv2d_winograd43_ok(2, 8, 8, 4, 64)        # Cin % 8
+    assert not _lib.conv2d_winograd43_ok(2, 8, 8, 32, 3)        # Cout % 64
+    with _lib.thread_option("IDIFF_NO_WINO43", 1):
+        assert not _lib.conv2d_winograd43_ok(2, 8, 8, 32, 64)
+    assert _lib.conv2d_winograd43_ok(2, 8, 8, 32, 64)
+    x = torch.zeros(2, 8, 8, 32, device=DEV)
+    u = torch.zeros(36 * 32 * 64, device=DEV)
+    with pytest.raises(RuntimeError, match="per image"):          # a row group that is not the image
+        _lib.conv2d_winograd43(x, u, torch.zeros(2, 8, 8, 64, device=DEV), 2, 8, 8, 32, 64,
+                               epilogue=_lib.make_epilogue(rowbias=torch.zeros(4, 64, device=DEV), rows_per_group=32))
+    with pytest.raises(RuntimeError, match="filter bank"):
+        _lib.conv2d_winograd43(x, torch.zeros(16 * 32 * 64, device=DEV), torch.zeros(2, 8, 8, 64, device=DEV), 2, 8, 8, 32, 64)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(3, 32, 64, 128), (6, 16, 128, 64), (5, 8, 64, 128), (11, 4, 32, 64), (64, 4, 8, 64), (70, 8, 16, 64)])
+def test_winograd43_colstats_feed_groupnorm(B, H, Cin, Cout):
+    """Column sums from the F(4x4,3x3) epilogue = a statistics pass over its output: two workgroups per sample (32x32), two, eight
+    and thirty-two whole samples per workgroup (16x16, 8x8, 4x4), sample counts that leave the last workgroup partly empty."""
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, H * H, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    ns = _lib.conv2d_winograd43_colstats_split(B, H, H, Cin, Cout)
+    assert ns == max(1, H * H // 512)
+    cs = torch.full((B * ns * Cout * 2,), float("nan"), device=DEV, dtype=torch.float64)
+    out = torch.empty(B, H * H, Cout, device=DEV)
+    u = _lib.winograd43_pack(w, Cin, Cout)
+    _lib.conv2d_winograd43(x, u, out, B, H, H, Cin, Cout, epilogue=_lib.make_epilogue(bias=bias, act="silu", rows_per_group=H * H, colstats=cs))
+    G = 32
+    st_a, st_b = torch.empty(B * G * 2, device=DEV), torch.empty(B * G * 2, device=DEV)
+    _lib.groupnorm_finalize(cs, ns, Cout, None, 0, 0, B, H * H, G, 1e-6, st_a)
+    nsp = _lib.groupnorm_nsplit(B, H * H, Cout)
+    ws = torch.empty(B * nsp * Cout * 2, device=DEV, dtype=torch.float64)
+    _lib.groupnorm_stats(out, Cout, None, 0, B, H * H, G, 1e-6, ws, st_b)
+    torch.testing.assert_close(st_a, st_b, rtol=1e-6, atol=1e-7)
+    tot = cs.view(B, ns, Cout, 2).sum(1)
+    torch.testing.assert_close(tot[..., 0], out.double().sum(1), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(tot[..., 1], (out.double() ** 2).sum(1), rtol=1e-6, atol=1e-6)
