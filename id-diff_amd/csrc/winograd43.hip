@@ -115,6 +115,9 @@ __device__ __forceinline__ void f4_wave_lds_sync() {
 __global__ void __launch_bounds__(F4_THREADS, 2)   // two waves per SIMD: one 512-thread workgroup per CU
 winograd43_kernel(const Wino43Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef IDIFF_W43_STAMP   // diagnostic build only (scripts/wino43_stamps.py): 100 MHz ticks at the phases of a workgroup's life
+  const uint64_t st_start = __builtin_amdgcn_s_memrealtime();
+#endif
   const int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
   {
@@ -127,7 +130,9 @@ winograd43_kernel(const Wino43Params p) {
   const int tile0 = tile_m * F4_TILES, n0 = tile_n * F4_COUT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wh = wave >> 2, wq = wave & 3, wa = wq >> 1, wb = wq & 1;     // cout half, row block, column block
+  // cout half, row block, column block.  Waves w and w + 4 share a SIMD: they get DIFFERENT column blocks, so that in the tail's
+  // two-part exchange (block 1 parks, block 0 adds) every SIMD has one working wave in each part instead of two or none
+  const int wh = wave >> 2, wq = (wave & 3) ^ wh, wa = wq >> 1, wb = wq & 1;
 
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
@@ -210,28 +215,32 @@ winograd43_kernel(const Wino43Params p) {
     acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[pp], 0, 0, 0);
   };
   auto v_at = [&](const float *S, int pp) { return *reinterpret_cast<const float4 *>(S + ((pp / 3) * 6 + (pp % 3)) * F4_VSLOT); };
-  auto compute = [&](int buf, int s, auto before_last) {
+  // LAST: the final step requests nothing (no next slab, no next input) and writes no stage -- the tail would only wait for
+  // loads nobody uses
+  auto compute = [&](int buf, int s, auto before_last, auto last) {
+    constexpr bool LAST = decltype(last)::value;
     const float *S = lds + buf * F4_STAGE + a_frag;
-    const int snext = min(s + 1, nsteps - 1);
     float4 f0 = v_at(S, 0), f1 = v_at(S, 1);
 #pragma unroll
     for (int pp = 0; pp < 9; ++pp) {
       __builtin_amdgcn_sched_barrier(0);
       if (pp == 6) { before_last(); __builtin_amdgcn_sched_barrier(0); }
       mfma4(pp, (pp & 1) ? f1 : f0);
-      // the register set is free once these MFMAs have read it: request the position three ahead (of the next step beyond 8;
-      // the last step re-requests its own slab: clamped, not skipped -- the scalar offset of a raw buffer is not range-checked)
-      if (pp + 3 < 9) load_b(pp + 3, s); else load_b(pp + 3 - 9, snext);
+      // the register set is free once these MFMAs have read it: request the position three ahead (of the next step beyond 8)
+      if (pp + 3 < 9) load_b(pp + 3, s); else if (!LAST) load_b(pp + 3 - 9, s + 1);
       if (pp + 2 < 9) { if (pp & 1) f1 = v_at(S, pp + 2); else f0 = v_at(S, pp + 2); }
     }
   };
-  auto step = [&](int s, auto is_early) {
+  auto step = [&](int s, auto is_early, auto last) {
+    constexpr bool LAST = decltype(last)::value;
     const int buf = s & 1;
-    if constexpr (decltype(is_early)::value) {
+    if constexpr (LAST) {
+      compute(buf, s, [] {}, last);
+    } else if constexpr (decltype(is_early)::value) {
       stage(buf ^ 1); fetch();
-      compute(buf, s, [] {});
+      compute(buf, s, [] {}, last);
     } else {
-      compute(buf, s, [&] { stage(buf ^ 1); fetch(); });
+      compute(buf, s, [&] { stage(buf ^ 1); fetch(); }, last);
     }
     __syncthreads();
   };
@@ -241,8 +250,15 @@ winograd43_kernel(const Wino43Params p) {
   stage(0);
   fetch();
   __syncthreads();
-  if (wave < 4) { for (int s = 0; s < nsteps; ++s) step(s, std::true_type()); }
-  else { for (int s = 0; s < nsteps; ++s) step(s, std::false_type()); }
+#ifdef IDIFF_W43_STAMP
+  const uint64_t st_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (wave < 4) { for (int s = 0; s + 1 < nsteps; ++s) step(s, std::true_type(), std::false_type()); }
+  else { for (int s = 0; s + 1 < nsteps; ++s) step(s, std::false_type(), std::false_type()); }
+  step(nsteps - 1, std::true_type(), std::true_type());
+#ifdef IDIFF_W43_STAMP
+  const uint64_t st_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---------------------------------------------------------------- tail
   const idiff_epilogue &ep = p.ep;
@@ -280,10 +296,17 @@ winograd43_kernel(const Wino43Params p) {
     }
   };
 
+#ifdef IDIFF_W43_STAMP
+  const bool want_stats = false;            // epilogue.colstats carries the stamp buffer in this build
+#else
   const bool want_stats = has_ep && ep.colstats != nullptr;
+#endif
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};    // column sums of this thread's 16 pixels x 4 channels
   // accumulator register `reg` of lane l is tile row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), cout wh * 32 + (l & 31)
   float *zbase = lds + (size_t)(4 * (lane >> 5)) * 2 * F4_COUT + wh * 32 + (lane & 31);
+#ifdef IDIFF_W43_STAMP
+  uint64_t st_tail[4] = {0, 0, 0, 0};
+#endif
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     // z_{i,b} for b = 2 pass, 2 pass + 1 and the three rows i of this wave's block: column block 1 parks, block 0 adds
@@ -314,6 +337,9 @@ winograd43_kernel(const Wino43Params p) {
         }
     }
     __syncthreads();
+#ifdef IDIFF_W43_STAMP
+    st_tail[2 * pass] = __builtin_amdgcn_s_memrealtime();       // z of this pass exchanged
+#endif
     __builtin_amdgcn_sched_barrier(0);
     prep();
 #pragma unroll 1
@@ -369,6 +395,9 @@ winograd43_kernel(const Wino43Params p) {
                                                so + a * rp, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef IDIFF_W43_STAMP
+    st_tail[2 * pass + 1] = __builtin_amdgcn_s_memrealtime();   // outputs of this pass stored (issued)
+#endif
   }
   if (want_stats) {
     // Per-tile partial sums meet in LDS ([32 tiles][64 channels][2] fp64 = 32 KB over the dead z area); one thread per (sample
@@ -395,6 +424,15 @@ winograd43_kernel(const Wino43Params p) {
       dst[0] = a; dst[1] = b;
     }
   }
+#ifdef IDIFF_W43_STAMP
+  if (has_ep && ep.colstats && tid == 0) {
+    uint64_t *st = reinterpret_cast<uint64_t *>(ep.colstats) + 10 * (int64_t)blockIdx.x;
+    st[6] = st_tail[0]; st[7] = st_tail[1]; st[8] = st_tail[2]; st[9] = st_tail[3];
+    st[0] = st_start; st[1] = st_loop0; st[2] = st_loop1; st[3] = __builtin_amdgcn_s_memrealtime();
+    st[4] = ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
+    st[5] = (uint64_t)nsteps;
+  }
+#endif
 }
 
 // U = G g G^T in fp64, rounded once; g[ky][kx] = wt[cout][ky][kx][cin] (the K-contiguous panel of the direct kernel)
@@ -471,9 +509,11 @@ IDIFF_API int idiff_conv2d_winograd43_f32(const float *x, const float *u, float 
     return fail("conv2d_winograd43: geometry B=%d H=%d W=%d Cin=%d Cout=%d not supported (ask idiff_conv2d_winograd43_ok)", B, H, W, Cin, Cout);
   if (!x || !u || !out) return fail("conv2d_winograd43: null pointer");
   if (((uintptr_t)x & 15) || ((uintptr_t)u & 15) || ((uintptr_t)out & 15)) return fail("conv2d_winograd43: x, u and out must be 16-byte aligned");
+#ifndef IDIFF_W43_STAMP
   if (ep && ep->colstats && idiff_conv2d_winograd43_colstats_split(B, H, W, Cin, Cout) <= 0)
     return fail("conv2d_winograd43: colstats needs whole workgroups per sample or whole samples per workgroup "
                 "(ask idiff_conv2d_winograd43_colstats_split)");
+#endif
   if (ep && (ep->rowbias || ep->rowscale) && ep->rows_per_group != H * W)
     return fail("conv2d_winograd43: per-row-group bias / scale only per image (rows_per_group = H * W = %d, got %d)", H * W, ep->rows_per_group);
   if (ep && ep->residual && (((uintptr_t)ep->residual & 15) || ep->ld_residual % 4 || ep->ld_residual < Cout || ep->ld_residual > 0x7fffffff / 4))
