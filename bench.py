@@ -53,8 +53,10 @@ HBM_PEAK_GBS = 8000.0
 DTYPE = "f32" if os.environ.get("IDIFF_NO_SPLIT") else \
     "f32 (3x3 convs: fp32 MFMA, Winograd F(4x4,3x3) / F(2x2,3x3); 1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate)"
 WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=1e-5, B=128 -> S 4480x3072 + centred spectrum + ID"
-TRAFFIC_TABLE = os.path.join("profiles", "r03_wino_traffic.json")
-WINOGRAD_SOURCE = os.path.join("id-diff_amd", "csrc", "winograd.hip")
+# PMC traffic tables (separate FETCH_SIZE / WRITE_SIZE passes, scripts/profile_round.sh), each stamped with the sha256 of the kernel
+# source it was measured on: F(4x4,3x3) (the dominant kernel) and F(2x2,3x3)
+TRAFFIC_TABLES = {"winograd43_kernel": (os.path.join("profiles", "r04_wino43_traffic.json"), os.path.join("id-diff_amd", "csrc", "winograd43.hip")),
+                  "winograd_kernel": (os.path.join("profiles", "r03_wino_traffic.json"), os.path.join("id-diff_amd", "csrc", "winograd.hip"))}
 
 
 def _sync(dev):
@@ -161,21 +163,22 @@ class KernelProbe:
         return out
 
 
-def winograd_traffic(keys):
+def winograd_traffic(keys, kernel="winograd_kernel"):
     """HBM bytes per launch of the sampled shapes from the committed PMC table (separate FETCH_SIZE / WRITE_SIZE passes,
     gfx950 corrections applied) -- ONLY if the table was measured on the kernel source that is in the tree now."""
-    path = os.path.join(ROOT, TRAFFIC_TABLE)
+    table_rel, source_rel = TRAFFIC_TABLES[kernel]
+    path = os.path.join(ROOT, table_rel)
     if not os.path.exists(path):
         return None
     doc = json.load(open(path))
-    if doc.get("kernel_source_sha256") != source_sha256(WINOGRAD_SOURCE):
+    if doc.get("kernel_source_sha256") != source_sha256(source_rel):
         return None
     table = doc["shapes"]
     if any(k not in table for k in keys):
         return None
     return {"bytes_per_launch": sum(table[k]["total_bytes"] for k in keys) / len(keys),
             "algorithmic_bytes_per_launch": sum(table[k]["algorithmic_bytes"] for k in keys) / len(keys),
-            "source": TRAFFIC_TABLE, "kernel_source_sha256": doc["kernel_source_sha256"]}
+            "source": table_rel, "kernel_source_sha256": doc["kernel_source_sha256"]}
 
 
 def roofline_report(probe):
@@ -184,8 +187,7 @@ def roofline_report(probe):
     if dom is None:
         return None
     tfl = dom["rate"] / 1e12
-    # the PMC traffic table was measured on the F(2x2,3x3) kernel; the F(4x4,3x3) kernel has none yet
-    traffic = winograd_traffic(dom["keys"]) if dom43 is None else None
+    traffic = winograd_traffic(dom["keys"], "winograd43_kernel" if dom43 is not None else "winograd_kernel")
     kernels = []
     if dom43 is not None and dom22 is not None:
         t22 = dom22["rate"] / 1e12
@@ -399,25 +401,30 @@ def cpu_baseline(cfg, rows_per_point, D, S_gpu):
     model = omodels.create_model(cfg)
     score_fn = osde.get_score_fn(osde.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales), model)
 
-    def median_rate(n, grad, reps):
-        x, t = torch.rand(n, 3, 32, 32), torch.full((n,), 1e-5)
-        times = []
-        for rep in range(reps + 1):
-            t0 = time.perf_counter()
-            if grad:
-                score_fn(x, t).detach()
-            else:
-                with torch.no_grad():
-                    score_fn(x, t)
-            times.append(time.perf_counter() - t0)
-            print(f"[bench] cpu_baseline: score_fn {'autograd' if grad else 'no_grad'} batch {rep} of {n} rows: {times[-1]:.2f}s",
-                  file=sys.stderr, flush=True)
-        return n / statistics.median(times[1:])
-
-    # the reference evaluates B = 128 rows per call (dim_reduction.py:167-183): time that batch shape
+    # the reference evaluates B = 128 rows per call (dim_reduction.py:167-183): time that batch shape.  The two modes are
+    # INTERLEAVED (no_grad, autograd, no_grad, ...) after one warm-up batch of each, median of 3 per mode: timed one mode after the
+    # other, the first series was still warming the allocator and the thread pool and autograd came out faster than no_grad.
     B = int(cfg.training.batch_size)
-    nograd = median_rate(B, False, 2)
-    withgrad = median_rate(B, True, 2)
+    x, t = torch.rand(B, 3, 32, 32), torch.full((B,), 1e-5)
+
+    def one(grad):
+        t0 = time.perf_counter()
+        if grad:
+            score_fn(x, t).detach()
+        else:
+            with torch.no_grad():
+                score_fn(x, t)
+        return time.perf_counter() - t0
+
+    times = {False: [], True: []}
+    for rep in range(4):
+        for grad in (False, True):
+            dt = one(grad)
+            if rep:
+                times[grad].append(dt)
+            print(f"[bench] cpu_baseline: score_fn {'autograd' if grad else 'no_grad'} batch {rep} of {B} rows: {dt:.2f}s"
+                  f"{' (warm-up)' if not rep else ''}", file=sys.stderr, flush=True)
+    nograd, withgrad = B / statistics.median(times[False]), B / statistics.median(times[True])
     S = S_gpu.cpu()
     c = S - S.mean(0, keepdim=True)
 
@@ -435,7 +442,7 @@ def cpu_baseline(cfg, rows_per_point, D, S_gpu):
     as_reference = rows_per_point / (rows_per_point / withgrad + svd_full)
     floor = rows_per_point / (rows_per_point / nograd + svd_vals)
     return {"value": as_reference, "unit": "score-vector evals/s", "cores": cores, "cpu_model": model_name, "kind": "port",
-            "sample": f"oracle NCSN++ score_fn on batches of B = {B} rows (the reference's batch shape), median of 2 after 1 warm-up: "
+            "sample": f"oracle NCSN++ score_fn on batches of B = {B} rows (the reference's batch shape), the two modes interleaved, median of 3 each after 1 warm-up: "
                       f"autograd on (as the reference runs, dim_reduction.py:183) {withgrad:.2f} evals/s, no_grad {nograd:.2f} "
                       f"evals/s; torch.linalg.svd "
                       f"(full matrices, dim_reduction.py:197) {svd_full:.2f} s and svdvals {svd_vals:.2f} s, median of 3, on the "

@@ -160,10 +160,10 @@ def main():
     say(f"fp64 network on {rows} rows: {time.time() - t0:.0f} s")
     forms = [("direct fp32 (ATen)", None),
              ("F(2x2,3x3) fp32, points 0,+-1", WinogradConv(2, [0, 1, -1])),
+             ("F(4x4,3x3) fp32, points 0,+-1/2,+-2 (the kernel's)", WinogradConv(4, [0, Fraction(1, 2), Fraction(-1, 2), 2, -2])),
              ("F(4x4,3x3) fp32, points 0,+-1,+-2 (Lavin)", WinogradConv(4, [0, 1, -1, 2, -2])),
-             ("F(4x4,3x3) fp32, points 0,+-1,+-1/2", WinogradConv(4, [0, 1, -1, Fraction(1, 2), Fraction(-1, 2)])),
              ("F(4x4,3x3) fp32, points 0,+-1,1/2,-2", WinogradConv(4, [0, 1, -1, Fraction(1, 2), -2])),
-             ("F(4x4,3x3) fp32, points 0,+-1,2,-1/2", WinogradConv(4, [0, 1, -1, 2, Fraction(-1, 2)]))]
+             ("F(4x4,3x3) fp32, points 0,+-2/3,+-3/2", WinogradConv(4, [0, Fraction(2, 3), Fraction(-2, 3), Fraction(3, 2), Fraction(-3, 2)]))]
     sv64 = odim.spectrum_f64(S64.float()) if rows >= 8 else None
     c64 = S64 - S64.mean(0, keepdim=True)
     sv64 = torch.linalg.svdvals(c64)

@@ -14,26 +14,29 @@ torch.manual_seed(0)
 model = mutils.create_model(cfg).to("cuda").eval()
 sde, eps = sde_lib.configure_sde(cfg)
 score_fn = mutils.get_score_fn(sde, model)
+# second argument: which kernel's calls to tabulate -- "43" = winograd43_kernel (F(4x4,3x3)), default winograd_kernel (F(2x2,3x3))
+F43 = len(sys.argv) > 2 and sys.argv[2] == "43"
+OP, PACK = ("conv2d_winograd43", _lib.winograd43_pack) if F43 else ("conv2d_winograd", _lib.winograd_pack)
 calls = []
-orig = _lib.conv2d_winograd
+orig = getattr(_lib, OP)
 
-def rec(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+def rec(x, u, out, B, H, W, Cin, Cout, epilogue=None, **kw):
     calls.append((B, H, W, Cin, Cout))
-    return orig(x, u, out, B, H, W, Cin, Cout, epilogue)
+    return orig(x, u, out, B, H, W, Cin, Cout, epilogue, **kw)
 
-_lib.conv2d_winograd = rec
+setattr(_lib, OP, rec)
 with torch.no_grad():
     ROWS = int(sys.argv[1]) if len(sys.argv) > 1 else 2240
     score_fn(torch.rand(ROWS, 3, 32, 32, device="cuda"), torch.full((ROWS,), 1e-5, device="cuda"))
-_lib.conv2d_winograd = orig
+setattr(_lib, OP, orig)
 torch.cuda.synchronize()
 for (B, H, W, Cin, Cout) in sorted(set(calls)):
     x = torch.randn(B, H * W, Cin, device="cuda")
     w = torch.randn(Cout, 3, 3, Cin, device="cuda") * 0.02
-    u = _lib.winograd_pack(w, Cin, Cout)
+    u = PACK(w, Cin, Cout)
     out = torch.empty(B, H * W, Cout, device="cuda")
     torch.cuda.synchronize()
     for _ in range(2):
-        _lib.conv2d_winograd(x, u, out, B, H, W, Cin, Cout)
+        orig(x, u, out, B, H, W, Cin, Cout)
     torch.cuda.synchronize()
     print("KEY", f"{B}x{H}x{W}x{Cin}->{Cout}", calls.count((B, H, W, Cin, Cout)), flush=True)
