@@ -27,7 +27,7 @@
 // K loop: 8 input channels per step; per wave 36 MFMAs from 9 sixteen-byte LDS reads of V and 9 sixteen-byte global loads of U
 //   (a ring of three register sets, each re-requested three positions ahead), two LDS stages of V, one barrier per step.
 // Loader (all 8 waves): lanes in groups of 8 = the rows r of the 6x6 patch of one (tile, 4-channel quad) unit (lanes 6, 7 of a
-//   group idle): six 16-byte loads (the row), the 6-point transform along x in registers (14 ops per component), the x-mixed row
+//   group idle): six 16-byte loads (the row), the 6-point transform along x in registers (12 ops per component), the x-mixed row
 //   to a wave-private LDS scratch, then lane c of the group reads COLUMN c of the unit back (6 x 16 bytes), transforms along y
 //   and writes V(0..5, c) to the stage.  The scratch exchange needs no workgroup barrier: DS operations of a wave are in order.
 //   Waves w and w + 4 share a SIMD: the first four transform at the start of a step, the others before their last positions.
@@ -87,14 +87,16 @@ __device__ __forceinline__ void f4_split_tile(const Wino43Params &p, int T, int 
   }
 }
 
-// the 6-point input transform t = B^T d on one component (14 operations)
+// the 6-point input transform t = B^T d on one component: 12 operations (the odd parts are formed UNSCALED, d3 - 4 d1 and
+// d3 - 0.25 d1, and their factors 0.5 and 2 ride in the fused multiply-adds that combine them with the even parts; the
+// products by powers of two are exact, so this rounds like the 14-operation form with its separate multiplies)
 __device__ __forceinline__ void f4_bt(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
                                       float &t0, float &t1, float &t2, float &t3, float &t4, float &t5) {
-  const float pe = fmaf(-4.f, d2, d4), po = fmaf(0.5f, d3, -2.f * d1);
-  const float re = fmaf(-0.25f, d2, d4), ro = fmaf(2.f, d3, -0.5f * d1);
+  const float pe = fmaf(-4.f, d2, d4), po = fmaf(-4.f, d1, d3);          // t1, t2 = pe +- 0.5 po
+  const float re = fmaf(-0.25f, d2, d4), ro = fmaf(-0.25f, d1, d3);      // t3, t4 = re +- 2 ro
   t0 = fmaf(-4.25f, d2, d0 + d4);
-  t1 = pe + po; t2 = pe - po;
-  t3 = re + ro; t4 = re - ro;
+  t1 = fmaf(0.5f, po, pe); t2 = fmaf(-0.5f, po, pe);
+  t3 = fmaf(2.f, ro, re); t4 = fmaf(-2.f, ro, re);
   t5 = fmaf(-4.25f, d3, d1 + d5);
 }
 __device__ __forceinline__ void f4_bt4(const float4 (&d)[6], float4 (&t)[6]) {

@@ -54,6 +54,9 @@ def d_conv(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue=None, p
 def d_wino(x, u, out, B, H, W, Cin, Cout, epilogue=None, split=False):
     return (f"B{B} {H}x{W} {Cin}->{Cout} (F(2x2,3x3); TF = direct-equivalent)", 2.0 * out.numel() * Cin * 9,
             4.0 * (B * H * W * Cin + out.numel()))
+def d_wino43(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+    return (f"B{B} {H}x{W} {Cin}->{Cout} (F(4x4,3x3); TF = direct-equivalent)", 2.0 * out.numel() * Cin * 9,
+            4.0 * (B * H * W * Cin + out.numel()))
 def d_gnapply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None):
     return (f"B{B} HW{HW} C{C}+{C2} act={act}", 0.0, 8.0 * B * HW * (C + C2))
 def d_gnapply_cs(x, C, x2, C2, B, HW, G, ws1, ns1, ws2, ns2, eps_, gamma, beta, act, y, mod=None):
@@ -68,7 +71,7 @@ def d_generic(*a, **k):
     n = sum(4.0 * v.numel() for v in list(a) + list(k.values()) if torch.is_tensor(v))
     return ("", 0.0, n)
 
-wrap("gemm", d_gemm); wrap("gemm_2src", d_gemm2); wrap("conv2d_nhwc", d_conv); wrap("conv2d_winograd", d_wino); wrap("groupnorm_apply", d_gnapply); wrap("groupnorm_apply_colstats", d_gnapply_cs); wrap("groupnorm_stats", d_gnstats)
+wrap("gemm", d_gemm); wrap("gemm_2src", d_gemm2); wrap("conv2d_nhwc", d_conv); wrap("conv2d_winograd", d_wino); wrap("conv2d_winograd43", d_wino43); wrap("groupnorm_apply", d_gnapply); wrap("groupnorm_apply_colstats", d_gnapply_cs); wrap("groupnorm_stats", d_gnstats)
 wrap("upfirdn2d_raw", d_ufd); wrap("softmax_rows", d_soft)
 for nm in ("groupnorm_finalize", "affine_act", "add_scale", "fourier_embed", "positional_embed", "concat_cols", "nchw_to_nhwc",
            "nhwc_to_nchw", "resample2x_nhwc"):
