@@ -53,12 +53,14 @@ constexpr int F4_OPER_FLOATS = F4_NPOS * 64 * F4_KC;     // one 8-channel slab o
 constexpr int F4_VSLOT = F4_TILES * F4_KC + 4;           // 260 = 4 mod 32: the six columns a lane group writes fall on distinct banks
 constexpr int F4_STAGE = F4_NPOS * F4_VSLOT;             // 9360 floats
 constexpr int F4_SCR_ROW = 7 * 4;                        // scratch row: 6 float4 + one of padding (28 dwords: rows on distinct banks)
-constexpr int F4_SCR_UNIT = 6 * F4_SCR_ROW;              // 168 floats
-constexpr int F4_SCR_WAVE = 8 * F4_SCR_UNIT;             // 1344 floats per wave
-constexpr int F4_SCRATCH = 8 * F4_SCR_WAVE;              // 10752 floats
+constexpr int F4_SCR_UNIT = 224;                         // floats per unit (6 rows used): with this pitch the column reads of the
+                                                         // four 16-lane groups of a ds_read_b128 fall on distinct banks as well (PMC:
+                                                         // SQ_LDS_BANK_CONFLICT was 21 % of the LDS cycles at the dense pitch of 168)
+constexpr int F4_SCR_WAVE = 8 * F4_SCR_UNIT;             // 1792 floats per wave
+constexpr int F4_SCRATCH = 8 * F4_SCR_WAVE;              // 14336 floats
 constexpr int F4_Z_FLOATS = 6 * F4_TILES * 2 * F4_COUT;  // the tail's exchange: [6 rows][tiles][2 columns][64 cout] = 24576 floats
 constexpr int F4_LOOP_FLOATS = 2 * F4_STAGE + F4_SCRATCH + 8;   // + 8: lane 7 of the last group reads one float4 past its unit
-constexpr size_t F4_LDS_BYTES = sizeof(float) * (size_t)(F4_LOOP_FLOATS > F4_Z_FLOATS ? F4_LOOP_FLOATS : F4_Z_FLOATS);   // 117,888 B
+constexpr size_t F4_LDS_BYTES = sizeof(float) * (size_t)(F4_LOOP_FLOATS > F4_Z_FLOATS ? F4_LOOP_FLOATS : F4_Z_FLOATS);   // 132,256 B
 constexpr int64_t F4_X_LIMIT = 0xFFFF0000ll;
 constexpr uint32_t F4_INVALID = 0xFFFF8000u;             // beyond any valid extent (the scalar step offset is not range-checked)
 
