@@ -3,19 +3,19 @@
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      d: 6x6 input patch at (4ty-1, 4tx-1), Y: 4x4 outputs at (4ty, 4tx)
 //
-// Interpolation points 0, +-1/2, +-2, infinity.  Measured before this file was written (scripts/f43_emulation.py, CPU emulation of
-// the whole nf = 128 NCSN++ with every eligible convolution in this form, fp32 transforms and contraction): per layer 1.0-1.5e-6
-// against an fp64 convolution (F(2x2,3x3): 3e-7; Lavin's points 0, +-1, +-2: 2.2e-6), rel_err(S) 5e-6 against an fp64 network (bar
-// 2e-5), every singular value above 2e-5 sigma_max within 1e-4 -- the round-1 estimate "loses two decimal digits" was wrong.  All
-// transform constants are dyadic (1/8 ... 8, 4.25): the transforms round like plain fp32 additions.
+// Interpolation points 0, +-a, +-b, infinity with a = 2/3, b = 3/2.  Measured before this file was written
+// (scripts/f43_emulation.py, CPU emulation of the whole nf = 128 NCSN++ with every eligible convolution in this form, fp32 transforms
+// and contraction): per layer 0.8-1.3e-6 against an fp64 convolution (F(2x2,3x3): 4e-7; Lavin's points 0, +-1, +-2: 1.6-2.7e-6),
+// rel_err(S) 3.3e-6 against an fp64 network (bar 2e-5), every singular value above 2e-5 sigma_max within 1.4e-5 (bar 1e-4) -- the
+// round-1 estimate "loses two decimal digits" was wrong.
 //
-//   B^T rows (input transform, t = B^T d):            A^T rows (output transform, y = A^T m):
-//     t0 = d0 - 4.25 d2 + d4                              y0 = m0 + (m1 + m2) + (m3 + m4)
-//     t1 = (d4 - 4 d2) + (0.5 d3 - 2 d1)                  y1 = 0.5 (m1 - m2) + 2 (m3 - m4)
-//     t2 = (d4 - 4 d2) - (0.5 d3 - 2 d1)                  y2 = 0.25 (m1 + m2) + 4 (m3 + m4)
-//     t3 = (d4 - 0.25 d2) + (2 d3 - 0.5 d1)               y3 = 0.125 (m1 - m2) + 8 (m3 - m4) + m5
-//     t4 = (d4 - 0.25 d2) - (2 d3 - 0.5 d1)
-//     t5 = d1 - 4.25 d3 + d5                           G rows: (1,0,0), (-8,-4,-2)/15, (-8,4,-2)/15, (1,2,4)/30, (1,-2,4)/30, (0,0,1)
+//   B^T rows (input transform, t = B^T d):                 A^T rows (output transform, y = A^T m):
+//     t0 = d0 - (a^2 + b^2) d2 + d4                           y0 = m0 + (m1 + m2) + (m3 + m4)
+//     t1 = (d4 - b^2 d2) + a (d3 - b^2 d1)                    y1 = a (m1 - m2) + b (m3 - m4)
+//     t2 = (d4 - b^2 d2) - a (d3 - b^2 d1)                    y2 = a^2 (m1 + m2) + b^2 (m3 + m4)
+//     t3 = (d4 - a^2 d2) + b (d3 - a^2 d1)                    y3 = a^3 (m1 - m2) + b^3 (m3 - m4) + m5
+//     t4 = (d4 - a^2 d2) - b (d3 - a^2 d1)
+//     t5 = d1 - (a^2 + b^2) d3 + d5                        G rows: (1, p, p^2) / prod_{q != p} (p - q) for p = 0, +-a, +-b; (0, 0, 1)
 //
 //   U = G g G^T is packed once per layer (idiff_winograd43_pack_f32, fp64, rounded once) as [Cin/8][Cout/64][36 slots][64 cout]
 //   [8 cin]; V = B^T d B is formed by the loader between L2 and LDS; M_p = V_p U_p^T for the 36 positions p = (i, j) (slot 6 i + j)
@@ -44,6 +44,16 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 
+// Interpolation points 0, +-a, +-b, infinity with a b = 1 (reciprocal pairs keep the transforms balanced): a = 2/3, b = 3/2.
+// (scripts/f43_emulation.py on the whole network: rel_err(S) 3.3e-6 for this set, 4.9e-6 for 1/2, 2 -- whose constants are all
+// dyadic -- and 7.0e-6 for Lavin's 1, 2.)  The transforms use these fp32 constants; G is evaluated in fp64 from the same a, b.
+#ifdef IDIFF_W43_DYADIC_POINTS   // A/B builds only (scripts/wino43_ab.py): the dyadic set 1/2, 2
+constexpr double F4_A = 0.5, F4_B = 2.0;
+#else
+constexpr double F4_A = 2.0 / 3.0, F4_B = 1.5;
+#endif
+constexpr float F4_a = (float)F4_A, F4_b = (float)F4_B, F4_a2 = (float)(F4_A * F4_A), F4_b2 = (float)(F4_B * F4_B),
+                F4_a3 = (float)(F4_A * F4_A * F4_A), F4_b3 = (float)(F4_B * F4_B * F4_B), F4_ab2 = (float)(F4_A * F4_A + F4_B * F4_B);
 constexpr int F4_TILES = 32;
 constexpr int F4_THREADS = 512;
 constexpr int F4_COUT = 64;
@@ -53,7 +63,10 @@ constexpr int F4_OPER_FLOATS = F4_NPOS * 64 * F4_KC;     // one 8-channel slab o
 constexpr int F4_VSLOT = F4_TILES * F4_KC + 4;           // 260 = 4 mod 32: the six columns a lane group writes fall on distinct banks
 constexpr int F4_STAGE = F4_NPOS * F4_VSLOT;             // 9360 floats
 constexpr int F4_SCR_ROW = 7 * 4;                        // scratch row: 6 float4 + one of padding (28 dwords: rows on distinct banks)
-constexpr int F4_SCR_UNIT = 224;                         // floats per unit (6 rows used): with this pitch the column reads of the
+#ifndef IDIFF_W43_SCR_UNIT
+#define IDIFF_W43_SCR_UNIT 224
+#endif
+constexpr int F4_SCR_UNIT = IDIFF_W43_SCR_UNIT;                       // floats per unit (6 rows used): with this pitch the column reads of the
                                                          // four 16-lane groups of a ds_read_b128 fall on distinct banks as well (PMC:
                                                          // SQ_LDS_BANK_CONFLICT was 21 % of the LDS cycles at the dense pitch of 168)
 constexpr int F4_SCR_WAVE = 8 * F4_SCR_UNIT;             // 1792 floats per wave
@@ -75,7 +88,13 @@ struct Wino43Params {
   uint32_t x_bytes, u_bytes, out_bytes, res_bytes;
   idiff_epilogue ep;
   int has_ep;
+  // the input transform's constants as kernel arguments: they then live in SGPRs and the twelve operations are plain VOP3 fmas
+  // with a scalar operand; as compile-time literals they became v_fmamk_f32 (a 32-bit literal per instruction), measured 3.7 %
+  // slower over a forward than the dyadic point set whose constants are inline operands (scripts/wino43_ab.py)
+  float c_nb2, c_na2, c_nab2, c_a, c_b;
 };
+
+struct F4Consts { float nb2, na2, nab2, a, b; };
 
 __device__ __forceinline__ void f4_split_tile(const Wino43Params &p, int T, int &img, int &ty, int &tx) {
   if (p.tx_shift >= 0) {
@@ -89,23 +108,22 @@ __device__ __forceinline__ void f4_split_tile(const Wino43Params &p, int T, int 
   }
 }
 
-// the 6-point input transform t = B^T d on one component: 12 operations (the odd parts are formed UNSCALED, d3 - 4 d1 and
-// d3 - 0.25 d1, and their factors 0.5 and 2 ride in the fused multiply-adds that combine them with the even parts; the
-// products by powers of two are exact, so this rounds like the 14-operation form with its separate multiplies)
-__device__ __forceinline__ void f4_bt(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
-                                      float &t0, float &t1, float &t2, float &t3, float &t4, float &t5) {
-  const float pe = fmaf(-4.f, d2, d4), po = fmaf(-4.f, d1, d3);          // t1, t2 = pe +- 0.5 po
-  const float re = fmaf(-0.25f, d2, d4), ro = fmaf(-0.25f, d1, d3);      // t3, t4 = re +- 2 ro
-  t0 = fmaf(-4.25f, d2, d0 + d4);
-  t1 = fmaf(0.5f, po, pe); t2 = fmaf(-0.5f, po, pe);
-  t3 = fmaf(2.f, ro, re); t4 = fmaf(-2.f, ro, re);
-  t5 = fmaf(-4.25f, d3, d1 + d5);
+// the 6-point input transform t = B^T d on one component: 12 operations (the odd parts are formed unscaled, d3 - b^2 d1 and
+// d3 - a^2 d1, and their factors a and b ride in the fused multiply-adds that combine them with the even parts)
+__device__ __forceinline__ void f4_bt(const F4Consts &k, const float d0, const float d1, const float d2, const float d3, const float d4,
+                                      const float d5, float &t0, float &t1, float &t2, float &t3, float &t4, float &t5) {
+  const float pe = fmaf(k.nb2, d2, d4), po = fmaf(k.nb2, d1, d3);          // t1, t2 = pe +- a po
+  const float re = fmaf(k.na2, d2, d4), ro = fmaf(k.na2, d1, d3);          // t3, t4 = re +- b ro
+  t0 = fmaf(k.nab2, d2, d0 + d4);
+  t1 = fmaf(k.a, po, pe); t2 = fmaf(-k.a, po, pe);
+  t3 = fmaf(k.b, ro, re); t4 = fmaf(-k.b, ro, re);
+  t5 = fmaf(k.nab2, d3, d1 + d5);
 }
-__device__ __forceinline__ void f4_bt4(const float4 (&d)[6], float4 (&t)[6]) {
-  f4_bt(d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x, t[0].x, t[1].x, t[2].x, t[3].x, t[4].x, t[5].x);
-  f4_bt(d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y, t[0].y, t[1].y, t[2].y, t[3].y, t[4].y, t[5].y);
-  f4_bt(d[0].z, d[1].z, d[2].z, d[3].z, d[4].z, d[5].z, t[0].z, t[1].z, t[2].z, t[3].z, t[4].z, t[5].z);
-  f4_bt(d[0].w, d[1].w, d[2].w, d[3].w, d[4].w, d[5].w, t[0].w, t[1].w, t[2].w, t[3].w, t[4].w, t[5].w);
+__device__ __forceinline__ void f4_bt4(const F4Consts &k, const float4 (&d)[6], float4 (&t)[6]) {
+  f4_bt(k, d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x, t[0].x, t[1].x, t[2].x, t[3].x, t[4].x, t[5].x);
+  f4_bt(k, d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y, t[0].y, t[1].y, t[2].y, t[3].y, t[4].y, t[5].y);
+  f4_bt(k, d[0].z, d[1].z, d[2].z, d[3].z, d[4].z, d[5].z, t[0].z, t[1].z, t[2].z, t[3].z, t[4].z, t[5].z);
+  f4_bt(k, d[0].w, d[1].w, d[2].w, d[3].w, d[4].w, d[5].w, t[0].w, t[1].w, t[2].w, t[3].w, t[4].w, t[5].w);
 }
 
 // one wave exchanging data through LDS with itself: DS operations of a wave execute in order; the compiler must neither
@@ -164,6 +182,7 @@ winograd43_kernel(const Wino43Params p) {
   // V(i, c = lr) of (ltile, quad lq): slot 6 i + lr, row ltile, 16-byte half lq swapped when bit 3 of the tile is set
   const int v_dst = lr * F4_VSLOT + ltile * F4_KC + 4 * (lq ^ ((ltile >> 3) & 1));
 
+  const F4Consts kc = {p.c_nb2, p.c_na2, p.c_nab2, p.c_a, p.c_b};
   float4 ldv[6];
   const int nsteps = p.Cin / F4_KC;
   int f_step = 0;
@@ -175,7 +194,7 @@ winograd43_kernel(const Wino43Params p) {
   };
   auto stage = [&](int buf) {
     float4 t[6];
-    f4_bt4(ldv, t);                                   // along x
+    f4_bt4(kc, ldv, t);                               // along x
     if (lact) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) *reinterpret_cast<float4 *>(scr_row + 4 * c) = t[c];
@@ -184,7 +203,7 @@ winograd43_kernel(const Wino43Params p) {
     float4 d[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const float4 *>(scr_col + r * F4_SCR_ROW);
-    f4_bt4(d, t);                                     // along y
+    f4_bt4(kc, d, t);                                 // along y
     f4_wave_lds_sync();                               // the scratch is free again before this wave's next stage()
     if (lact) {
       float *Vd = lds + buf * F4_STAGE + v_dst;
@@ -323,8 +342,8 @@ winograd43_kernel(const Wino43Params p) {
           const float m3 = acc[ii * 3][reg], m4 = acc[ii * 3 + 1][reg], m5 = acc[ii * 3 + 2][reg];
           const int trow = (reg & 3) + 8 * (reg >> 2);
           float *zp = zbase + (((3 * wa + ii) * F4_TILES + trow) * 2) * F4_COUT;
-          if (pass == 0) { zp[0] = m3 + m4; zp[F4_COUT] = 2.f * (m3 - m4); }
-          else { zp[0] = 4.f * (m3 + m4); zp[F4_COUT] = fmaf(8.f, m3 - m4, m5); }
+          if (pass == 0) { zp[0] = m3 + m4; zp[F4_COUT] = F4_b * (m3 - m4); }
+          else { zp[0] = F4_b2 * (m3 + m4); zp[F4_COUT] = fmaf(F4_b3, m3 - m4, m5); }
         }
     }
     __syncthreads();
@@ -336,8 +355,8 @@ winograd43_kernel(const Wino43Params p) {
           const float m0 = acc[ii * 3][reg], m1 = acc[ii * 3 + 1][reg], m2 = acc[ii * 3 + 2][reg];
           const int trow = (reg & 3) + 8 * (reg >> 2);
           float *zp = zbase + (((3 * wa + ii) * F4_TILES + trow) * 2) * F4_COUT;
-          if (pass == 0) { zp[0] += m0 + (m1 + m2); zp[F4_COUT] = fmaf(0.5f, m1 - m2, zp[F4_COUT]); }
-          else { zp[0] = fmaf(0.25f, m1 + m2, zp[0]); zp[F4_COUT] = fmaf(0.125f, m1 - m2, zp[F4_COUT]); }
+          if (pass == 0) { zp[0] += m0 + (m1 + m2); zp[F4_COUT] = fmaf(F4_a, m1 - m2, zp[F4_COUT]); }
+          else { zp[0] = fmaf(F4_a2, m1 + m2, zp[0]); zp[F4_COUT] = fmaf(F4_a3, m1 - m2, zp[F4_COUT]); }
         }
     }
     __syncthreads();
@@ -364,9 +383,9 @@ winograd43_kernel(const Wino43Params p) {
       {                                                                                                      \
         const float s12 = z[1].cmp + z[2].cmp, d12 = z[1].cmp - z[2].cmp, s34 = z[3].cmp + z[4].cmp, d34 = z[3].cmp - z[4].cmp; \
         y[0][e] = z[0].cmp + (s12 + s34);                                                                     \
-        y[1][e] = fmaf(2.f, d34, 0.5f * d12);                                                                 \
-        y[2][e] = fmaf(4.f, s34, 0.25f * s12);                                                                \
-        y[3][e] = fmaf(8.f, d34, fmaf(0.125f, d12, z[5].cmp));                                                \
+        y[1][e] = fmaf(F4_b, d34, F4_a * d12);                                                                \
+        y[2][e] = fmaf(F4_b2, s34, F4_a2 * s12);                                                              \
+        y[3][e] = fmaf(F4_b3, d34, fmaf(F4_a3, d12, z[5].cmp));                                               \
       }
       IDIFF_F4_AT(x, 0) IDIFF_F4_AT(y, 1) IDIFF_F4_AT(z, 2) IDIFF_F4_AT(w, 3)
 #undef IDIFF_F4_AT
@@ -441,11 +460,14 @@ winograd43_kernel(const Wino43Params p) {
 
 // U = G g G^T in fp64, rounded once; g[ky][kx] = wt[cout][ky][kx][cin] (the K-contiguous panel of the direct kernel)
 __global__ void winograd43_pack_kernel(const float *wt, float *u, int Cin, int Cout) {
-  const double G[6][3] = {{1.0, 0.0, 0.0},
-                          {-8.0 / 15.0, -4.0 / 15.0, -2.0 / 15.0},
-                          {-8.0 / 15.0, 4.0 / 15.0, -2.0 / 15.0},
-                          {1.0 / 30.0, 2.0 / 30.0, 4.0 / 30.0},
-                          {1.0 / 30.0, -2.0 / 30.0, 4.0 / 30.0},
+  // G row of point p: (1, p, p^2) / N(p), N(p) = prod over the other finite points (p - q); N(0) = a^2 b^2 = 1,
+  // N(+-a) = 2 a^2 (a^2 - b^2), N(+-b) = 2 b^2 (b^2 - a^2); the point at infinity picks g[2]
+  const double a = F4_A, b = F4_B, na = 1.0 / (2.0 * a * a * (a * a - b * b)), nb = 1.0 / (2.0 * b * b * (b * b - a * a)), n0 = 1.0 / (a * a * b * b);
+  const double G[6][3] = {{n0, 0.0, 0.0},
+                          {na, a * na, a * a * na},
+                          {na, -a * na, a * a * na},
+                          {nb, b * nb, b * b * nb},
+                          {nb, -b * nb, b * b * nb},
                           {0.0, 0.0, 1.0}};
   const int64_t total = (int64_t)Cin * Cout;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -544,6 +566,7 @@ IDIFF_API int idiff_conv2d_winograd43_f32(const float *x, const float *u, float 
   } else {
     p.has_ep = 0; p.ep.rows_per_group = 1; p.ep.out_scale = 1.f;
   }
+  p.c_nb2 = -F4_b2; p.c_na2 = -F4_a2; p.c_nab2 = -F4_ab2; p.c_a = F4_a; p.c_b = F4_b;
   static AttrGuard guard;
   const void *fn = reinterpret_cast<const void *>(winograd43_kernel);
   if (int rc = set_dynamic_lds_once(guard, &fn, 1, (int)F4_LDS_BYTES, "conv2d_winograd43")) return rc;
