@@ -54,6 +54,21 @@ constexpr double F4_A = 2.0 / 3.0, F4_B = 1.5;
 #endif
 constexpr float F4_a = (float)F4_A, F4_b = (float)F4_B, F4_a2 = (float)(F4_A * F4_A), F4_b2 = (float)(F4_B * F4_B),
                 F4_a3 = (float)(F4_A * F4_A * F4_A), F4_b3 = (float)(F4_B * F4_B * F4_B), F4_ab2 = (float)(F4_A * F4_A + F4_B * F4_B);
+#ifndef IDIFF_W43_EARLY_WAVES
+#define IDIFF_W43_EARLY_WAVES 2
+#endif
+constexpr int F4_EARLY_WAVES = IDIFF_W43_EARLY_WAVES;   // waves 0 .. n-1 transform at the start of a step, the others late (A/B)
+#ifndef IDIFF_W43_MID_WAVES
+#define IDIFF_W43_MID_WAVES IDIFF_W43_EARLY_WAVES
+#endif
+#ifndef IDIFF_W43_MID_AT
+#define IDIFF_W43_MID_AT 3
+#endif
+constexpr int F4_MID_WAVES = IDIFF_W43_MID_WAVES, F4_MID_AT = IDIFF_W43_MID_AT;   // waves EARLY .. MID-1 transform in front of position MID_AT
+#ifndef IDIFF_W43_LATE_AT
+#define IDIFF_W43_LATE_AT 6
+#endif
+constexpr int F4_LATE_AT = IDIFF_W43_LATE_AT;   // the late role transforms in front of this position of its step (A/B: scripts/wino43_ab.py)
 constexpr int F4_TILES = 32;
 constexpr int F4_THREADS = 512;
 constexpr int F4_COUT = 64;
@@ -240,33 +255,33 @@ winograd43_kernel(const Wino43Params p) {
   auto v_at = [&](const float *S, int pp) { return *reinterpret_cast<const float4 *>(S + ((pp / 3) * 6 + (pp % 3)) * F4_VSLOT); };
   // LAST: the final step requests nothing (no next slab, no next input) and writes no stage -- the tail would only wait for
   // loads nobody uses
-  auto compute = [&](int buf, int s, auto before_last, auto last) {
+  // AT: the position of the step in front of which this wave transforms and stages the NEXT step's input (0: at the start of
+  // the step, "early"; 9: never, the last step).  Waves get different AT (compile-time per loop copy) so that the transforms of
+  // a CU are spread over the step instead of piling up behind the barrier.
+  auto compute = [&](int buf, int s, auto at, auto last) {
     constexpr bool LAST = decltype(last)::value;
+    constexpr int AT = decltype(at)::value;
     const float *S = lds + buf * F4_STAGE + a_frag;
     float4 f0 = v_at(S, 0), f1 = v_at(S, 1);
 #pragma unroll
     for (int pp = 0; pp < 9; ++pp) {
       __builtin_amdgcn_sched_barrier(0);
-      if (pp == 6) { before_last(); __builtin_amdgcn_sched_barrier(0); }
+      if (pp == AT && AT > 0) { stage(buf ^ 1); fetch(); __builtin_amdgcn_sched_barrier(0); }
       mfma4(pp, (pp & 1) ? f1 : f0);
       // the register set is free once these MFMAs have read it: request the position three ahead (of the next step beyond 8)
       if (pp + 3 < 9) load_b(pp + 3, s); else if (!LAST) load_b(pp + 3 - 9, s + 1);
       if (pp + 2 < 9) { if (pp & 1) f1 = v_at(S, pp + 2); else f0 = v_at(S, pp + 2); }
     }
   };
-  auto step = [&](int s, auto is_early, auto last) {
+  auto step = [&](int s, auto at, auto last) {
     constexpr bool LAST = decltype(last)::value;
+    constexpr int AT = decltype(at)::value;
     const int buf = s & 1;
-    if constexpr (LAST) {
-      compute(buf, s, [] {}, last);
-    } else if constexpr (decltype(is_early)::value) {
-      stage(buf ^ 1); fetch();
-      compute(buf, s, [] {}, last);
-    } else {
-      compute(buf, s, [&] { stage(buf ^ 1); fetch(); }, last);
-    }
+    if constexpr (!LAST && AT == 0) { stage(buf ^ 1); fetch(); }
+    compute(buf, s, at, last);
     __syncthreads();
   };
+  auto run = [&](auto at) { for (int s = 0; s + 1 < nsteps; ++s) step(s, at, std::false_type()); };
 
   load_b(0, 0); load_b(1, 0); load_b(2, 0);
   fetch();
@@ -276,9 +291,10 @@ winograd43_kernel(const Wino43Params p) {
 #ifdef IDIFF_W43_STAMP
   const uint64_t st_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (wave < 4) { for (int s = 0; s + 1 < nsteps; ++s) step(s, std::true_type(), std::false_type()); }
-  else { for (int s = 0; s + 1 < nsteps; ++s) step(s, std::false_type(), std::false_type()); }
-  step(nsteps - 1, std::true_type(), std::true_type());
+  if (wave < F4_EARLY_WAVES) run(std::integral_constant<int, 0>());
+  else if (wave < F4_MID_WAVES) run(std::integral_constant<int, F4_MID_AT>());
+  else run(std::integral_constant<int, F4_LATE_AT>());
+  step(nsteps - 1, std::integral_constant<int, 9>(), std::true_type());
 #ifdef IDIFF_W43_STAMP
   const uint64_t st_loop1 = __builtin_amdgcn_s_memrealtime();
 #endif
