@@ -65,6 +65,10 @@ constexpr int F4_EARLY_WAVES = IDIFF_W43_EARLY_WAVES;   // waves 0 .. n-1 transf
 #define IDIFF_W43_MID_AT 3
 #endif
 constexpr int F4_MID_WAVES = IDIFF_W43_MID_WAVES, F4_MID_AT = IDIFF_W43_MID_AT;   // waves EARLY .. MID-1 transform in front of position MID_AT
+#ifndef IDIFF_W43_VRING
+#define IDIFF_W43_VRING 2
+#endif
+constexpr int F4_VRING = IDIFF_W43_VRING;   // V fragments in flight ahead of their MFMAs (register sets)
 #ifndef IDIFF_W43_LATE_AT
 #define IDIFF_W43_LATE_AT 6
 #endif
@@ -262,15 +266,17 @@ winograd43_kernel(const Wino43Params p) {
     constexpr bool LAST = decltype(last)::value;
     constexpr int AT = decltype(at)::value;
     const float *S = lds + buf * F4_STAGE + a_frag;
-    float4 f0 = v_at(S, 0), f1 = v_at(S, 1);
+    float4 f[F4_VRING];
+#pragma unroll
+    for (int q = 0; q < F4_VRING; ++q) f[q] = v_at(S, q);
 #pragma unroll
     for (int pp = 0; pp < 9; ++pp) {
       __builtin_amdgcn_sched_barrier(0);
       if (pp == AT && AT > 0) { stage(buf ^ 1); fetch(); __builtin_amdgcn_sched_barrier(0); }
-      mfma4(pp, (pp & 1) ? f1 : f0);
+      mfma4(pp, f[pp % F4_VRING]);
       // the register set is free once these MFMAs have read it: request the position three ahead (of the next step beyond 8)
       if (pp + 3 < 9) load_b(pp + 3, s); else if (!LAST) load_b(pp + 3 - 9, s + 1);
-      if (pp + 2 < 9) { if (pp & 1) f1 = v_at(S, pp + 2); else f0 = v_at(S, pp + 2); }
+      if (pp + F4_VRING < 9) f[pp % F4_VRING] = v_at(S, pp + F4_VRING);
     }
   };
   auto step = [&](int s, auto at, auto last) {
