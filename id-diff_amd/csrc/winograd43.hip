@@ -356,6 +356,17 @@ winograd43_kernel(const Wino43Params p) {
   for (int pass = 0; pass < 2; ++pass) {
     // z_{i,b} for b = 2 pass, 2 pass + 1 and the three rows i of this wave's block: column block 1 parks, block 0 adds
     if (pass) __syncthreads();                       // every z of the first pass has been read
+    // the residual operands of this pass's two output columns are requested HERE, in front of the exchange that covers their
+    // latency (requested at their point of use they cost 3 us per workgroup: four exposed round trips)
+    float4 res[2][4];
+    if (has_res) {
+      prep();
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          res[bb][a] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)roff, (a * p.W + 2 * pass + bb) * ld_res * 4, 0));
+    }
     if (wb == 1) {
 #pragma unroll
       for (int ii = 0; ii < 3; ++ii)
@@ -387,19 +398,13 @@ winograd43_kernel(const Wino43Params p) {
 #endif
     __builtin_amdgcn_sched_barrier(0);
     prep();
-#pragma unroll 1
-    for (int bb = 0; bb < 2; ++bb) {                 // rolled: the two columns do not need their operands in flight together
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
       const float *zr = lds + (tl * 2 + bb) * F4_COUT + 4 * cq;
       float4 z[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) z[i] = *reinterpret_cast<const float4 *>(zr + i * (F4_TILES * 2 * F4_COUT));
-      float4 res[4];
       const int b = 2 * pass + bb;
-      if (has_res) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-          res[a] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)roff, (a * p.W + b) * ld_res * 4, 0));
-      }
       float y[4][4];
 #define IDIFF_F4_AT(cmp, e)                                                                                  \
       {                                                                                                      \
@@ -418,7 +423,7 @@ winograd43_kernel(const Wino43Params p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[a][e] = idiff::act_apply(y[a][e], act);
         }
-        if (has_res) { y[a][0] += res[a].x; y[a][1] += res[a].y; y[a][2] += res[a].z; y[a][3] += res[a].w; }
+        if (has_res) { y[a][0] += res[bb][a].x; y[a][1] += res[bb][a].y; y[a][2] += res[bb][a].z; y[a][3] += res[bb][a].w; }
         if (scaled) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[a][e] *= sc;
