@@ -44,6 +44,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6
 # split-precision contractions (igemm.hip, SPLIT): six bf16 MFMA products per fp32 product -> the fp32-equivalent ceiling is
 # the dense bf16 peak (2.5 PFLOP/s) / 6
 BF16_MFMA_PEAK_TFLOPS = 2500.0
+F16_MFMA_PEAK_TFLOPS = 2500.0        # the fp16 forms take the same cycles as the bf16 ones (MI355X_MICROARCH.md, matrix-core table)
+L2_READ_PEAK_GBS = 18800.0           # upper end of the guide's measured 16.8-18.8 TB/s for rows every workgroup reads from L2
 SPLIT_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 HBM_PEAK_GBS = 8000.0
 # fp32 tensors end to end.  3x3 convolutions: exact-fp32 matrix cores (Winograd F(2x2,3x3)).  1x1 / NIN / attention / dense
@@ -51,12 +53,16 @@ HBM_PEAK_GBS = 8000.0
 # >= 2^-16) run on the bf16 matrix cores with fp32 accumulation -- 1.7e-7 against an fp64 contraction where the fp32 MFMA
 # chain gives 2.0e-7 (scripts/bf16x6_probe.hip); every parity bar of tests/ is unchanged.  IDIFF_NO_SPLIT=1 selects fp32 MFMAs.
 DTYPE = "f32" if os.environ.get("IDIFF_NO_SPLIT") else \
-    "f32 (3x3 convs: fp32 MFMA, Winograd F(4x4,3x3) / F(2x2,3x3); 1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate)"
+    "f32 (3x3 convs: Winograd F(4x4,3x3), fp32 transforms, contraction on pairs of fp16 values -- 22 significand bits, 3 products, fp32 accumulate; F(2x2,3x3) on fp32 MFMA for the 4x4 maps; 1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate)"
 WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=1e-5, B=128 -> S 4480x3072 + centred spectrum + ID"
 # PMC traffic tables (separate FETCH_SIZE / WRITE_SIZE passes, scripts/profile_round.sh), each stamped with the sha256 of the kernel
 # source it was measured on: F(4x4,3x3) (the dominant kernel) and F(2x2,3x3)
-TRAFFIC_TABLES = {"winograd43_kernel": (os.path.join("profiles", "r04_wino43_traffic.json"), os.path.join("id-diff_amd", "csrc", "winograd43.hip")),
-                  "winograd_kernel": (os.path.join("profiles", "r03_wino_traffic.json"), os.path.join("id-diff_amd", "csrc", "winograd.hip"))}
+_CSRC = os.path.join("id-diff_amd", "csrc")
+TRAFFIC_TABLES = {"winograd43h_kernel": (os.path.join("profiles", "r04_wino43h_traffic.json"),
+                                         (os.path.join(_CSRC, "winograd43h.hip"), os.path.join(_CSRC, "winograd43_shared.h"))),
+                  "winograd43_kernel": (os.path.join("profiles", "r04_wino43_traffic.json"),
+                                        (os.path.join(_CSRC, "winograd43.hip"), os.path.join(_CSRC, "winograd43_shared.h"))),
+                  "winograd_kernel": (os.path.join("profiles", "r03_wino_traffic.json"), (os.path.join(_CSRC, "winograd.hip"),))}
 
 
 def _sync(dev):
@@ -64,9 +70,13 @@ def _sync(dev):
         torch.cuda.synchronize()
 
 
-def source_sha256(rel):
-    with open(os.path.join(ROOT, rel), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()
+def source_sha256(rels):
+    """sha256 over the concatenated sources of a kernel (scripts/parse_wino_traffic.py stamps its tables the same way)"""
+    h = hashlib.sha256()
+    for rel in rels:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 class KernelProbe:
@@ -107,9 +117,10 @@ class KernelProbe:
             # executed flops of F(2x2,3x3): 16 positions x [tiles x Cin] x [Cin x Cout]; the implicit GEMM would be 2.25x that
             return "winograd_kernel", 2.0 * 16 * (B * H * W // 4) * Cin * Cout, f"{B}x{H}x{W}x{Cin}->{Cout}"
 
-        def wino43(x, u, out, B, H, W, Cin, Cout, epilogue=None):
-            # executed flops of F(4x4,3x3): 36 positions x [tiles x Cin] x [Cin x Cout]; the implicit GEMM would be 4x that
-            return "winograd43_kernel", 2.0 * 36 * (B * H * W // 16) * Cin * Cout, f"{B}x{H}x{W}x{Cin}->{Cout}"
+        def wino43(x, u, out, B, H, W, Cin, Cout, epilogue=None, pairs=False):
+            # executed flops of F(4x4,3x3): 36 positions x [tiles x Cin] x [Cin x Cout]; the implicit GEMM would be 4x that.  On fp16
+            # pairs (winograd43h_kernel) each of them is three fp16 products: counted once, as one fp32-equivalent multiply-add
+            return ("winograd43h_kernel" if pairs else "winograd43_kernel"), 2.0 * 36 * (B * H * W // 16) * Cin * Cout, f"{B}x{H}x{W}x{Cin}->{Cout}"
 
         def gn_apply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None):
             return "gn_apply_rows", 8.0 * B * HW * (C + (C2 or 0)), f"{B}x{HW}x{C + (C2 or 0)}"
@@ -181,15 +192,34 @@ def winograd_traffic(keys, kernel="winograd_kernel"):
             "source": table_rel, "kernel_source_sha256": doc["kernel_source_sha256"]}
 
 
+def winograd43h_l2_bytes(keys):
+    """Bytes winograd43h_kernel pulls from L2 per launch, by construction: per workgroup (32 tiles x 64 output channels) and K step
+    (16 channels) the filter slab 36 x 64 x 16 x 4 B (fp16 pairs) and the 32 input patches 36 x 16 x 4 B each."""
+    tot = 0.0
+    for k in keys:
+        B, H, W, rest = k.split("x")
+        Cin, Cout = rest.split("->")
+        B, H, W, Cin, Cout = map(int, (B, H, W, Cin, Cout))
+        wgs = ((B * (H // 4) * (W // 4) + 31) // 32) * (Cout // 64)
+        tot += wgs * (Cin // 16) * (36 * 64 * 16 * 4 + 32 * 36 * 16 * 4)
+    return tot / len(keys)
+
+
 def roofline_report(probe):
-    dom43, dom22 = probe.group("winograd43_kernel"), probe.group("winograd_kernel")
-    dom = dom43 or dom22
+    dom43h, dom43, dom22 = probe.group("winograd43h_kernel"), probe.group("winograd43_kernel"), probe.group("winograd_kernel")
+    dom = dom43h or dom43 or dom22
     if dom is None:
         return None
     tfl = dom["rate"] / 1e12
-    traffic = winograd_traffic(dom["keys"], "winograd43_kernel" if dom43 is not None else "winograd_kernel")
+    dom_name = "winograd43h_kernel" if dom43h is not None else ("winograd43_kernel" if dom43 is not None else "winograd_kernel")
+    traffic = winograd_traffic(dom["keys"], dom_name)
     kernels = []
-    if dom43 is not None and dom22 is not None:
+    if dom43h is not None and dom43 is not None:
+        t43 = dom43["rate"] / 1e12
+        kernels.append({"kernel": "winograd43_kernel (F(4x4,3x3), fp32 contraction: inputs not fed by a GroupNorm, Cin % 16 != 0)", "bound": "mfma",
+                        "achieved": t43, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": t43 / FP32_MFMA_PEAK_TFLOPS,
+                        "launches_sampled": dom43["launches"], "avg_launch_us": dom43["avg_us"]})
+    if dom_name != "winograd_kernel" and dom22 is not None:
         t22 = dom22["rate"] / 1e12
         kernels.append({"kernel": "winograd_kernel (F(2x2,3x3): the 4x4 maps and launches too small for the 4x4 form)", "bound": "mfma",
                         "achieved": t22, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": t22 / FP32_MFMA_PEAK_TFLOPS,
@@ -218,7 +248,19 @@ def roofline_report(probe):
         else:
             kernels.append({"kernel": name, "bound": "hbm", "achieved": g["rate"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": g["rate"] / 1e9 / HBM_PEAK_GBS, "launches_sampled": g["launches"], "avg_launch_us": g["avg_us"]})
-    if dom43 is not None:
+    peak, extra = FP32_MFMA_PEAK_TFLOPS, {}
+    if dom43h is not None:
+        name = ("winograd43h_kernel (3x3 conv as F(4x4,3x3): 36 [tiles x Cin] x [Cin x Cout] contractions per launch on "
+                "v_mfma_f32_32x32x16_f16, each fp32 operand a pair of fp16 values, 3 fp16 products per fp32 multiply-add)")
+        counted, ratio = ("executed Winograd-domain multiply-adds, each counted ONCE (fp32-equivalent; the matrix cores execute three fp16 "
+                          "products for it, so the peak is the dense fp16 peak / 3; the implicit GEMM of the same conv is 4x more)"), 4.0
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0
+        # the kernel's actual limiter: every CU pulls its filter slabs and input patches through L2 (no reuse within a workgroup beyond
+        # its 32 tiles x 64 channels); MI355X_MICROARCH.md measures 16.8-18.8 TB/s for rows every workgroup reads from its XCD's L2
+        l2 = winograd43h_l2_bytes(dom["keys"]) / (dom["avg_us"] * 1e-6) / 1e9
+        extra = {"l2_read": {"achieved": l2, "peak": L2_READ_PEAK_GBS, "unit": "GB/s", "frac": l2 / L2_READ_PEAK_GBS,
+                             "bytes": "per workgroup and 16-channel step: 147,456 B of filter pairs + 73,728 B of input patches, by construction"}}
+    elif dom43 is not None:
         name = ("winograd43_kernel (3x3 conv as F(4x4,3x3): 36 [tiles x Cin] x [Cin x Cout] contractions per launch, "
                 "v_mfma_f32_32x32x2_f32)")
         counted, ratio = "executed Winograd-domain multiply-adds (the implicit GEMM of the same conv is 4x more)", 4.0
@@ -226,14 +268,16 @@ def roofline_report(probe):
         name = ("winograd_kernel (3x3 conv as F(2x2,3x3): 16 [tiles x Cin] x [Cin x Cout] contractions per launch, "
                 "v_mfma_f32_32x32x2_f32)")
         counted, ratio = "executed Winograd-domain multiply-adds (the implicit GEMM of the same conv is 2.25x more)", 2.25
-    return {"bound": "mfma", "kernel": name,
-            "achieved": tfl, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP32_MFMA_PEAK_TFLOPS,
-            "flops_counted": counted,
-            "direct_conv_equivalent_tflops": tfl * ratio,
-            "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
-            "launches_sampled": dom["launches"], "avg_launch_us": dom["avg_us"],
-            "sampled_in": "a second, untimed pass over the same points (spectrum overlap on, as in the timed region)",
-            "kernels": kernels}
+    out = {"bound": "mfma", "kernel": name,
+           "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
+           "flops_counted": counted,
+           "direct_conv_equivalent_tflops": tfl * ratio,
+           "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
+           "launches_sampled": dom["launches"], "avg_launch_us": dom["avg_us"],
+           "sampled_in": "a second, untimed pass over the same points (spectrum overlap on, as in the timed region)",
+           "kernels": kernels}
+    out.update(extra)
+    return out
 
 
 def spectrum_stage_report(rows, D, dev, reps=3):

@@ -55,6 +55,10 @@ _SIGNATURES = {
     "idiff_winograd43_weight_floats": (c_i64, [c_i, c_i]),
     "idiff_winograd43_pack_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "idiff_conv2d_winograd43_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),
+    "idiff_conv2d_winograd43h_ok": (c_i, [c_i] * 5),
+    "idiff_winograd43h_weight_floats": (c_i64, [c_i, c_i]),
+    "idiff_winograd43h_pack_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    "idiff_conv2d_winograd43h_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),
     "idiff_conv2d_winograd_split_ok": (c_i, [c_i] * 5),
     "idiff_winograd_split_weight_floats": (c_i64, [c_i, c_i]),
     "idiff_winograd_pack_split_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
@@ -359,18 +363,36 @@ def conv2d_winograd43_colstats_split(B, H, W, Cin, Cout):
     return lib().idiff_conv2d_winograd43_colstats_split(B, H, W, Cin, Cout)
 
 
-def winograd43_pack(wt, Cin, Cout):
-    """wt [Cout, 3, 3, Cin] -> the transformed filter bank of idiff_conv2d_winograd43_f32 (36 * Cin * Cout floats)."""
+def conv2d_winograd43h_ok(B, H, W, Cin, Cout):
+    """True when the fp16-pair F(4x4, 3x3) kernel serves this geometry (IDIFF_NO_WINO43H and the fp32 form's switches turn it off)."""
+    return bool(lib().idiff_conv2d_winograd43h_ok(B, H, W, Cin, Cout))
+
+
+def winograd43_pack(wt, Cin, Cout, pairs=False):
+    """wt [Cout, 3, 3, Cin] -> the transformed filter bank of idiff_conv2d_winograd43_f32 (36 * Cin * Cout floats), or with
+    pairs=True that of idiff_conv2d_winograd43h_f32 (scaled fp16 pairs, 36 * Cin * Cout + 4 floats)."""
     _dev(wt, "wt")
     if wt.numel() != Cout * 9 * Cin:
         raise RuntimeError(f"winograd43_pack: expected {Cout}x3x3x{Cin} weights, got {tuple(wt.shape)}")
+    if pairs:
+        u = torch.empty(lib().idiff_winograd43h_weight_floats(Cin, Cout), device=wt.device, dtype=torch.float32)
+        _check(lib().idiff_winograd43h_pack_f32(wt.data_ptr(), u.data_ptr(), Cin, Cout, _stream()), "idiff_winograd43h_pack_f32")
+        return u
     u = torch.empty(lib().idiff_winograd43_weight_floats(Cin, Cout), device=wt.device, dtype=torch.float32)
     _check(lib().idiff_winograd43_pack_f32(wt.data_ptr(), u.data_ptr(), Cin, Cout, _stream()), "idiff_winograd43_pack_f32")
     return u
 
 
-def conv2d_winograd43(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+def conv2d_winograd43(x, u, out, B, H, W, Cin, Cout, epilogue=None, pairs=False):
+    """pairs: `u` is a bank of fp16 pairs (winograd43_pack(..., pairs=True)) and the contraction runs on the fp16 matrix cores."""
     ep = ctypes.byref(epilogue) if epilogue is not None else None
+    if pairs:
+        if u.numel() != 36 * Cin * Cout + 4:
+            raise RuntimeError(f"conv2d_winograd43: a bank of {u.numel()} floats ({36 * Cin * Cout + 4} expected): pack it with "
+                               "winograd43_pack(..., pairs=True)")
+        _check(lib().idiff_conv2d_winograd43h_f32(x.data_ptr(), u.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, ep, _stream()),
+               "idiff_conv2d_winograd43h_f32")
+        return out
     if u.numel() != 36 * Cin * Cout:
         raise RuntimeError(f"conv2d_winograd43: a filter bank of {u.numel()} floats ({36 * Cin * Cout} expected): pack it with winograd43_pack")
     _check(lib().idiff_conv2d_winograd43_f32(x.data_ptr(), u.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, ep, _stream()),

@@ -35,25 +35,10 @@
 //   two parts: the waves of column block 1 park their part in LDS, those of block 0 add theirs on top ([6 i][32 tiles][2 b][64 cout]
 //   fp32 = 96 KB per pass over the dead stages, two passes: output columns b = 0, 1 and b = 2, 3); then every thread owns one
 //   (tile, 4-channel group) and finishes y_{a,b} = sum_i A^T[a][i] z_{i,b} with the fused epilogue and 16-byte stores.
-#include "common.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "winograd43_shared.h"
 
 namespace {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
-
-// Interpolation points 0, +-a, +-b, infinity with a b = 1 (reciprocal pairs keep the transforms balanced): a = 2/3, b = 3/2.
-// (scripts/f43_emulation.py on the whole network: rel_err(S) 3.3e-6 for this set, 4.9e-6 for 1/2, 2 -- whose constants are all
-// dyadic -- and 7.0e-6 for Lavin's 1, 2.)  The transforms use these fp32 constants; G is evaluated in fp64 from the same a, b.
-#ifdef IDIFF_W43_DYADIC_POINTS   // A/B builds only (scripts/wino43_ab.py): the dyadic set 1/2, 2
-constexpr double F4_A = 0.5, F4_B = 2.0;
-#else
-constexpr double F4_A = 2.0 / 3.0, F4_B = 1.5;
-#endif
-constexpr float F4_a = (float)F4_A, F4_b = (float)F4_B, F4_a2 = (float)(F4_A * F4_A), F4_b2 = (float)(F4_B * F4_B),
-                F4_a3 = (float)(F4_A * F4_A * F4_A), F4_b3 = (float)(F4_B * F4_B * F4_B), F4_ab2 = (float)(F4_A * F4_A + F4_B * F4_B);
 #ifndef IDIFF_W43_EARLY_WAVES
 #define IDIFF_W43_EARLY_WAVES 2
 #endif
@@ -73,12 +58,6 @@ constexpr int F4_VRING = IDIFF_W43_VRING;   // V fragments in flight ahead of th
 #define IDIFF_W43_LATE_AT 6
 #endif
 constexpr int F4_LATE_AT = IDIFF_W43_LATE_AT;   // the late role transforms in front of this position of its step (A/B: scripts/wino43_ab.py)
-constexpr int F4_TILES = 32;
-constexpr int F4_THREADS = 512;
-constexpr int F4_COUT = 64;
-constexpr int F4_KC = 8;
-constexpr int F4_NPOS = 36;
-constexpr int F4_OPER_FLOATS = F4_NPOS * 64 * F4_KC;     // one 8-channel slab of U for 64 output channels: 18432 floats = 72 KB
 constexpr int F4_VSLOT = F4_TILES * F4_KC + 4;           // 260 = 4 mod 32: the six columns a lane group writes fall on distinct banks
 constexpr int F4_STAGE = F4_NPOS * F4_VSLOT;             // 9360 floats
 constexpr int F4_SCR_ROW = 7 * 4;                        // scratch row: 6 float4 + one of padding (28 dwords: rows on distinct banks)
@@ -90,54 +69,8 @@ constexpr int F4_SCR_UNIT = IDIFF_W43_SCR_UNIT;                       // floats 
                                                          // SQ_LDS_BANK_CONFLICT was 21 % of the LDS cycles at the dense pitch of 168)
 constexpr int F4_SCR_WAVE = 8 * F4_SCR_UNIT;             // 1792 floats per wave
 constexpr int F4_SCRATCH = 8 * F4_SCR_WAVE;              // 14336 floats
-constexpr int F4_Z_FLOATS = 6 * F4_TILES * 2 * F4_COUT;  // the tail's exchange: [6 rows][tiles][2 columns][64 cout] = 24576 floats
 constexpr int F4_LOOP_FLOATS = 2 * F4_STAGE + F4_SCRATCH + 8;   // + 8: lane 7 of the last group reads one float4 past its unit
 constexpr size_t F4_LDS_BYTES = sizeof(float) * (size_t)(F4_LOOP_FLOATS > F4_Z_FLOATS ? F4_LOOP_FLOATS : F4_Z_FLOATS);   // 132,256 B
-constexpr int64_t F4_X_LIMIT = 0xFFFF0000ll;
-constexpr uint32_t F4_INVALID = 0xFFFF8000u;             // beyond any valid extent (the scalar step offset is not range-checked)
-
-struct Wino43Params {
-  const float *x;
-  const float *u;
-  float *out;
-  int B, H, W, Cin, Cout;
-  int tiles_x, tiles_y, tiles_per_img, total_tiles;
-  int tx_shift, tpi_shift;        // log2 of tiles_x / tiles_per_img when both are powers of two, else -1 (division)
-  int tiles_m, tiles_n, ngroup;
-  uint32_t x_bytes, u_bytes, out_bytes, res_bytes;
-  idiff_epilogue ep;
-  int has_ep;
-  // the input transform's constants as kernel arguments: they then live in SGPRs and the twelve operations are plain VOP3 fmas
-  // with a scalar operand; as compile-time literals they became v_fmamk_f32 (a 32-bit literal per instruction), measured 3.7 %
-  // slower over a forward than the dyadic point set whose constants are inline operands (scripts/wino43_ab.py)
-  float c_nb2, c_na2, c_nab2, c_a, c_b;
-};
-
-struct F4Consts { float nb2, na2, nab2, a, b; };
-
-__device__ __forceinline__ void f4_split_tile(const Wino43Params &p, int T, int &img, int &ty, int &tx) {
-  if (p.tx_shift >= 0) {
-    img = T >> p.tpi_shift;
-    const int rem = T & (p.tiles_per_img - 1);
-    ty = rem >> p.tx_shift; tx = rem & (p.tiles_x - 1);
-  } else {
-    img = T / p.tiles_per_img;
-    const int rem = T - img * p.tiles_per_img;
-    ty = rem / p.tiles_x; tx = rem - ty * p.tiles_x;
-  }
-}
-
-// the 6-point input transform t = B^T d on one component: 12 operations (the odd parts are formed unscaled, d3 - b^2 d1 and
-// d3 - a^2 d1, and their factors a and b ride in the fused multiply-adds that combine them with the even parts)
-__device__ __forceinline__ void f4_bt(const F4Consts &k, const float d0, const float d1, const float d2, const float d3, const float d4,
-                                      const float d5, float &t0, float &t1, float &t2, float &t3, float &t4, float &t5) {
-  const float pe = fmaf(k.nb2, d2, d4), po = fmaf(k.nb2, d1, d3);          // t1, t2 = pe +- a po
-  const float re = fmaf(k.na2, d2, d4), ro = fmaf(k.na2, d1, d3);          // t3, t4 = re +- b ro
-  t0 = fmaf(k.nab2, d2, d0 + d4);
-  t1 = fmaf(k.a, po, pe); t2 = fmaf(-k.a, po, pe);
-  t3 = fmaf(k.b, ro, re); t4 = fmaf(-k.b, ro, re);
-  t5 = fmaf(k.nab2, d3, d1 + d5);
-}
 __device__ __forceinline__ void f4_bt4(const F4Consts &k, const float4 (&d)[6], float4 (&t)[6]) {
   f4_bt(k, d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x, t[0].x, t[1].x, t[2].x, t[3].x, t[4].x, t[5].x);
   f4_bt(k, d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y, t[0].y, t[1].y, t[2].y, t[3].y, t[4].y, t[5].y);
@@ -516,16 +449,6 @@ __global__ void winograd43_pack_kernel(const float *wt, float *u, int Cin, int C
   }
 }
 
-bool f4_geometry_ok(int B, int H, int W, int Cin, int Cout) {
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return false;
-  if (H % 4 || W % 4 || Cin % F4_KC || Cout % F4_COUT) return false;
-  if ((int64_t)Cin * 4 > 0x7000) return false;                               // channel offset must stay below the invalid-pixel bias
-  if ((int64_t)36 * Cin * Cout * 4 >= F4_X_LIMIT) return false;
-  if ((int64_t)B * (H / 4) * (W / 4) > 0x7fffffff / 4) return false;
-  if ((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) * 4 >= F4_X_LIMIT) return false;   // one buffer descriptor per tensor
-  return true;
-}
-
 }  // namespace
 
 IDIFF_API int idiff_conv2d_winograd43_ok(int B, int H, int W, int Cin, int Cout) {
@@ -600,3 +523,4 @@ IDIFF_API int idiff_conv2d_winograd43_f32(const float *x, const float *u, float 
   hipLaunchKernelGGL(winograd43_kernel, dim3(p.tiles_m * p.tiles_n), dim3(F4_THREADS), F4_LDS_BYTES, (hipStream_t)stream, p);
   return launch_status("conv2d_winograd43");
 }
+

@@ -188,7 +188,7 @@ class BeatGANsUNetModel(HipScoreModel):
             assert x2 is None
             h, x = self._box(h, mod.up), self._box(x, mod.up)
         w0, b0 = self._cw(pk, mod.in_layers[2])
-        h = self._conv(h, w0, b0, stats=True)
+        h = self._conv(h, w0, b0, stats=True, normed=True)
         off = pk["emb_off"][id(mod)]
         h = self._gn_act(h, mod.out_layers[0], "silu", mod=emb_all[:, off:off + 2 * mod.out_channels])
         if isinstance(mod.skip_connection, nn.Identity):
@@ -202,7 +202,7 @@ class BeatGANsUNetModel(HipScoreModel):
                 part = self._pointwise(x, ws[0].view(ws[0].shape[0], -1), bsk)
                 sc = self._pointwise(x2, ws[1].view(ws[1].shape[0], -1), None, residual=part.buf)
         w1, b1 = self._cw(pk, mod.out_layers[3])
-        return self._conv(h, w1, b1, residual=sc.buf, stats=True)
+        return self._conv(h, w1, b1, residual=sc.buf, stats=True, normed=True)
 
     def _attn(self, mod, x, pk):
         """AttentionBlock._forward (BeatGANsblocks.py:433-443) with QKVAttentionLegacy (:466-491), one head."""
@@ -293,7 +293,7 @@ class BeatGANsUNetModel(HipScoreModel):
                 k += 1
         n = self._gn_act(h, self.out[0], "silu")
         w, b = self._cw(pk, self.out[2])
-        h = self._conv(n, w, b)
+        h = self._conv(n, w, b, normed=True)
         out = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
         _lib.nhwc_to_nchw(h.buf, out, B, C, H * W, h.C, out_rowscale)
         return out

@@ -373,8 +373,11 @@ class NCSNpp(HipScoreModel):
                              gn.weight.detach(), gn.bias.detach(), act, y.buf, mod=mod)
         return y
 
-    def _conv(self, x, wt, bias, stride=1, pad=1, pad_hi=None, stats=False, **ep):
-        """``stats=True``: the output feeds a GroupNorm -> ask the epilogue for its per-tile column sums."""
+    def _conv(self, x, wt, bias, stride=1, pad=1, pad_hi=None, stats=False, normed=False, **ep):
+        """``stats=True``: the output feeds a GroupNorm -> ask the epilogue for its per-tile column sums.
+        ``normed=True``: the input is the output of a GroupNorm (+ activation, + FIR resampling), i.e. bounded by
+        sqrt(group size) * |gamma| + |beta| -- only then may the F(4x4, 3x3) contraction run on fp16 pairs, whose transformed input
+        must stay below 65504 (include/idiff_hip.h); any other input takes the fp32 contraction."""
         B = x.buf.shape[0]
         cout, kh, kw, cin = wt.shape
         assert cin == x.C, (cin, x.C)
@@ -387,14 +390,16 @@ class NCSNpp(HipScoreModel):
         if (kh, kw, stride, pad, ph) == (3, 3, 1, 1, 1) and ep["rows_per_group"] == OH * OW and _winograd43_pays(B, x.H, x.W, cin, cout):
             # Winograd F(4x4, 3x3): 2.25 multiplications per output (F(2x2, 3x3) below: 4, the implicit GEMM: 9)
             bank = self._packed.setdefault("wino43", {})
-            if id(wt) not in bank:
-                bank[id(wt)] = (wt, _lib.winograd43_pack(wt, cin, cout))
+            pairs = normed and _lib.conv2d_winograd43h_ok(B, x.H, x.W, cin, cout)
+            key = (id(wt), pairs)
+            if key not in bank:
+                bank[key] = (wt, _lib.winograd43_pack(wt, cin, cout, pairs=pairs))
             if stats:
                 ns = _lib.conv2d_winograd43_colstats_split(B, x.H, x.W, cin, cout)
                 if ns > 0:
                     y.stats = (torch.empty(B * ns * cout * 2, device=x.buf.device, dtype=torch.float64), ns)
                     ep["colstats"] = y.stats[0]
-            _lib.conv2d_winograd43(x.buf, bank[id(wt)][1], y.buf, B, x.H, x.W, cin, cout, epilogue=_lib.make_epilogue(bias=bias, **ep))
+            _lib.conv2d_winograd43(x.buf, bank[key][1], y.buf, B, x.H, x.W, cin, cout, epilogue=_lib.make_epilogue(bias=bias, **ep), pairs=pairs)
             return y
         if (kh, kw, stride, pad, ph) == (3, 3, 1, 1, 1) and _lib.conv2d_winograd_ok(B, x.H, x.W, cin, cout):
             # Winograd F(2x2, 3x3): 2.25x fewer MFMA flops; the transformed filter bank is cached beside the panel
@@ -487,7 +492,7 @@ class NCSNpp(HipScoreModel):
                 h, x = self._box(h, mod.up), self._box(x, mod.up)
         w0, b0 = self._conv_w(pk, (idx, 0), mod.Conv_0)
         off = pk["dense_off"][idx]
-        h = self._conv(h, w0, b0, rowbias=temb_all[:, off:off + mod.out_ch], stats=True)
+        h = self._conv(h, w0, b0, rowbias=temb_all[:, off:off + mod.out_ch], stats=True, normed=True)
         h = self._gn_act(h, mod.GroupNorm_1, self.act_name)
         # shortcut
         if hasattr(mod, "Conv_2") or hasattr(mod, "NIN_0"):
@@ -512,7 +517,7 @@ class NCSNpp(HipScoreModel):
             assert x2 is None
             sc = x
         w1, b1 = self._conv_w(pk, (idx, 1), mod.Conv_1)
-        return self._conv(h, w1, b1, residual=sc.buf, out_scale=rs, stats=True)   # next: a GroupNorm_0 / skip
+        return self._conv(h, w1, b1, residual=sc.buf, out_scale=rs, stats=True, normed=True)   # next: a GroupNorm_0 / skip
 
     def _attn(self, idx, x, pk):
         """AttnBlockpp (layerspp.py:62-91)."""
@@ -640,9 +645,9 @@ class NCSNpp(HipScoreModel):
                     pk["conv"][key] = (wpad.contiguous(), bpad)
                 w, b = pk["conv"][key]
                 if step[3]:
-                    pyr = self._conv(n, w, b)
+                    pyr = self._conv(n, w, b, normed=True)
                 else:
-                    pyr = self._conv(n, w, b, residual=self._fir(pyr, pk, "up").buf)
+                    pyr = self._conv(n, w, b, residual=self._fir(pyr, pk, "up").buf, normed=True)
             elif op == "up":
                 h = self._resblock(step[1], h, temb_all, pk) if step[2] else self._fir(h, pk, "up")
             elif op == "up_plain":   # layers.Upsample (models/layers.py:593-604): nearest x2 (+ 3x3 conv)
@@ -653,7 +658,7 @@ class NCSNpp(HipScoreModel):
             elif op == "head":
                 n = self._gn_act(h, M[step[1]], self.act_name)
                 w, b = self._conv_w(pk, (step[2], "head"), M[step[2]])
-                h = self._conv(n, w, b)
+                h = self._conv(n, w, b, normed=True)
             elif op == "head_pyramid":
                 h = pyr
         assert not hs

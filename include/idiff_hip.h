@@ -45,7 +45,8 @@ const char *idiff_source_stamp(void);
  * IDIFF_SBR_LOOKAHEAD (opt-in: band reduction with the look-ahead -- the bulk of a panel's trailing update on a helper
  * stream beside the next panel's factorisation; 5 % at D = 12288 when the helper gets a hardware queue of its own, 50 %
  * SLOWER when the runtime maps it onto the caller's queue, which happens once a process has made a few streams),
- * IDIFF_NO_WINO43 (3x3 convolutions on the F(2x2,3x3) kernel instead of F(4x4,3x3)).
+ * IDIFF_NO_WINO43 (3x3 convolutions on the F(2x2,3x3) kernel instead of F(4x4,3x3)), IDIFF_NO_WINO43H (F(4x4,3x3) with its
+ * contractions on the fp32 matrix cores instead of fp16 pairs).
  * Returns the previous value, -1 for an unknown name.  No reference counterpart. */
 int idiff_set_option(const char *name, int value);
 
@@ -183,9 +184,9 @@ int idiff_conv2d_winograd_f32(const float *x, const float *u, float *out, int B,
                               const idiff_epilogue *ep, void *stream);
 int idiff_conv2d_winograd_colstats_split(int B, int H, int W, int Cin, int Cout);
 /* F(4x4, 3x3): the same convolution with 36 multiplications per 4x4 output tile (2.25 per output; the F(2x2, 3x3) form above
- * spends 4), interpolation points 0, +-1/2, +-2, infinity, all arithmetic fp32 on v_mfma_f32_32x32x2_f32 (csrc/winograd43.hip).
- * Per layer 1-1.5e-6 against an fp64 convolution where the 2x2 form gives 3-9e-7; measured on the whole nf = 128 NCSN++ before
- * the kernel was written (scripts/f43_emulation.py): rel_err(S) 5e-6 against an fp64 network, singular values within 1e-4.
+ * spends 4), interpolation points 0, +-2/3, +-3/2, infinity, all arithmetic fp32 on v_mfma_f32_32x32x2_f32 (csrc/winograd43.hip).
+ * Per layer 0.8-1.4e-6 against an fp64 convolution where the 2x2 form gives 3-9e-7; measured on the whole nf = 128 NCSN++ before
+ * the kernel was written (scripts/f43_emulation.py): rel_err(S) 3.3e-6 against an fp64 network, singular values within 1.4e-5.
  *   idiff_conv2d_winograd43_ok      1 when served: H % 4 == 0, W % 4 == 0, Cin % 8 == 0, Cout % 64 == 0, every tensor within one
  *                                   buffer descriptor (4 GiB), and neither IDIFF_NO_WINOGRAD nor IDIFF_NO_WINO43 set.
  *   idiff_winograd43_weight_floats  size of the transformed filter bank (36 * Cin * Cout floats).
@@ -202,6 +203,22 @@ int64_t idiff_winograd43_weight_floats(int Cin, int Cout);
 int idiff_winograd43_pack_f32(const float *wt, float *u, int Cin, int Cout, void *stream);
 int idiff_conv2d_winograd43_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
                                 const idiff_epilogue *ep, void *stream);
+/* F(4x4, 3x3) with the 36 contractions on the fp16 matrix cores (v_mfma_f32_32x32x16_f16), each fp32 operand as a PAIR of fp16
+ * values hi = fp16(v), lo = fp16(v - hi) and three of the four partial products kept (hi hi + hi lo + lo hi, fp32 accumulation);
+ * transforms in fp32 as above.  The filter bank is scaled by a power of two at pack time (undone exactly on the outputs) so that its
+ * low parts are normal fp16 numbers; the transformed input is used as is and must stay below 65504 in magnitude (activations below
+ * ~2000): beyond that the outputs are NaN.  Same parity bars as the fp32 form; measured (scripts/f43_emulation.py, whole network)
+ * per layer 8.0e-7 and rel_err(S) 3.33e-6 where the fp32 contraction gives 7.8e-7 and 3.27e-6.
+ *   idiff_conv2d_winograd43h_ok     1 when served: the fp32 form's conditions, Cin % 16 == 0, 32 <= Cin <= 1024, and none of
+ *                                   IDIFF_NO_WINOGRAD / IDIFF_NO_WINO43 / IDIFF_NO_WINO43H set.
+ *   idiff_winograd43h_weight_floats size of the bank in floats (36 * Cin * Cout for the fp16 pairs + 4 of header).
+ *   idiff_winograd43h_pack_f32      wt [Cout, 3, 3, Cin] -> the scaled pairs of U = G g G^T (fp64, rounded once to fp32, then cut).
+ *   idiff_conv2d_winograd43h_f32    as idiff_conv2d_winograd43_f32; colstats geometry: idiff_conv2d_winograd43_colstats_split. */
+int idiff_conv2d_winograd43h_ok(int B, int H, int W, int Cin, int Cout);
+int64_t idiff_winograd43h_weight_floats(int Cin, int Cout);
+int idiff_winograd43h_pack_f32(const float *wt, float *u, int Cin, int Cout, void *stream);
+int idiff_conv2d_winograd43h_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
+                                 const idiff_epilogue *ep, void *stream);
 
 /* Split-precision form of the same convolution: the 16 position-wise contractions run on the bf16 matrix cores with every
  * fp32 operand cut exactly into three bf16 pieces and six of the nine partial products kept (fp32 accumulation; what is

@@ -69,7 +69,11 @@ def toom_cook(points, m, r):
 class WinogradConv:
     """conv3x3 / stride 1 / pad 1 as F(m x m, 3 x 3) with fp32 transforms and an fp32 contraction (torch CPU)."""
 
-    def __init__(self, m, points):
+    def __init__(self, m, points, split=None):
+        # split = "f16x2": both operands of the contraction as a pair of fp16 values (hi = fp16(v), lo = fp16(v - hi), V scaled by
+        # 1/4 and U by a power of two that brings max|U| to 2^12), three products hi*hi + hi*lo + lo*hi accumulated in fp32 --
+        # what winograd43h_kernel's v_mfma_f32_32x32x16_f16 contraction computes
+        self.split = split
         self.m, self.n = m, m + 2
         AT, G, BT = toom_cook(points, m, 3)
         self.G64 = torch.from_numpy(G)
@@ -89,7 +93,16 @@ class WinogradConv:
         d = xp.unfold(2, n, m).unfold(3, n, m)                     # [B, C, th, tw, n, n]
         th, tw = d.shape[2], d.shape[3]
         V = torch.einsum("ik,bcxykl,jl->ijbxyc", self.BT, d, self.BT).reshape(n * n, B * th * tw, C)     # fp32
-        M = torch.bmm(V, U.transpose(1, 2))                        # [n*n, tiles, O] fp32 contraction over C
+        if self.split == "f16x2":
+            ku = 12 - int(torch.ceil(torch.log2(U.abs().max())))
+            Vs, Us = V * 0.25, U * (2.0 ** ku)
+            assert float(Vs.abs().max()) < 65504, "fp16 range"
+            Vh = Vs.half().float(); Vl = (Vs - Vh).half().float()
+            Uh = Us.half().float(); Ul = (Us - Uh).half().float()
+            Ut = lambda t: t.transpose(1, 2)
+            M = (torch.bmm(Vh, Ut(Uh)) + torch.bmm(Vh, Ut(Ul)) + torch.bmm(Vl, Ut(Uh))) * (4.0 * 2.0 ** -ku)
+        else:
+            M = torch.bmm(V, U.transpose(1, 2))                    # [n*n, tiles, O] fp32 contraction over C
         M = M.reshape(n, n, B, th, tw, -1)
         Y = torch.einsum("ik,klbxyo,jl->boxiyj", self.AT, M, self.AT)                                   # [B, O, th, m, tw, m]
         y = Y.reshape(B, -1, H, W)
@@ -163,7 +176,10 @@ def main():
              ("F(4x4,3x3) fp32, points 0,+-1/2,+-2 (the kernel's)", WinogradConv(4, [0, Fraction(1, 2), Fraction(-1, 2), 2, -2])),
              ("F(4x4,3x3) fp32, points 0,+-1,+-2 (Lavin)", WinogradConv(4, [0, 1, -1, 2, -2])),
              ("F(4x4,3x3) fp32, points 0,+-1,1/2,-2", WinogradConv(4, [0, 1, -1, Fraction(1, 2), -2])),
-             ("F(4x4,3x3) fp32, points 0,+-2/3,+-3/2", WinogradConv(4, [0, Fraction(2, 3), Fraction(-2, 3), Fraction(3, 2), Fraction(-3, 2)]))]
+             ("F(4x4,3x3) fp32, points 0,+-2/3,+-3/2", WinogradConv(4, [0, Fraction(2, 3), Fraction(-2, 3), Fraction(3, 2), Fraction(-3, 2)])),
+             ("F(4x4,3x3) 0,+-2/3,+-3/2, contraction on fp16 pairs", WinogradConv(4, [0, Fraction(2, 3), Fraction(-2, 3), Fraction(3, 2), Fraction(-3, 2)], split="f16x2"))]
+    if len(sys.argv) > 3:
+        forms = [forms[int(i)] for i in sys.argv[3].split(",")]
     sv64 = odim.spectrum_f64(S64.float()) if rows >= 8 else None
     c64 = S64 - S64.mean(0, keepdim=True)
     sv64 = torch.linalg.svdvals(c64)

@@ -54,8 +54,8 @@ def d_conv(x, wt, out, B, H, W, Cin, Cout, KH, KW, stride, pad, epilogue=None, p
 def d_wino(x, u, out, B, H, W, Cin, Cout, epilogue=None, split=False):
     return (f"B{B} {H}x{W} {Cin}->{Cout} (F(2x2,3x3); TF = direct-equivalent)", 2.0 * out.numel() * Cin * 9,
             4.0 * (B * H * W * Cin + out.numel()))
-def d_wino43(x, u, out, B, H, W, Cin, Cout, epilogue=None):
-    return (f"B{B} {H}x{W} {Cin}->{Cout} (F(4x4,3x3); TF = direct-equivalent)", 2.0 * out.numel() * Cin * 9,
+def d_wino43(x, u, out, B, H, W, Cin, Cout, epilogue=None, pairs=False):
+    return (f"B{B} {H}x{W} {Cin}->{Cout} (F(4x4,3x3){' on fp16 pairs' if pairs else ''}; TF = direct-equivalent)", 2.0 * out.numel() * Cin * 9,
             4.0 * (B * H * W * Cin + out.numel()))
 def d_gnapply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None):
     return (f"B{B} HW{HW} C{C}+{C2} act={act}", 0.0, 8.0 * B * HW * (C + C2))

@@ -1,11 +1,13 @@
-"""parse_wino_traffic.py <log of wino_shapes.py> <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [43]
-(43: the F(4x4,3x3) kernel, winograd43_kernel / winograd43.hip, 36 transformed positions; default the F(2x2,3x3) kernel)
+"""parse_wino_traffic.py <log of wino_shapes.py> <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [43 | 43h]
+(43: the F(4x4,3x3) kernel, winograd43_kernel / winograd43.hip, 36 transformed positions; 43h: its fp16-pair form, winograd43h_kernel /
+winograd43h.hip; default the F(2x2,3x3) kernel)
 HBM bytes per launch = FETCH_SIZE * 1024 * 2 (gfx950 counts half of a wide coalesced read, MI355X_MICROARCH.md section
 HBM) + WRITE_SIZE * 1024; the second isolated launch of each shape is taken."""
 import csv, glob, hashlib, json, os, sys
 log, fdir, wdir, out = sys.argv[1:5]
-F43 = len(sys.argv) > 5 and sys.argv[5] == "43"
-KERNEL, NPOS, SRC = ("winograd43_kernel", 36, "winograd43.hip") if F43 else ("winograd_kernel", 16, "winograd.hip")
+MODE = sys.argv[5] if len(sys.argv) > 5 else ""
+KERNEL, NPOS, SRC = {"43": ("winograd43_kernel", 36, ["winograd43.hip", "winograd43_shared.h"]),
+                     "43h": ("winograd43h_kernel", 36, ["winograd43h.hip", "winograd43_shared.h"])}.get(MODE, ("winograd_kernel", 16, ["winograd.hip"]))
 keys = [(l.split()[1], int(l.split()[2])) for l in open(log) if l.startswith("KEY")]
 
 def counters(d, name):
@@ -27,8 +29,8 @@ for i, (k, cnt) in enumerate(keys):
     alg = 4 * (B * H * W * Cin + NPOS * Cin * Cout + B * H * W * Cout)
     shapes[k] = {"fetch_bytes": fb, "write_bytes": wb, "total_bytes": fb + wb, "algorithmic_bytes": alg,
                  "ratio": round((fb + wb) / alg, 3), "calls_per_forward": cnt}
-src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "id-diff_amd", "csrc", SRC)
-sha = hashlib.sha256(open(src, "rb").read()).hexdigest()      # bench.py reports traffic only for this very source
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "id-diff_amd", "csrc")
+sha = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in SRC)).hexdigest()      # bench.py reports traffic only for these very sources
 json.dump({"kernel": KERNEL, "kernel_source_sha256": sha, "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on scripts/wino_shapes.py: "
                    "every distinct Winograd-conv call of the nf=128 NCSN++ forward at the bench's launch-set size, second "
                    "isolated launch of each; bytes = FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024; algorithmic = "

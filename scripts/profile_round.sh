@@ -23,23 +23,29 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 python3 $R/scripts/parse_wino_traffic.py $O/shapes43_fetch.log $O/fetch43 $O/write43 $O/${TAG}_wino43_traffic.json 43 > $O/traffic43_summary.txt 2>&1 || echo "traffic43 parse failed"
 cat $O/traffic43_summary.txt
 [ -s $O/${TAG}_wino43_traffic.json ] && cp $O/${TAG}_wino43_traffic.json $R/profiles/${TAG}_wino43_traffic.json
+echo "[1c] traffic passes, F(4x4,3x3) kernel on fp16 pairs"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch43h -- python3 $R/scripts/wino_shapes.py 2240 43h > $O/shapes43h_fetch.log 2>&1 || echo "fetch43h pass failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write43h -- python3 $R/scripts/wino_shapes.py 2240 43h > $O/shapes43h_write.log 2>&1 || echo "write43h pass failed"
+python3 $R/scripts/parse_wino_traffic.py $O/shapes43h_fetch.log $O/fetch43h $O/write43h $O/${TAG}_wino43h_traffic.json 43h > $O/traffic43h_summary.txt 2>&1 || echo "traffic43h parse failed"
+cat $O/traffic43h_summary.txt
+[ -s $O/${TAG}_wino43h_traffic.json ] && cp $O/${TAG}_wino43h_traffic.json $R/profiles/${TAG}_wino43h_traffic.json
 echo "[2] PMC of the dominant kernel (16x16 256->256)"
-for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" "TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum TCP_TCC_READ_REQ_sum"; do
   n=$(echo $set | cut -d' ' -f1)
-  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$n -- python3 $R/scripts/wino_one.py 16 256 256 2240 f43 > $O/pmc_$n.log 2>&1 || echo "pmc pass $n failed"
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$n -- python3 $R/scripts/wino_one.py 16 256 256 2240 f43h > $O/pmc_$n.log 2>&1 || echo "pmc pass $n failed"
 done
 python3 - <<PY > $O/${TAG}_pmc_winograd.txt
 import csv, glob, collections
-print("winograd43_kernel (F(4x4,3x3)), conv [2240,16,16,256]->256, per launch (rocprofv3 --pmc, 3 passes):")
+print("winograd43h_kernel (F(4x4,3x3) on fp16 pairs), conv [2240,16,16,256]->256, per launch (rocprofv3 --pmc, one pass per counter set):")
 for f in sorted(glob.glob("$O/pmc_*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "winograd43_kernel" in r["Kernel_Name"]:
+        if "winograd43h_kernel" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         print(f"  {k:32s} {sum(v)/max(1,len(v)):.4g}")
 for f in sorted(glob.glob("$O/pmc_SQ_VALU*/**/*kernel_trace.csv", recursive=True)):
-    d = [(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(f)) if 'winograd43_kernel' in r['Kernel_Name']]
+    d = [(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(f)) if 'winograd43h_kernel' in r['Kernel_Name']]
     print("  kernel duration us (that pass):", [round(x) for x in d])
 PY
 cat $O/${TAG}_pmc_winograd.txt

@@ -1,0 +1,56 @@
+"""Builds of winograd43h_kernel compared on ONE box: python scripts/wino43h_ab.py "<flags 1>" "<flags 2>" ... [--rounds N]
+Each entry rebuilds the library with the flags ("" = as committed; the IDIFF_W43H_DIAG_* flags make timing-only kernels whose
+results are wrong by construction) and times the fp16-pair F(4x4) convolutions of one nf = 128 NCSN++ forward at B = 2240."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "id-diff_amd", "csrc", "build.sh")
+
+def build(extra):
+    src = open(BUILD).read()
+    patched = src.replace("extra=\"\"", "extra=\"%s\"" % extra) if extra else src
+    tmp = BUILD + ".ab.sh"
+    open(tmp, "w").write(patched)
+    try:
+        subprocess.run(["bash", tmp], check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, IDIFF_SCRATCH_LIMIT="100000"))
+    finally:
+        os.remove(tmp)
+
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, ROOT)
+    import torch
+    import id_diff_amd
+    from id_diff_amd import _lib
+    dev = torch.device("cuda:0")
+    B = 2240
+    shapes = [(32, 128, 128, 13), (16, 256, 256, 14), (32, 256, 128, 4), (32, 256, 256, 2), (16, 512, 256, 4), (8, 256, 256, 17),
+              (32, 384, 128, 1), (8, 512, 256, 5), (16, 384, 256, 1), (16, 128, 128, 2), (16, 128, 256, 1)]
+    tot, detail = 0.0, []
+    for H, Cin, Cout, calls in shapes:
+        x = torch.randn(B, H * H, Cin, device=dev)
+        w = torch.randn(Cout, 3, 3, Cin, device=dev) / (9 * Cin) ** 0.5
+        o = torch.empty(B, H * H, Cout, device=dev)
+        ep = _lib.make_epilogue(bias=torch.randn(Cout, device=dev), act="silu", rows_per_group=H * H)
+        u = _lib.winograd43_pack(w, Cin, Cout, pairs=True)
+        fn = lambda: _lib.conv2d_winograd43(x, u, o, B, H, H, Cin, Cout, epilogue=ep, pairs=True)
+        for _ in range(2): fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): fn()
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 5
+        tot += t * calls
+        if (H, Cin, Cout) in ((16, 256, 256), (32, 128, 128), (8, 256, 256)): detail.append(f"{H}x{H} {Cin}->{Cout} {t*1e3:.0f} us")
+    print(f"{sys.argv[2]!r:60s} pairs {tot:7.1f} ms per forward   [{', '.join(detail)}]", flush=True)
+    sys.exit(0)
+
+args = sys.argv[1:]
+rounds = 1
+if "--rounds" in args:
+    i = args.index("--rounds"); rounds = int(args[i + 1]); del args[i:i + 2]
+try:
+    for r in range(rounds):
+        for flags in args:
+            build(flags)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "child", flags or "(as committed)"], check=False)
+finally:
+    build("")

@@ -14,14 +14,17 @@ torch.manual_seed(0)
 model = mutils.create_model(cfg).to("cuda").eval()
 sde, eps = sde_lib.configure_sde(cfg)
 score_fn = mutils.get_score_fn(sde, model)
-# second argument: which kernel's calls to tabulate -- "43" = winograd43_kernel (F(4x4,3x3)), default winograd_kernel (F(2x2,3x3))
-F43 = len(sys.argv) > 2 and sys.argv[2] == "43"
+# second argument: which kernel's calls to tabulate -- "43" = winograd43_kernel (F(4x4,3x3), fp32 contraction), "43h" = winograd43h_kernel
+# (the same on fp16 pairs), default winograd_kernel (F(2x2,3x3))
+MODE = sys.argv[2] if len(sys.argv) > 2 else ""
+F43, PAIRS = MODE in ("43", "43h"), MODE == "43h"
 OP, PACK = ("conv2d_winograd43", _lib.winograd43_pack) if F43 else ("conv2d_winograd", _lib.winograd_pack)
 calls = []
 orig = getattr(_lib, OP)
 
 def rec(x, u, out, B, H, W, Cin, Cout, epilogue=None, **kw):
-    calls.append((B, H, W, Cin, Cout))
+    if not F43 or bool(kw.get("pairs")) == PAIRS:
+        calls.append((B, H, W, Cin, Cout))
     return orig(x, u, out, B, H, W, Cin, Cout, epilogue, **kw)
 
 setattr(_lib, OP, rec)
@@ -33,10 +36,11 @@ torch.cuda.synchronize()
 for (B, H, W, Cin, Cout) in sorted(set(calls)):
     x = torch.randn(B, H * W, Cin, device="cuda")
     w = torch.randn(Cout, 3, 3, Cin, device="cuda") * 0.02
-    u = PACK(w, Cin, Cout)
+    kw = {"pairs": True} if PAIRS else {}
+    u = PACK(w, Cin, Cout, **kw)
     out = torch.empty(B, H * W, Cout, device="cuda")
     torch.cuda.synchronize()
     for _ in range(2):
-        orig(x, u, out, B, H, W, Cin, Cout)
+        orig(x, u, out, B, H, W, Cin, Cout, **kw)
     torch.cuda.synchronize()
     print("KEY", f"{B}x{H}x{W}x{Cin}->{Cout}", calls.count((B, H, W, Cin, Cout)), flush=True)

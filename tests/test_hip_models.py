@@ -387,11 +387,12 @@ def wino43_everywhere(monkeypatch):
     executor keeps launches of fewer than 512 workgroups on the 2x2 form: a speed rule, not a correctness one)."""
     from id_diff_amd.models import ncsnpp as hip_ncsnpp
     monkeypatch.setattr(hip_ncsnpp, "WINO43_MIN_WORKGROUPS", 1)
-    calls = {"n": 0}
+    calls = {"n": 0, "pairs": 0}
     orig = _lib.conv2d_winograd43
 
     def counted(*a, **k):
         calls["n"] += 1
+        calls["pairs"] += bool(k.get("pairs"))
         return orig(*a, **k)
     monkeypatch.setattr(_lib, "conv2d_winograd43", counted)
     return calls
@@ -408,9 +409,17 @@ def test_wide_ncsnpp_golden_through_winograd43(golden, wino43_everywhere):
     x, t = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV)
     raw = model(x, t * 999)
     assert wino43_everywhere["n"] >= 8, wino43_everywhere            # the 3x3 convs of the levels of 8x8 pixels and larger
+    assert wino43_everywhere["pairs"] >= 8, wino43_everywhere        # ... all fed by a GroupNorm: contraction on fp16 pairs
     assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
     y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x, t)
     assert rel_err(y.cpu(), z["score"]) < NET_RTOL
+    # the same network with the contraction on the fp32 matrix cores (IDIFF_NO_WINO43H): same bar
+    before = dict(wino43_everywhere)
+    model._invalidate()
+    with _lib.thread_option("IDIFF_NO_WINO43H", 1):
+        raw32 = model(x, t * 999)
+    assert wino43_everywhere["n"] - before["n"] >= 8 and wino43_everywhere["pairs"] == before["pairs"], wino43_everywhere
+    assert rel_err(raw32.cpu(), z["model_out"]) < NET_RTOL
 
 
 def test_wide_beatgans_golden_through_winograd43(golden, wino43_everywhere):
@@ -421,7 +430,7 @@ def test_wide_beatgans_golden_through_winograd43(golden, wino43_everywhere):
     model._invalidate()
     x, t = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV)
     raw = model(x, t * 999)
-    assert wino43_everywhere["n"] >= 4, wino43_everywhere
+    assert wino43_everywhere["n"] >= 4 and wino43_everywhere["pairs"] >= 4, wino43_everywhere
     assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
 
 

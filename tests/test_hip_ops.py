@@ -732,6 +732,83 @@ def test_conv2d_winograd43_vs_cpu(B, H, W, Cin, Cout):
     assert float((out.permute(0, 3, 1, 2).cpu().double() - ref2).abs().max()) < 1e-4 * float(ref2.abs().max())
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 32, 32, 128, 128), (3, 8, 8, 256, 64), (5, 8, 12, 80, 64), (2, 16, 16, 512, 256), (130, 4, 4, 48, 64),
+                                            (1, 64, 64, 32, 64), (2, 8, 8, 32, 64), (33, 8, 8, 256, 256), (7, 16, 16, 384, 256)])
+def test_conv2d_winograd43_pairs_vs_cpu(B, H, W, Cin, Cout):
+    """The same convolution with its 36 contractions on the fp16 matrix cores, every fp32 operand as a pair of fp16 values
+    (winograd43h_kernel): same bars as the fp32 contraction (3e-6 against the fp64 CPU convolution with every epilogue term, against
+    the direct kernel likewise; measured 0.6-1.5e-6, at or below the fp32 contraction's).  Inputs span five decades with exact
+    zeros among them: elements far below the typical magnitude have a SUBNORMAL low part, which the matrix core must keep."""
+    g = torch.Generator().manual_seed(B * H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x = x * (torch.rand(B, Cin, H, W, generator=g) < 0.9) * torch.exp(torch.randn(B, Cin, H, W, generator=g).clamp(-6, 2))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    temb = torch.randn(B, Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    rsc = torch.rand(B, generator=g) + 0.5
+    assert _lib.conv2d_winograd43h_ok(B, H, W, Cin, Cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wt = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    u = _lib.winograd43_pack(wt, Cin, Cout, pairs=True)
+    assert u.numel() == 36 * Cin * Cout + 4
+    descale = float(u[-4])
+    assert descale > 0 and np.log2(descale) == round(np.log2(descale))       # a power of two: undone exactly
+    out = torch.full((B, H, W, Cout), float("nan"), device=DEV)          # every output must be written
+    _lib.conv2d_winograd43(xd, u, out, B, H, W, Cin, Cout, epilogue=_lib.make_epilogue(bias=b.to(DEV)), pairs=True)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 3e-6
+    assert float((out.permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    direct = torch.empty_like(out)
+    _lib.conv2d_nhwc(xd, wt, direct, B, H, W, Cin, Cout, 3, 3, 1, 1, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
+    assert rel_err(out.cpu(), direct.double().cpu()) < 3e-6
+    resd = res.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ns = _lib.conv2d_winograd43_colstats_split(B, H, W, Cin, Cout)
+    cs = torch.full((B * ns * Cout * 2,), float("nan"), device=DEV, dtype=torch.float64) if ns > 0 else None
+    _lib.conv2d_winograd43(xd, u, out, B, H, W, Cin, Cout, pairs=True,
+                           epilogue=_lib.make_epilogue(bias=b.to(DEV), rowbias=temb.to(DEV), rows_per_group=H * W, act="silu",
+                                                       residual=resd, out_scale=0.7071, rowscale=rsc.to(DEV), colstats=cs))
+    ref2 = (F.silu(ref + temb.double()[:, :, None, None]) + res.double()) * 0.7071 * rsc.double()[:, None, None, None]
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref2) < 3e-6
+    assert float((out.permute(0, 3, 1, 2).cpu().double() - ref2).abs().max()) < 1e-4 * float(ref2.abs().max())
+    if ns > 0:                                                            # the column sums are those of the stored outputs
+        tot = cs.view(B, ns, Cout, 2).sum(1)
+        o64 = out.double().reshape(B, H * W, Cout)
+        torch.testing.assert_close(tot[..., 0], o64.sum(1), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(tot[..., 1], (o64 * o64).sum(1), rtol=1e-6, atol=1e-6)
+
+
+def test_conv2d_winograd43_pairs_limits():
+    """What the fp16-pair form refuses (-> the fp32 contraction serves it), its switch, and its documented failure: a transformed
+    input beyond the fp16 range gives NaN outputs, never finite wrong ones."""
+    assert not _lib.conv2d_winograd43h_ok(2, 8, 8, 24, 64)       # Cin % 16
+    assert not _lib.conv2d_winograd43h_ok(2, 8, 8, 16, 64)       # fewer than two K steps
+    assert _lib.conv2d_winograd43_ok(2, 8, 8, 24, 64)            # ... which the fp32 form takes
+    with _lib.thread_option("IDIFF_NO_WINO43H", 1):
+        assert not _lib.conv2d_winograd43h_ok(2, 8, 8, 32, 64)
+        assert _lib.conv2d_winograd43_ok(2, 8, 8, 32, 64)
+    assert _lib.conv2d_winograd43h_ok(2, 8, 8, 32, 64)
+    g = torch.Generator().manual_seed(0)
+    wt = (torch.randn(64, 3, 3, 32, generator=g) / 17).to(DEV)
+    u = _lib.winograd43_pack(wt, 32, 64, pairs=True)
+    with pytest.raises(RuntimeError, match="pairs=True"):         # an fp32 bank handed to the pair kernel
+        _lib.conv2d_winograd43(torch.zeros(2, 8, 8, 32, device=DEV), _lib.winograd43_pack(wt, 32, 64), torch.zeros(2, 8, 8, 64, device=DEV),
+                               2, 8, 8, 32, 64, pairs=True)
+    x = torch.randn(2, 8, 8, 32, generator=g).to(DEV)
+    out = torch.empty(2, 8, 8, 64, device=DEV)
+    _lib.conv2d_winograd43(x * 300.0, u, out, 2, 8, 8, 32, 64, pairs=True)      # |V| up to ~1.2e4: well inside
+    ref = torch.empty_like(out)
+    _lib.conv2d_winograd43(x * 300.0, _lib.winograd43_pack(wt, 32, 64), ref, 2, 8, 8, 32, 64)
+    assert rel_err(out.cpu(), ref.double().cpu()) < 3e-6
+    _lib.conv2d_winograd43(x * 1e5, u, out, 2, 8, 8, 32, 64, pairs=True)        # beyond: loud
+    assert bool(torch.isnan(out).any()) and not bool(torch.isfinite(out).all())
+    # an all-zero filter packs (no scale to find) and convolves to the bias
+    uz = _lib.winograd43_pack(torch.zeros_like(wt), 32, 64, pairs=True)
+    bias = torch.randn(64, generator=g).to(DEV)
+    _lib.conv2d_winograd43(x, uz, out, 2, 8, 8, 32, 64, epilogue=_lib.make_epilogue(bias=bias), pairs=True)
+    torch.testing.assert_close(out, bias.expand(2, 8, 8, 64), rtol=0, atol=0)
+
+
 def test_conv2d_winograd43_rejects_what_it_cannot_take():
     assert not _lib.conv2d_winograd43_ok(2, 6, 8, 32, 64)       # height not a multiple of 4
     assert not _lib.conv2d_winograd43_ok(2, 8, 8, 4, 64)        # Cin % 8

@@ -372,8 +372,9 @@ def test_bench_main_two_ranks_real_workload_one_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak" and line["config"]["process_group"] == "gloo"
     assert line["value"] == pytest.approx(2 * 4480 / (line["ms_per_step"] * 1e-3), rel=1e-6)
     assert len(line["id_estimates_all_ranks"]) == 2 and line["id_estimates_all_ranks"][0] == line["id_estimates"][0]
-    assert line["roofline"] is not None and line["roofline"]["kernel"].startswith("winograd43_kernel")
-    assert 0.3 < line["roofline"]["frac"] < 1.0 and line["svd_wall_clock_ms_per_point"] > 0
+    assert line["roofline"] is not None and line["roofline"]["kernel"].startswith("winograd43h_kernel")
+    # fp32-equivalent multiply-adds against the fp16 peak / 3; the kernel's own limiter is L2 read bandwidth
+    assert 0.1 < line["roofline"]["frac"] < 1.0 and 0.4 < line["roofline"]["l2_read"]["frac"] < 1.2 and line["svd_wall_clock_ms_per_point"] > 0
 
 
 def _rows_rccl_worker(port, q):
