@@ -40,6 +40,7 @@ constexpr size_t H4_LDS_BYTES = 2 * H4_STAGE_BYTES > (int)sizeof(float) * F4_Z_F
 #define IDIFF_W43H_BRING 3
 #endif
 constexpr int H4_BRING = IDIFF_W43H_BRING;     // positions of U requested ahead (register sets of 8)
+
 #ifndef IDIFF_W43H_LATE_AT
 #define IDIFF_W43H_LATE_AT 5
 #endif
@@ -78,6 +79,8 @@ __device__ __forceinline__ void h4_bt_pairs(const H4Consts &k, const f2 P0, cons
 __global__ void __launch_bounds__(F4_THREADS, 2)
 winograd43h_kernel(const Wino43Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BRING = H4_BRING;                // positions of U requested ahead; must divide 9 (the ring's phase then repeats every step)
+  static_assert(9 % H4_BRING == 0, "the ring of U registers must divide the nine positions of a step");
   char *const ldsb = reinterpret_cast<char *>(lds);
   const int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
@@ -101,7 +104,10 @@ winograd43h_kernel(const Wino43Params p) {
   // one stage dword and exchange them by DPP (see stage()).
   const int lch = tid & 15, ltile = tid >> 4;
   const uint32_t cin4 = (uint32_t)p.Cin * 4u;
-  uint32_t v_row[6];                                  // pixel (4 ty - 1 + i, 4 tx), my channel: always inside the row
+  // Vector offsets of my channel at pixel column 4 tx: v_mid for patch rows 1 .. 5 (image row 4 ty, the scalar offset adds (i - 1) rows:
+  // rows 1 .. 4 of a patch always lie inside the image), v_top for row 0 and v_bot (= v_mid) for row 5, F4_INVALID where the row is
+  // outside the image or the tile beyond the last one -- three registers where six offsets would be held.
+  uint32_t v_top, v_mid, v_bot;
   bool c0ok, c5ok;                                    // columns 4 tx - 1 and 4 tx + 4 inside the image
   {
     const int T = tile0 + ltile;
@@ -109,12 +115,12 @@ winograd43h_kernel(const Wino43Params p) {
     int img, ty, tx;
     f4_split_tile(p, tv ? T : 0, img, ty, tx);
     c0ok = tx > 0; c5ok = tx + 1 < p.tiles_x;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int y = 4 * ty - 1 + i;
-      v_row[i] = (tv && y >= 0 && y < p.H) ? (uint32_t)(((img * p.H + y) * p.W + 4 * tx) * p.Cin + lch) * 4u : F4_INVALID;
-    }
+    const uint32_t at_row1 = (uint32_t)(((img * p.H + 4 * ty) * p.W + 4 * tx) * p.Cin + lch) * 4u;
+    v_mid = tv ? at_row1 : F4_INVALID;
+    v_top = (tv && ty > 0) ? at_row1 - (uint32_t)p.W * cin4 : F4_INVALID;
+    v_bot = (tv && ty + 1 < p.tiles_y) ? at_row1 : F4_INVALID;
   }
+  const int row4 = p.W * (int)cin4;                   // bytes per image row
   const int nsteps = p.Cin / H4_KC;
   // The patch in PAIRS of rows: dp[r][j] = (d[2r][j], d[2r+1][j]) -- one packed instruction (v_pk_fma_f32 / v_pk_add_f32) then
   // transforms two rows along x at once, and along y the three pairs of a column ARE the operand pairs of h4_bt_pairs.
@@ -132,9 +138,11 @@ winograd43h_kernel(const Wino43Params p) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       float v;
-      if (j == 0) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX0, (int)(c0ok ? v_row[i] : invalid), choff, 0));
-      else if (j == 5) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX5, (int)(c5ok ? v_row[i] : invalid), choff, 0));
-      else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)v_row[i], choff + (j - 1) * (int)cin4, 0));
+      const uint32_t vo = i == 0 ? v_top : (i == 5 ? v_bot : v_mid);
+      const int ro = i == 0 ? 0 : (i - 1) * row4;
+      if (j == 0) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX0, (int)(c0ok ? vo : invalid), choff + ro, 0));
+      else if (j == 5) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX5, (int)(c5ok ? vo : invalid), choff + ro, 0));
+      else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)vo, choff + ro + (j - 1) * (int)cin4, 0));
       dp[i >> 1][j][i & 1] = v;
     }
   };
@@ -207,12 +215,12 @@ winograd43h_kernel(const Wino43Params p) {
   // V fragment of tile row fr: chunk fh of plane 0, chunk 2 + fh of plane 1 (bit 5 flipped), swizzled as the writer does
   const int a_off = pos0 * H4_POS_BYTES + fr * H4_TILE_BYTES + ((fh ^ ((fr >> 2) & 3)) << 4);
   const uint32_t u_lane = (uint32_t)((wh * 32 + fr) * (H4_KC * 2) + fh * 16);
-  halfx8 bh[H4_BRING], bl[H4_BRING];
+  halfx8 bh[BRING], bl[BRING];
   auto load_b = [&](int pp, int step) __attribute__((always_inline)) {
     const int slot = pos0 + (pp / 3) * 6 + (pp % 3);
     const int soff = ((step * p.tiles_n + tile_n) * F4_NPOS + slot) * H4_SLOT_BYTES;
-    bh[pp % H4_BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane, soff, 0));
-    bl[pp % H4_BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane + H4_PLANE_BYTES, soff, 0));
+    bh[pp % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane, soff, 0));
+    bl[pp % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane + H4_PLANE_BYTES, soff, 0));
   };
   // Waves w and w + 4 share a SIMD: the first four transform and stage the next step's input at the start of a step (`early`),
   // the others in front of position H4_LATE_AT, so that one wave's vector work runs beside the other's matrix instructions.
@@ -233,7 +241,7 @@ winograd43h_kernel(const Wino43Params p) {
       __builtin_amdgcn_sched_barrier(0);
       if (!LAST && pp == H4_LATE_AT && !early) { stage(buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
       if (pp + 1 < 9) { ah[(pp + 1) & 1] = a_hi(pp + 1); al[(pp + 1) & 1] = a_lo(pp + 1); }
-      const halfx8 xh = ah[pp & 1], xl = al[pp & 1], yh = bh[pp % H4_BRING], yl = bl[pp % H4_BRING];
+      const halfx8 xh = ah[pp & 1], xl = al[pp & 1], yh = bh[pp % BRING], yl = bl[pp % BRING];
 #ifdef IDIFF_W43H_DIAG_NO_MFMA    // timing-only build: the operands are consumed by one vector instruction each instead
       acc[pp][0] += (float)xh[0] + (float)xl[0] + (float)yh[0] + (float)yl[0];
 #else
@@ -242,16 +250,16 @@ winograd43h_kernel(const Wino43Params p) {
       acc[pp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, acc[pp], 0, 0, 0);
 #endif
 #ifdef IDIFF_W43H_DIAG_NO_BLOAD   // timing-only build: U is loaded for the first step only
-      if (s == 0) { if (pp + H4_BRING < 9) load_b(pp + H4_BRING, s); }
+      if (s == 0) { if (pp + BRING < 9) load_b(pp + BRING, s); }
 #else
-      if (pp + H4_BRING < 9) load_b(pp + H4_BRING, s); else if (!LAST) load_b(pp + H4_BRING - 9, s + 1);
+      if (pp + BRING < 9) load_b(pp + BRING, s); else if (!LAST) load_b(pp + BRING - 9, s + 1);
 #endif
     }
     __syncthreads();
   };
 
 #pragma unroll
-  for (int pp = 0; pp < H4_BRING; ++pp) load_b(pp, 0);
+  for (int pp = 0; pp < BRING; ++pp) load_b(pp, 0);
 #pragma unroll
   for (int j = 0; j < 6; ++j) fetch_col(j, 0);
   stage(0);
