@@ -168,12 +168,17 @@ class _T:
 # ------------------------------------------------------------------------------------------------------------
 # launches of fewer workgroups than this stay on the F(2x2, 3x3) kernel (tests set it to 1 to send small batches through F(4x4, 3x3))
 WINO43_MIN_WORKGROUPS = 512
+WINO43_PAIRS_MIN_WORKGROUPS = 256
 
 
-def _winograd43_pays(B, H, W, cin, cout):
+def _winograd43_pays(B, H, W, cin, cout, normed=False):
     """F(4x4, 3x3) where it is served AND faster than F(2x2, 3x3): a workgroup takes 32 tiles of 4x4 pixels x 64 channels and a
-    CU holds one, so maps of 4x4 pixels (one tile per sample) or launches of fewer than two workgroups per CU stay on the 2x2
-    form (measured 0.87x there, 1.2-1.33x elsewhere: profiles/r04_wino43_time.txt)."""
+    CU holds one.  With the contraction on the fp32 matrix cores, maps of 4x4 pixels (one tile per sample) or launches of fewer
+    than two workgroups per CU stay on the 2x2 form (measured 0.87x there, 1.2-1.33x elsewhere: profiles/r04_wino43_time.txt);
+    on fp16 pairs (``normed`` inputs, see _conv) it wins from one workgroup per CU on, 4x4 maps included (127 us against 207,
+    209 against 370 at B = 2240, 256 / 512 -> 256 channels)."""
+    if normed and _lib.conv2d_winograd43h_ok(B, H, W, cin, cout):
+        return ((B * (H // 4) * (W // 4) + 31) // 32) * (cout // 64) >= WINO43_PAIRS_MIN_WORKGROUPS
     if H < 8 or W < 8 or not _lib.conv2d_winograd43_ok(B, H, W, cin, cout):
         return False
     return ((B * (H // 4) * (W // 4) + 31) // 32) * (cout // 64) >= WINO43_MIN_WORKGROUPS
@@ -387,7 +392,7 @@ class NCSNpp(HipScoreModel):
         y = self._new(B, OH, OW, cout, x.buf)
         if "rows_per_group" not in ep:
             ep["rows_per_group"] = OH * OW
-        if (kh, kw, stride, pad, ph) == (3, 3, 1, 1, 1) and ep["rows_per_group"] == OH * OW and _winograd43_pays(B, x.H, x.W, cin, cout):
+        if (kh, kw, stride, pad, ph) == (3, 3, 1, 1, 1) and ep["rows_per_group"] == OH * OW and _winograd43_pays(B, x.H, x.W, cin, cout, normed):
             # Winograd F(4x4, 3x3): 2.25 multiplications per output (F(2x2, 3x3) below: 4, the implicit GEMM: 9)
             bank = self._packed.setdefault("wino43", {})
             pairs = normed and _lib.conv2d_winograd43h_ok(B, x.H, x.W, cin, cout)

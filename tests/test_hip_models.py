@@ -387,6 +387,7 @@ def wino43_everywhere(monkeypatch):
     executor keeps launches of fewer than 512 workgroups on the 2x2 form: a speed rule, not a correctness one)."""
     from id_diff_amd.models import ncsnpp as hip_ncsnpp
     monkeypatch.setattr(hip_ncsnpp, "WINO43_MIN_WORKGROUPS", 1)
+    monkeypatch.setattr(hip_ncsnpp, "WINO43_PAIRS_MIN_WORKGROUPS", 1)
     calls = {"n": 0, "pairs": 0}
     orig = _lib.conv2d_winograd43
 
