@@ -45,6 +45,9 @@ struct Wino43Params {
   // with a scalar operand; as compile-time literals they became v_fmamk_f32 (a 32-bit literal per instruction), measured 3.7 %
   // slower over a forward than the dyadic point set whose constants are inline operands (scripts/wino43_ab.py)
   float c_nb2, c_na2, c_nab2, c_a, c_b;
+#ifdef IDIFF_W43H_STAMP
+  uint64_t *stamps;               // diagnostic build: 8 ticks per workgroup (the launcher takes the address from IDIFF_W43H_STAMP_PTR)
+#endif
 };
 
 struct F4Consts { float nb2, na2, nab2, a, b; };
@@ -77,7 +80,7 @@ __device__ __forceinline__ void f4_bt(const F4Consts &k, const float d0, const f
 // DESCALE: the accumulators carry U's power-of-two scaling, undone on the finished sums before the epilogue.
 template <bool DESCALE>
 __device__ __forceinline__ void f4_tail(const Wino43Params &p, float *lds, floatx16 (&acc)[9], const int tile0, const int tile_m,
-                                        const int n0, const int wh, const int wa, const int wb, const float descale) {
+                                        const int n0, const int wh, const int wa, const int wb, const float descale, uint64_t *stamp_out = nullptr) {
   const idiff_epilogue &ep = p.ep;
   const bool has_ep = p.has_ep != 0;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -112,6 +115,12 @@ __device__ __forceinline__ void f4_tail(const Wino43Params &p, float *lds, float
     }
   };
   const bool want_stats = has_ep && ep.colstats != nullptr;
+#ifdef IDIFF_W43H_STAMP
+  uint64_t st_tail[5] = {0, 0, 0, 0, 0};
+#define IDIFF_TAIL_STAMP(k) st_tail[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define IDIFF_TAIL_STAMP(k)
+#endif
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   // accumulator register `reg` of lane l is tile row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), cout wh * 32 + (l & 31)
   float *zbase = lds + (size_t)(4 * (lane >> 5)) * 2 * F4_COUT + wh * 32 + (lane & 31);
@@ -153,6 +162,7 @@ __device__ __forceinline__ void f4_tail(const Wino43Params &p, float *lds, float
         }
     }
     __syncthreads();
+    IDIFF_TAIL_STAMP(2 * pass);                       // z of this pass exchanged
     __builtin_amdgcn_sched_barrier(0);
     prep();
 #pragma unroll
@@ -205,6 +215,7 @@ __device__ __forceinline__ void f4_tail(const Wino43Params &p, float *lds, float
                                                so + a * rp, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    IDIFF_TAIL_STAMP(2 * pass + 1);                   // outputs of this pass stored (issued)
   }
   if (want_stats) {
     __syncthreads();
@@ -227,6 +238,11 @@ __device__ __forceinline__ void f4_tail(const Wino43Params &p, float *lds, float
       dst[0] = a; dst[1] = b;
     }
   }
+#ifdef IDIFF_W43H_STAMP
+  IDIFF_TAIL_STAMP(4);
+  if (threadIdx.x == 0 && stamp_out) { for (int k = 0; k < 5; ++k) stamp_out[3 + k] = st_tail[k]; }
+#endif
+#undef IDIFF_TAIL_STAMP
 }
 
 

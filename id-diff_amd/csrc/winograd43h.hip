@@ -79,6 +79,9 @@ __device__ __forceinline__ void h4_bt_pairs(const H4Consts &k, const f2 P0, cons
 __global__ void __launch_bounds__(F4_THREADS, 2)
 winograd43h_kernel(const Wino43Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef IDIFF_W43H_STAMP   // diagnostic build (scripts/wino43h_stamps.py): 100 MHz ticks at the phases of a workgroup's life; buffer in p.coef
+  const uint64_t st_start = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int BRING = H4_BRING;                // positions of U requested ahead; must divide 9 (the ring's phase then repeats every step)
   static_assert(9 % H4_BRING == 0, "the ring of U registers must divide the nine positions of a step");
   char *const ldsb = reinterpret_cast<char *>(lds);
@@ -264,17 +267,38 @@ winograd43h_kernel(const Wino43Params p) {
   for (int j = 0; j < 6; ++j) fetch_col(j, 0);
   stage(0);
   __syncthreads();
+#ifdef IDIFF_W43H_STAMP
+  const uint64_t st_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
   {
     int s = 0;                                        // at least two steps (Cin >= 32, checked by the launcher)
     do step(s, std::false_type()); while (++s + 1 < nsteps);
   }
   step(nsteps - 1, std::true_type());
+#ifdef IDIFF_W43H_STAMP
+  const uint64_t st_loop1 = __builtin_amdgcn_s_memrealtime();
+  uint64_t *st_out = p.stamps ? p.stamps + 8 * (int64_t)blockIdx.x : nullptr;
+  if (tid == 0 && st_out) { st_out[0] = st_start; st_out[1] = st_loop0; st_out[2] = st_loop1; }
+#endif
 
 #ifdef IDIFF_W43H_DIAG_NO_VWRITE
   if (diag_sink == 12345u) ldsb[tid] = 1;
 #endif
   const float descale = p.u[(int64_t)36 * p.Cin * p.Cout];
+#ifdef IDIFF_W43H_DIAG_NO_TAIL     // timing-only build: one store per lane instead of the tail
+  float diag_sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) diag_sum += acc[i][r];
+  if (diag_sum == 12345.f) p.out[tid] = descale;
+#else
+#ifdef IDIFF_W43H_STAMP
+  f4_tail<true>(p, lds, acc, tile0, tile_m, n0, wh, wa, wb, descale, st_out);
+#else
   f4_tail<true>(p, lds, acc, tile0, tile_m, n0, wh, wa, wb, descale);
+#endif
+#endif
 }
 
 // pass 1: max |U| over the layer (bits of a non-negative float order like unsigned integers; the word was zeroed by the launcher)
@@ -387,6 +411,9 @@ IDIFF_API int idiff_conv2d_winograd43h_f32(const float *x, const float *u, float
     p.has_ep = 0; p.ep.rows_per_group = 1; p.ep.out_scale = 1.f;
   }
   p.c_nb2 = -F4_b2; p.c_na2 = -F4_a2; p.c_nab2 = -F4_ab2; p.c_a = F4_a; p.c_b = F4_b;
+#ifdef IDIFF_W43H_STAMP
+  { const char *e = getenv("IDIFF_W43H_STAMP_PTR"); p.stamps = e ? reinterpret_cast<uint64_t *>(strtoull(e, nullptr, 0)) : nullptr; }
+#endif
   static AttrGuard guard;
   const void *fn = reinterpret_cast<const void *>(winograd43h_kernel);
   if (int rc = set_dynamic_lds_once(guard, &fn, 1, (int)H4_LDS_BYTES, "conv2d_winograd43h")) return rc;

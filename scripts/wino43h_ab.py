@@ -29,7 +29,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         x = torch.randn(B, H * H, Cin, device=dev)
         w = torch.randn(Cout, 3, 3, Cin, device=dev) / (9 * Cin) ** 0.5
         o = torch.empty(B, H * H, Cout, device=dev)
-        ep = _lib.make_epilogue(bias=torch.randn(Cout, device=dev), act="silu", rows_per_group=H * H)
+        # the epilogue of a ResnetBlock's first convolution: bias, per-sample bias (time embedding), column sums for the next GroupNorm
+        ns = _lib.conv2d_winograd43_colstats_split(B, H, H, Cin, Cout)
+        cs = torch.empty(B * ns * Cout * 2, device=dev, dtype=torch.float64)
+        ep = _lib.make_epilogue(bias=torch.randn(Cout, device=dev), rowbias=torch.randn(B, Cout, device=dev), rows_per_group=H * H, colstats=cs)
         u = _lib.winograd43_pack(w, Cin, Cout, pairs=True)
         fn = lambda: _lib.conv2d_winograd43(x, u, o, B, H, H, Cin, Cout, epilogue=ep, pairs=True)
         for _ in range(2): fn()

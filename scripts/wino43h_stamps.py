@@ -1,0 +1,57 @@
+"""Where a workgroup of winograd43h_kernel spends its life (diagnostic build -DIDIFF_W43H_STAMP: s_memrealtime, 100 MHz, of lane 0 at
+kernel start, loop start, loop end, and at the tail's phases), with the epilogue of a ResnetBlock's first convolution (bias, per-sample
+bias, column sums) and of its second (residual, scale, column sums).  Run on the GPU box: python scripts/wino43h_stamps.py"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "id-diff_amd", "csrc", "build.sh")
+
+def build(extra):
+    src = open(BUILD).read()
+    patched = src.replace('extra=""', 'extra="%s"' % extra) if extra else src
+    tmp = BUILD + ".stamp.sh"
+    open(tmp, "w").write(patched)
+    try:
+        subprocess.run(["bash", tmp], check=True, stdout=subprocess.DEVNULL)
+    finally:
+        os.remove(tmp)
+
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, ROOT)
+    import torch
+    dev = "cuda"
+    B = 2240
+    holder = torch.zeros(8 * 20000, device=dev, dtype=torch.int64)
+    os.environ["IDIFF_W43H_STAMP_PTR"] = hex(holder.data_ptr())
+    import id_diff_amd
+    from id_diff_amd import _lib
+    for (H, Cin, Cout) in ((32, 128, 128), (16, 256, 256), (16, 512, 256), (8, 256, 256)):
+        x = torch.randn(B, H * H, Cin, device=dev)
+        w = torch.randn(Cout, 3, 3, Cin, device=dev) / (9 * Cin) ** 0.5
+        u = _lib.winograd43_pack(w, Cin, Cout, pairs=True)
+        out = torch.empty(B, H * H, Cout, device=dev)
+        nwg = ((B * (H // 4) ** 2 + 31) // 32) * (Cout // 64)
+        ns = _lib.conv2d_winograd43_colstats_split(B, H, H, Cin, Cout)
+        cs = torch.empty(B * ns * Cout * 2, device=dev, dtype=torch.float64)
+        res = torch.randn(B, H * H, Cout, device=dev)
+        eps = {"plain (bias)": _lib.make_epilogue(bias=torch.randn(Cout, device=dev)),
+               "conv 0 (bias, time-embedding bias, column sums)": _lib.make_epilogue(bias=torch.randn(Cout, device=dev), rowbias=torch.randn(B, Cout, device=dev), rows_per_group=H * H, colstats=cs),
+               "conv 1 (bias, residual, scale, column sums)": _lib.make_epilogue(bias=torch.randn(Cout, device=dev), residual=res, out_scale=0.7071, rows_per_group=H * H, colstats=cs)}
+        for name, ep in eps.items():
+            for _ in range(3):
+                holder.zero_()
+                _lib.conv2d_winograd43(x, u, out, B, H, H, Cin, Cout, epilogue=ep, pairs=True)
+            torch.cuda.synchronize()
+            t = holder[:8 * nwg].view(nwg, 8).cpu().double() * 0.01     # microseconds
+            ph = [t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3], t[:, 5] - t[:, 4], t[:, 6] - t[:, 5], t[:, 7] - t[:, 6]]
+            m = [float(v.median()) for v in ph]
+            steps = Cin // 16
+            print(f"{H}x{H} {Cin}->{Cout} [{name}]: {nwg} workgroups; median us per workgroup: prologue {m[0]:.1f}, K loop {m[1]:.1f} ({steps} steps: {m[1] / steps:.2f} each), "
+                  f"tail {sum(m[2:]):.1f} = exchange 0 {m[2]:.1f} + outputs 0 {m[3]:.1f} + exchange 1 {m[4]:.1f} + outputs 1 {m[5]:.1f} + column sums {m[6]:.1f};  "
+                  f"kernel span {float(t[:, 7].max() - t[:, 0].min()):.0f} us", flush=True)
+    sys.exit(0)
+
+try:
+    build("-DIDIFF_W43H_STAMP")
+    subprocess.run([sys.executable, os.path.abspath(__file__), "child"], check=False)
+finally:
+    build("")
