@@ -41,10 +41,14 @@ constexpr size_t H4_LDS_BYTES = 2 * H4_STAGE_BYTES > (int)sizeof(float) * F4_Z_F
 #endif
 constexpr int H4_BRING = IDIFF_W43H_BRING;     // positions of U requested ahead (register sets of 8)
 
-#ifndef IDIFF_W43H_LATE_AT
-#define IDIFF_W43H_LATE_AT 5
+#ifndef IDIFF_W43H_STAGE_AT
+#define IDIFF_W43H_STAGE_AT 0
 #endif
-constexpr int H4_LATE_AT = IDIFF_W43H_LATE_AT;
+#ifndef IDIFF_W43H_COLS_PER_PART
+#define IDIFF_W43H_COLS_PER_PART 1
+#endif
+constexpr int H4_COLS_PER_PART = IDIFF_W43H_COLS_PER_PART;   // columns staged behind one position (1, 2, 3 or 6)
+constexpr int H4_STAGE_AT = IDIFF_W43H_STAGE_AT;   // the next step's staging starts behind this position (0 .. 2): seven parts, one per position
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -161,9 +165,11 @@ winograd43h_kernel(const Wino43Params p) {
 #ifdef IDIFF_W43H_DIAG_NO_VWRITE
   uint32_t diag_sink = 0;
 #endif
-  auto stage = [&](int buf) __attribute__((always_inline)) {
+  // The stage of a step in seven parts -- the transform along x (all rows), then one column at a time: transform along y, cut into pairs,
+  // store, request the next step's column.  step() spreads them over the wave's positions (see there).
+  auto stage_rows = [&]() __attribute__((always_inline)) {
 #ifdef IDIFF_W43H_DIAG_NO_STAGE   // timing-only build (scripts/wino43h_ab.py): no transform, no stage writes, no input loads
-    ++f_step; (void)buf; return;
+    return;
 #endif
     // along x: two rows per instruction, in place
 #pragma unroll
@@ -173,38 +179,44 @@ winograd43h_kernel(const Wino43Params p) {
       dp[r][0] = t0; dp[r][1] = t1; dp[r][2] = t2; dp[r][3] = t3; dp[r][4] = t4; dp[r][5] = t5;
       __builtin_amdgcn_sched_barrier(0);              // one row pair / column at a time: interleaved they need registers that do not exist
     }
+  };
+  auto stage_col = [&](int buf, int j) __attribute__((always_inline)) {
+#ifdef IDIFF_W43H_DIAG_NO_STAGE
+    if (j == 5) ++f_step;
+    (void)buf; return;
+#endif
     char *Vd = ldsb + buf * H4_STAGE_BYTES + w_off;
+    // along y: V(0, j), V(5, j) | V(1, j), V(2, j) | V(3, j), V(4, j); each pair is cut into its fp16 pairs and written
+    f2 v[3];
+    h4_bt_pairs(kc, dp[0][j], dp[1][j], dp[2][j], v[0], v[1], v[2]);
+    constexpr int row_lo[3] = {0, 1, 3}, row_hi[3] = {5, 2, 4};
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      // along y: V(0, j), V(5, j) | V(1, j), V(2, j) | V(3, j), V(4, j); each pair is cut into its fp16 pairs and written
-      f2 v[3];
-      h4_bt_pairs(kc, dp[0][j], dp[1][j], dp[2][j], v[0], v[1], v[2]);
-      constexpr int row_lo[3] = {0, 1, 3}, row_hi[3] = {5, 2, 4};
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        // (hi, lo) of the two positions, two halves per register.  Two-byte stores of them (72 per lane and step) took as long as
-        // everything else in the kernel together (scripts/wino43h_ab.py: the stage without its stores cost nothing), so neighbouring
-        // lanes -- channels 2m and 2m + 1 -- trade: the even lane collects both channels' hi parts, the odd lane both lo parts, and each
-        // stores whole dwords.
-        const uint32_t xh = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[q], h2));
-        const uint32_t xl = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[q] - __builtin_convertvector(__builtin_bit_cast(h2, xh), f2), h2));
-        const uint32_t give = odd ? xh : xl, keep = odd ? xl : xh;
-        const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
-        char *qa = Vd + (6 * row_lo[q] + j) * H4_POS_BYTES, *qb = Vd + (6 * row_hi[q] + j) * H4_POS_BYTES;
+    for (int q = 0; q < 3; ++q) {
+      // (hi, lo) of the two positions, two halves per register; neighbouring lanes -- channels 2m and 2m + 1 -- trade by DPP: the even
+      // lane collects both channels' hi parts, the odd lane both lo parts, and each stores whole dwords
+      const uint32_t xh = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[q], h2));
+      const uint32_t xl = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[q] - __builtin_convertvector(__builtin_bit_cast(h2, xh), f2), h2));
+      const uint32_t give = odd ? xh : xl, keep = odd ? xl : xh;
+      const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
+      char *qa = Vd + (6 * row_lo[q] + j) * H4_POS_BYTES, *qb = Vd + (6 * row_hi[q] + j) * H4_POS_BYTES;
 #ifdef IDIFF_W43H_DIAG_NO_VWRITE  // timing-only build: the pairs are summed into one register instead of written
-        diag_sink += keep + got; (void)qa; (void)qb;
+      diag_sink += keep + got; (void)qa; (void)qb;
 #else
-        *reinterpret_cast<uint32_t *>(qa) = __builtin_amdgcn_perm(got, keep, sel0);
-        *reinterpret_cast<uint32_t *>(qb) = __builtin_amdgcn_perm(got, keep, sel1);
+      *reinterpret_cast<uint32_t *>(qa) = __builtin_amdgcn_perm(got, keep, sel0);
+      *reinterpret_cast<uint32_t *>(qb) = __builtin_amdgcn_perm(got, keep, sel1);
 #endif
-      }
-#ifdef IDIFF_W43H_DIAG_NO_XLOAD   // timing-only build: the input is loaded for the first step only
-      if (f_step == 0)
-#endif
-      fetch_col(j, f_step + 1);                       // the column's registers are free: the next step's column moves in
-      __builtin_amdgcn_sched_barrier(0);
     }
-    ++f_step;
+#ifdef IDIFF_W43H_DIAG_NO_XLOAD   // timing-only build: the input is loaded for the first step only
+    if (f_step == 0)
+#endif
+    fetch_col(j, f_step + 1);                         // the column's registers are free: the next step's column moves in
+    if (j == 5) ++f_step;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto stage = [&](int buf) __attribute__((always_inline)) {       // all of it at once: the first step's, before the loop
+    stage_rows();
+#pragma unroll
+    for (int j = 0; j < 6; ++j) stage_col(buf, j);
   };
 
   // ---------------------------------------------------------------- contraction
@@ -225,11 +237,10 @@ winograd43h_kernel(const Wino43Params p) {
     bh[pp % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane, soff, 0));
     bl[pp % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane + H4_PLANE_BYTES, soff, 0));
   };
-  // Waves w and w + 4 share a SIMD: the first four transform and stage the next step's input at the start of a step (`early`),
-  // the others in front of position H4_LATE_AT, so that one wave's vector work runs beside the other's matrix instructions.
-  // One loop body for both roles (a wave-uniform branch picks the place): two copies of the loop joined the last step through a
-  // merge the register allocator could only make by spilling.
-  const bool early = wave < 4;
+  // A step: nine positions, each three matrix instructions whose U operands were requested three positions earlier -- about one L2 round
+  // trip (~1600 clocks) per three positions, so the contraction alone is bound by that latency (stamps: 5200 clocks of a 9000-clock step
+  // when the staging was done in one block of 3000-3600 clocks beside it).  The next step's staging is therefore cut into seven parts and
+  // one part follows each of the first seven positions' matrix instructions: the wave does its vector work while its own loads fly.
   auto step = [&](int s, auto last) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last)::value;
     const int buf = s & 1;
@@ -237,12 +248,10 @@ winograd43h_kernel(const Wino43Params p) {
     auto a_hi = [&](int pp) { return *reinterpret_cast<const halfx8 *>(S + ((pp / 3) * 6 + (pp % 3)) * H4_POS_BYTES); };
     auto a_lo = [&](int pp) { return *reinterpret_cast<const halfx8 *>(S + ((pp / 3) * 6 + (pp % 3)) * H4_POS_BYTES + 32 - 2 * (a_off & 32)); };
     halfx8 ah[2], al[2];
-    if (!LAST && early) { stage(buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
     ah[0] = a_hi(0); al[0] = a_lo(0);
 #pragma unroll
     for (int pp = 0; pp < 9; ++pp) {
       __builtin_amdgcn_sched_barrier(0);
-      if (!LAST && pp == H4_LATE_AT && !early) { stage(buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
       if (pp + 1 < 9) { ah[(pp + 1) & 1] = a_hi(pp + 1); al[(pp + 1) & 1] = a_lo(pp + 1); }
       const halfx8 xh = ah[pp & 1], xl = al[pp & 1], yh = bh[pp % BRING], yl = bl[pp % BRING];
 #ifdef IDIFF_W43H_DIAG_NO_MFMA    // timing-only build: the operands are consumed by one vector instruction each instead
@@ -257,6 +266,13 @@ winograd43h_kernel(const Wino43Params p) {
 #else
       if (pp + BRING < 9) load_b(pp + BRING, s); else if (!LAST) load_b(pp + BRING - 9, s + 1);
 #endif
+      if (!LAST) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (pp == H4_STAGE_AT) stage_rows();
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (pp == H4_STAGE_AT + 1 + j / H4_COLS_PER_PART) stage_col(buf ^ 1, j);
+      }
     }
     __syncthreads();
   };
@@ -279,6 +295,11 @@ winograd43h_kernel(const Wino43Params p) {
   const uint64_t st_loop1 = __builtin_amdgcn_s_memrealtime();
   uint64_t *st_out = p.stamps ? p.stamps + 8 * (int64_t)blockIdx.x : nullptr;
   if (tid == 0 && st_out) { st_out[0] = st_start; st_out[1] = st_loop0; st_out[2] = st_loop1; }
+  // phase clocks of wave 0 (stages at the start of a step) and wave 4 (stages in front of position H4_LATE_AT), lane 0 each
+  if ((tid == 0 || tid == 256) && p.stamps) {
+    uint64_t *q = p.stamps + 8 * (int64_t)gridDim.x + 4 * ((int64_t)blockIdx.x * 2 + (tid >> 8));
+    q[0] = ph_stage; q[1] = ph_wait;
+  }
 #endif
 
 #ifdef IDIFF_W43H_DIAG_NO_VWRITE

@@ -20,7 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
     dev = "cuda"
     B = 2240
-    holder = torch.zeros(8 * 20000, device=dev, dtype=torch.int64)
+    holder = torch.zeros(16 * 20000, device=dev, dtype=torch.int64)
     os.environ["IDIFF_W43H_STAMP_PTR"] = hex(holder.data_ptr())
     import id_diff_amd
     from id_diff_amd import _lib
@@ -48,6 +48,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             print(f"{H}x{H} {Cin}->{Cout} [{name}]: {nwg} workgroups; median us per workgroup: prologue {m[0]:.1f}, K loop {m[1]:.1f} ({steps} steps: {m[1] / steps:.2f} each), "
                   f"tail {sum(m[2:]):.1f} = exchange 0 {m[2]:.1f} + outputs 0 {m[3]:.1f} + exchange 1 {m[4]:.1f} + outputs 1 {m[5]:.1f} + column sums {m[6]:.1f};  "
                   f"kernel span {float(t[:, 7].max() - t[:, 0].min()):.0f} us", flush=True)
+            ph = holder[8 * nwg:16 * nwg].view(nwg, 2, 4).cpu().double()       # [workgroup][wave 0 / wave 4][stage ticks, barrier ticks, -, -]
+            loop_us = float((t[:, 2] - t[:, 1]).median())
+            clk = float(ph[:, 0, 0].median() + 1) * 0                          # (ticks are shader clocks: shown as a share of the loop below)
+            for wv, nm in ((0, "wave 0 (stages first)"), (1, "wave 4 (stages at position 5)")):
+                st_t, wt_t = float(ph[:, wv, 0].median()), float(ph[:, wv, 1].median())
+                print(f"      {nm}: per step {st_t / (steps - 1):.0f} clocks staging, {wt_t / steps:.0f} clocks at the barrier  (a step is {loop_us / steps * 2400:.0f} clocks at 2.4 GHz)", flush=True)
     sys.exit(0)
 
 try:
