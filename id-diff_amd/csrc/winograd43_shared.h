@@ -136,31 +136,36 @@ __device__ __forceinline__ void f4_tail(const Wino43Params &p, float *lds, float
         for (int a = 0; a < 4; ++a)
           res[bb][a] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)roff, (a * p.W + 2 * pass + bb) * ld_res * 4, 0));
     }
-    if (wb == 1) {
+    // Row mixing z_{i,b} = sum_j A^T[b][j] m_{i,j}: a wave has three of a row's six columns, its partner (other column block, same
+    // rows and channels) the rest.  Each wave PARKS its part for one half of the tile rows (block 1: accumulator registers 0-7 = tile
+    // rows < 16, block 0: registers 8-15) and after the barrier ADDS its part for the other half onto what the partner parked: every
+    // wave works in both phases and moves half of what a park-all / add-all split (block 1 parks, block 0 adds) would make it move.
+    auto exchange = [&](auto blk, auto lo, auto park) __attribute__((always_inline)) {
+      constexpr int BLK = decltype(blk)::value, LO = decltype(lo)::value;
+      constexpr bool PARK = decltype(park)::value;
 #pragma unroll
       for (int ii = 0; ii < 3; ++ii)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const float m3 = acc[ii * 3][reg], m4 = acc[ii * 3 + 1][reg], m5 = acc[ii * 3 + 2][reg];
-          const int trow = (reg & 3) + 8 * (reg >> 2);
-          float *zp = zbase + (((3 * wa + ii) * F4_TILES + trow) * 2) * F4_COUT;
-          if (pass == 0) { zp[0] = m3 + m4; zp[F4_COUT] = F4_b * (m3 - m4); }
-          else { zp[0] = F4_b2 * (m3 + m4); zp[F4_COUT] = fmaf(F4_b3, m3 - m4, m5); }
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int reg = LO + r8;
+          const float ma = acc[ii * 3][reg], mb = acc[ii * 3 + 1][reg], mc = acc[ii * 3 + 2][reg];
+          float p0, p1;
+          if (BLK == 1) {                               // columns 3, 4, 5: m3, m4, m5
+            if (pass == 0) { p0 = ma + mb; p1 = F4_b * (ma - mb); }
+            else { p0 = F4_b2 * (ma + mb); p1 = fmaf(F4_b3, ma - mb, mc); }
+          } else {                                      // columns 0, 1, 2: m0, m1, m2
+            if (pass == 0) { p0 = ma + (mb + mc); p1 = F4_a * (mb - mc); }
+            else { p0 = F4_a2 * (mb + mc); p1 = F4_a3 * (mb - mc); }
+          }
+          float *zp = zbase + (((3 * wa + ii) * F4_TILES + (reg & 3) + 8 * (reg >> 2)) * 2) * F4_COUT;
+          if (PARK) { zp[0] = p0; zp[F4_COUT] = p1; }
+          else { zp[0] += p0; zp[F4_COUT] += p1; }
         }
-    }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I8 = std::integral_constant<int, 8>;
+    if (wb == 1) exchange(I1(), I0(), std::true_type()); else exchange(I0(), I8(), std::true_type());
     __syncthreads();
-    if (wb == 0) {
-#pragma unroll
-      for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const float m0 = acc[ii * 3][reg], m1 = acc[ii * 3 + 1][reg], m2 = acc[ii * 3 + 2][reg];
-          const int trow = (reg & 3) + 8 * (reg >> 2);
-          float *zp = zbase + (((3 * wa + ii) * F4_TILES + trow) * 2) * F4_COUT;
-          if (pass == 0) { zp[0] += m0 + (m1 + m2); zp[F4_COUT] = fmaf(F4_a, m1 - m2, zp[F4_COUT]); }
-          else { zp[0] = fmaf(F4_a2, m1 + m2, zp[0]); zp[F4_COUT] = fmaf(F4_a3, m1 - m2, zp[F4_COUT]); }
-        }
-    }
+    if (wb == 1) exchange(I1(), I8(), std::false_type()); else exchange(I0(), I0(), std::false_type());
     __syncthreads();
     IDIFF_TAIL_STAMP(2 * pass);                       // z of this pass exchanged
     __builtin_amdgcn_sched_barrier(0);

@@ -241,6 +241,10 @@ winograd43h_kernel(const Wino43Params p) {
   // trip (~1600 clocks) per three positions, so the contraction alone is bound by that latency (stamps: 5200 clocks of a 9000-clock step
   // when the staging was done in one block of 3000-3600 clocks beside it).  The next step's staging is therefore cut into seven parts and
   // one part follows each of the first seven positions' matrix instructions: the wave does its vector work while its own loads fly.
+#ifdef IDIFF_W43H_STAMP
+  uint32_t ph_stage = 0, ph_wait = 0;                 // shader-clock ticks this wave spent in its staging parts / at the step barrier
+#define IDIFF_PH_T() ({ __builtin_amdgcn_sched_barrier(0); const uint64_t t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); t_; })
+#endif
   auto step = [&](int s, auto last) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last)::value;
     const int buf = s & 1;
@@ -268,13 +272,23 @@ winograd43h_kernel(const Wino43Params p) {
 #endif
       if (!LAST) {
         __builtin_amdgcn_sched_barrier(0);
+#ifdef IDIFF_W43H_STAMP
+        const uint64_t a_ = IDIFF_PH_T();
+#endif
         if (pp == H4_STAGE_AT) stage_rows();
 #pragma unroll
         for (int j = 0; j < 6; ++j)
           if (pp == H4_STAGE_AT + 1 + j / H4_COLS_PER_PART) stage_col(buf ^ 1, j);
+#ifdef IDIFF_W43H_STAMP
+        ph_stage += (uint32_t)(IDIFF_PH_T() - a_);
+#endif
       }
     }
+#ifdef IDIFF_W43H_STAMP
+    { const uint64_t a_ = IDIFF_PH_T(); __syncthreads(); ph_wait += (uint32_t)(IDIFF_PH_T() - a_); }
+#else
     __syncthreads();
+#endif
   };
 
 #pragma unroll
@@ -295,7 +309,7 @@ winograd43h_kernel(const Wino43Params p) {
   const uint64_t st_loop1 = __builtin_amdgcn_s_memrealtime();
   uint64_t *st_out = p.stamps ? p.stamps + 8 * (int64_t)blockIdx.x : nullptr;
   if (tid == 0 && st_out) { st_out[0] = st_start; st_out[1] = st_loop0; st_out[2] = st_loop1; }
-  // phase clocks of wave 0 (stages at the start of a step) and wave 4 (stages in front of position H4_LATE_AT), lane 0 each
+  // phase clocks of waves 0 and 4 (the two waves of one SIMD), lane 0 each
   if ((tid == 0 || tid == 256) && p.stamps) {
     uint64_t *q = p.stamps + 8 * (int64_t)gridDim.x + 4 * ((int64_t)blockIdx.x * 2 + (tid >> 8));
     q[0] = ph_stage; q[1] = ph_wait;
