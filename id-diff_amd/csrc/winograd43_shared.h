@@ -128,8 +128,10 @@ __device__ __forceinline__ void f4_tail(const Wino43Params &p, float *lds, float
   for (int pass = 0; pass < 2; ++pass) {
     if (pass) __syncthreads();
     float4 res[2][4];
+    // the output addresses and per-tile epilogue operands (bias, per-sample bias, scale: loads from L2) are formed HERE, in front of
+    // the exchange that covers their latency; formed behind it they stood in the way of every output phase
+    prep();
     if (has_res) {
-      prep();
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
@@ -169,7 +171,6 @@ __device__ __forceinline__ void f4_tail(const Wino43Params &p, float *lds, float
     __syncthreads();
     IDIFF_TAIL_STAMP(2 * pass);                       // z of this pass exchanged
     __builtin_amdgcn_sched_barrier(0);
-    prep();
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
       const float *zr = lds + (tl * 2 + bb) * F4_COUT + 4 * cq;
@@ -231,16 +232,40 @@ __device__ __forceinline__ void f4_tail(const Wino43Params &p, float *lds, float
       red[((tl * F4_COUT) + 4 * cq + e) * 2 + 1] = s2[e];
     }
     __syncthreads();
-    const int per = p.tiles_per_img < F4_TILES ? p.tiles_per_img : F4_TILES;
+    const int per = p.tiles_per_img < F4_TILES ? p.tiles_per_img : F4_TILES;      // tiles added up per slot
     const int slots = F4_TILES / per;
-    for (int o = tid; o < slots * F4_COUT; o += F4_THREADS) {
-      const int smp = o / F4_COUT, ch = o - smp * F4_COUT;
-      const int64_t slot = (int64_t)tile_m * slots + smp;
-      if (slots > 1 && slot >= p.B) continue;
-      double a = 0.0, b = 0.0;
-      for (int k = 0; k < per; ++k) { a += red[((smp * per + k) * F4_COUT + ch) * 2]; b += red[((smp * per + k) * F4_COUT + ch) * 2 + 1]; }
-      double *dst = ep.colstats + (slot * p.Cout + n0 + ch) * 2;
-      dst[0] = a; dst[1] = b;
+    if (per >= 4) {
+      // two levels, so that all 512 threads add: thread (channel, q) the four tiles 4q .. 4q + 3 (never across a sample: per is a
+      // multiple of 4), then one thread per (slot, channel) the per / 4 partial sums -- a chain of 4 + 8 additions, not 32
+      double *part = red + F4_TILES * F4_COUT * 2;                                // [8][64][2] behind the per-tile sums
+      {
+        const int ch = tid & 63, q = tid >> 6;
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a += red[((4 * q + k) * F4_COUT + ch) * 2]; b += red[((4 * q + k) * F4_COUT + ch) * 2 + 1]; }
+        part[(q * F4_COUT + ch) * 2] = a; part[(q * F4_COUT + ch) * 2 + 1] = b;
+      }
+      __syncthreads();
+      const int quads = per / 4;
+      for (int o = tid; o < slots * F4_COUT; o += F4_THREADS) {
+        const int smp = o / F4_COUT, ch = o - smp * F4_COUT;
+        const int64_t slot = (int64_t)tile_m * slots + smp;                         // sample, or (sample, split) = workgroup row
+        if (slots > 1 && slot >= p.B) continue;
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < quads; ++k) { a += part[((smp * quads + k) * F4_COUT + ch) * 2]; b += part[((smp * quads + k) * F4_COUT + ch) * 2 + 1]; }
+        double *dst = ep.colstats + (slot * p.Cout + n0 + ch) * 2;
+        dst[0] = a; dst[1] = b;
+      }
+    } else {
+      for (int o = tid; o < slots * F4_COUT; o += F4_THREADS) {
+        const int smp = o / F4_COUT, ch = o - smp * F4_COUT;
+        const int64_t slot = (int64_t)tile_m * slots + smp;
+        if (slots > 1 && slot >= p.B) continue;
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < per; ++k) { a += red[((smp * per + k) * F4_COUT + ch) * 2]; b += red[((smp * per + k) * F4_COUT + ch) * 2 + 1]; }
+        double *dst = ep.colstats + (slot * p.Cout + n0 + ch) * 2;
+        dst[0] = a; dst[1] = b;
+      }
     }
   }
 #ifdef IDIFF_W43H_STAMP
