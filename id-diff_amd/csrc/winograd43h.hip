@@ -291,11 +291,27 @@ winograd43h_kernel(const Wino43Params p) {
 #endif
   };
 
+#ifdef IDIFF_W43H_STAMP
+  __builtin_amdgcn_sched_barrier(0);
+  const uint64_t st_pro0 = __builtin_amdgcn_s_memrealtime();     // set-up done, nothing requested yet
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
   for (int pp = 0; pp < BRING; ++pp) load_b(pp, 0);
 #pragma unroll
   for (int j = 0; j < 6; ++j) fetch_col(j, 0);
+#ifdef IDIFF_W43H_STAMP
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint64_t st_pro1 = __builtin_amdgcn_s_memrealtime();     // first operands arrived
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   stage(0);
+#ifdef IDIFF_W43H_STAMP
+  __builtin_amdgcn_sched_barrier(0);
+  const uint64_t st_pro2 = __builtin_amdgcn_s_memrealtime();     // first stage written by this wave
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   __syncthreads();
 #ifdef IDIFF_W43H_STAMP
   const uint64_t st_loop0 = __builtin_amdgcn_s_memrealtime();
@@ -312,7 +328,7 @@ winograd43h_kernel(const Wino43Params p) {
   // phase clocks of waves 0 and 4 (the two waves of one SIMD), lane 0 each
   if ((tid == 0 || tid == 256) && p.stamps) {
     uint64_t *q = p.stamps + 8 * (int64_t)gridDim.x + 4 * ((int64_t)blockIdx.x * 2 + (tid >> 8));
-    q[0] = ph_stage; q[1] = ph_wait;
+    q[0] = ph_stage; q[1] = ph_wait; q[2] = ((st_pro0 - st_start) << 32) | ((st_pro1 - st_pro0) << 16) | (st_pro2 - st_pro1); q[3] = st_loop0 - st_pro2;
   }
 #endif
 

@@ -51,6 +51,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             ph = holder[8 * nwg:16 * nwg].view(nwg, 2, 4).cpu().double()       # [workgroup][wave 0 / wave 4][stage ticks, barrier ticks, -, -]
             loop_us = float((t[:, 2] - t[:, 1]).median())
             clk = float(ph[:, 0, 0].median() + 1) * 0                          # (ticks are shader clocks: shown as a share of the loop below)
+            pro = holder[8 * nwg:16 * nwg].view(nwg, 2, 4).cpu()[:, 0]              # wave 0's prologue split, 100 MHz ticks
+            a, b, c, d = (pro[:, 2] >> 32).double() * 0.01, ((pro[:, 2] >> 16) & 0xFFFF).double() * 0.01, (pro[:, 2] & 0xFFFF).double() * 0.01, pro[:, 3].double() * 0.01
+            print(f"      prologue (wave 0, median us): set-up {float(a.median()):.1f}, first operands requested -> arrived {float(b.median()):.1f}, first stage {float(c.median()):.1f}, barrier {float(d.median()):.1f}", flush=True)
             for wv, nm in ((0, "wave 0"), (1, "wave 4 (same SIMD)")):
                 st_t, wt_t = float(ph[:, wv, 0].median()), float(ph[:, wv, 1].median())
                 print(f"      {nm}: per step {st_t / (steps - 1):.0f} clocks in its seven staging parts, {wt_t / steps:.0f} clocks at the barrier  (a step is {loop_us / steps * 2400:.0f} clocks at 2.4 GHz)", flush=True)
