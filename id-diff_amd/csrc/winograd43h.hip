@@ -16,13 +16,15 @@ namespace {
 // Why: v_mfma_f32_32x32x2_f32 runs at the vector ALU's own rate (157 TFLOP/s, 64 cycles for 4096 flops) and holds the SIMD
 // while it does, so every transform instruction above comes out of the contraction's time; the fp16 instruction does 32768 flops in
 // 32 cycles and holds the SIMD's issue for 8 of them: three of them per position and 16 channels = 96 cycles where the fp32 form
-// spends 512, and the transforms run beside them.  The kernel is then bound by its vector work and by U's bytes from L2.
+// spends 512, and the transforms run beside them.  What bounds the kernel then is memory latency: a wave has one in-order counter for
+// its loads, the input patch misses to HBM and the U loads queue behind it (profiles/r04_wino43h_loop_experiments.txt).
 //
 // Workgroup, waves, accumulators, tail: as winograd43_kernel.  K step: 16 input channels.
 // Loader: thread (tile t = tid / 16, channel c = tid % 16) holds the 6 x 6 patch of its tile and channel in 36 registers (4-byte
 //   loads, 64 contiguous bytes per tile and pixel), transforms it in place -- rows, then columns, no transposition --, splits each
-//   V(i, j) into its pair and writes the two halves to the stage; as soon as a column of the patch is consumed the same registers
-//   receive the next step's column.
+//   V(i, j) into its pair, trades halves with the neighbouring lane (channels 2m, 2m + 1) and stores whole dwords to the stage; as soon as a
+//   column of the patch is consumed the same registers receive the next step's column.  The work is cut into seven parts, one behind
+//   each of the first seven positions' matrix instructions of the current step (step()).
 // Stage (LDS): [36 positions][32 tiles][64 B]; the 64 bytes of a tile are four 16-byte chunks (plane, channel half), chunk c
 //   stored at c ^ ((tile >> 2) & 3) so that the 16 lanes of a ds_read_b128 group (tiles r .. r + 15, one chunk each) cover all
 //   64 banks.  Two stages = 147,456 B.
