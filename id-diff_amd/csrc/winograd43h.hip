@@ -197,9 +197,13 @@ winograd43h_kernel(const Wino43Params p) {
       // (hi, lo) of the two positions, two halves per register; neighbouring lanes -- channels 2m and 2m + 1 -- trade by DPP: the even
       // lane collects both channels' hi parts, the odd lane both lo parts, and each stores whole dwords
       const uint32_t xh = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[q], h2));
-      const uint32_t xl = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[q] - __builtin_convertvector(__builtin_bit_cast(h2, xh), f2), h2));
+      // v - hi in one mixed-precision instruction per component (fp32 + fp16 * -1: exact), not a conversion back and a subtraction
+      f2 rest;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rest.x) : "v"(xh), "v"(v[q].x));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest.y) : "v"(xh), "v"(v[q].y));
+      const uint32_t xl = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, h2));
       const uint32_t give = odd ? xh : xl, keep = odd ? xl : xh;
-      const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
+      const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp((int)give, (int)give, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]: every lane receives
       char *qa = Vd + (6 * row_lo[q] + j) * H4_POS_BYTES, *qb = Vd + (6 * row_hi[q] + j) * H4_POS_BYTES;
 #ifdef IDIFF_W43H_DIAG_NO_VWRITE  // timing-only build: the pairs are summed into one register instead of written
       diag_sink += keep + got; (void)qa; (void)qb;
