@@ -50,10 +50,6 @@ constexpr int H4_BRING = IDIFF_W43H_BRING;     // positions of U requested ahead
 #define IDIFF_W43H_COLS_PER_PART 1
 #endif
 constexpr int H4_COLS_PER_PART = IDIFF_W43H_COLS_PER_PART;   // columns staged behind one position (1, 2, 3 or 6)
-#ifndef IDIFF_W43H_ROTATE
-#define IDIFF_W43H_ROTATE 1
-#endif
-constexpr bool H4_ROTATE = IDIFF_W43H_ROTATE != 0;   // sibling workgroups (same tiles, other output channels) start at different channel steps
 constexpr int H4_STAGE_AT = IDIFF_W43H_STAGE_AT;   // the next step's staging starts behind this position (0 .. 2): seven parts, one per position
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -135,11 +131,6 @@ winograd43h_kernel(const Wino43Params p) {
   }
   const int row4 = p.W * (int)cin4;                   // bytes per image row
   const int nsteps = p.Cin / H4_KC;
-  // The Cout / 64 workgroups that convolve the same tiles for different output channels start together and would ask for every input
-  // line at the same moment: all of them would wait for the one HBM miss.  Each walks the channel steps from a different start (the
-  // order of a sum is free), so a line is fetched from HBM by one of them and found in the caches by the others later.
-  const int rot = H4_ROTATE ? (tile_n * nsteps) / p.tiles_n : 0;
-  auto cstep = [&](int s) __attribute__((always_inline)) { const int c = s + rot; return c >= nsteps ? c - nsteps : c; };
   // The patch in PAIRS of rows: dp[r][j] = (d[2r][j], d[2r+1][j]) -- one packed instruction (v_pk_fma_f32 / v_pk_add_f32) then
   // transforms two rows along x at once, and along y the three pairs of a column ARE the operand pairs of h4_bt_pairs.
   f2 dp[3][6];
@@ -150,7 +141,7 @@ winograd43h_kernel(const Wino43Params p) {
   const __amdgpu_buffer_rsrc_t rX0 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x - p.Cin), 0, (int)(p.x_bytes + cin4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rX5 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + 4 * p.Cin), 0, (int)(p.x_bytes - 4u * cin4), 0x00020000);
   auto fetch_col = [&](int j, int step) __attribute__((always_inline)) {
-    const int choff = cstep(min(step, nsteps - 1)) * (H4_KC * 4);
+    const int choff = min(step, nsteps - 1) * (H4_KC * 4);
     uint32_t invalid = F4_INVALID;
     asm volatile("" : "+s"(invalid));                 // the edge offsets are formed per use: hoisted they would hold 12 registers
 #pragma unroll
@@ -248,7 +239,7 @@ winograd43h_kernel(const Wino43Params p) {
   halfx8 bh[BRING], bl[BRING];
   auto load_b = [&](int pp, int step) __attribute__((always_inline)) {
     const int slot = pos0 + (pp / 3) * 6 + (pp % 3);
-    const int soff = ((cstep(step) * p.tiles_n + tile_n) * F4_NPOS + slot) * H4_SLOT_BYTES;
+    const int soff = ((step * p.tiles_n + tile_n) * F4_NPOS + slot) * H4_SLOT_BYTES;
     bh[pp % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane, soff, 0));
     bl[pp % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane + H4_PLANE_BYTES, soff, 0));
   };
