@@ -374,3 +374,21 @@ def test_nan_spectra_raise_instead_of_yielding_an_id():
     assert torch.equal(dim_reduction.checked_spectra(ok), ok)
     with pytest.raises(RuntimeError, match="reported a failure"):
         dim_reduction.checked_spectra(torch.tensor([[3.0, float("nan"), 1.0]]))
+
+
+def test_winograd_form_routing():
+    """Which 3x3 kernel form the executor picks (host logic + the C-ABI's geometry answers, no GPU): GroupNorm-fed convolutions go to the
+    fp16-pair F(4x4, 3x3) kernel from one workgroup per CU on, 4x4 maps included; other inputs keep the fp32 contraction and its
+    stricter profitability rule; geometries the pair kernel refuses (Cin % 16) fall back; the switch turns the pair form off."""
+    from id_diff_amd import _lib
+    from id_diff_amd.models import ncsnpp as hip_ncsnpp
+    pays = hip_ncsnpp._winograd43_pays
+    assert pays(2240, 32, 32, 128, 128, normed=True) and pays(2240, 32, 32, 128, 128)
+    assert pays(2240, 4, 4, 256, 256, normed=True) and not pays(2240, 4, 4, 256, 256)          # 280 workgroups of one-tile samples
+    assert pays(128, 16, 16, 256, 256, normed=True) and not pays(127, 16, 16, 256, 128, normed=True)   # 256 workgroups (one per CU) is the threshold
+    assert not pays(64, 8, 8, 256, 256, normed=True) and not pays(64, 8, 8, 256, 256)          # a test-sized batch: F(2x2) or the implicit GEMM
+    assert _lib.conv2d_winograd43_ok(4, 8, 8, 24, 64) and not _lib.conv2d_winograd43h_ok(4, 8, 8, 24, 64)   # Cin % 16
+    assert pays(8192, 8, 8, 24, 64, normed=True) == pays(8192, 8, 8, 24, 64)                   # refused by the pair kernel: the fp32 rule decides
+    with _lib.thread_option("IDIFF_NO_WINO43H", 1):
+        assert not pays(2240, 4, 4, 256, 256, normed=True) and pays(2240, 32, 32, 128, 128, normed=True)
+    assert _lib.lib().idiff_winograd43h_weight_floats(128, 256) == 36 * 128 * 256 + 4
