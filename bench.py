@@ -52,8 +52,11 @@ HBM_PEAK_GBS = 8000.0
 # contractions: every fp32 operand is cut EXACTLY into three bf16 pieces and six of the nine partial products (all of weight
 # >= 2^-16) run on the bf16 matrix cores with fp32 accumulation -- 1.7e-7 against an fp64 contraction where the fp32 MFMA
 # chain gives 2.0e-7 (scripts/bf16x6_probe.hip); every parity bar of tests/ is unchanged.  IDIFF_NO_SPLIT=1 selects fp32 MFMAs.
-DTYPE = "f32" if os.environ.get("IDIFF_NO_SPLIT") else \
-    "f32 (3x3 convs: Winograd F(4x4,3x3), fp32 transforms, contraction on pairs of fp16 values -- 22 significand bits, 3 products, fp32 accumulate; F(2x2,3x3) on fp32 MFMA for the 4x4 maps; 1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate)"
+_CONV_ARITH = ("3x3 convs: Winograd F(4x4,3x3), fp32 transforms, fp32 MFMA contraction" if (os.environ.get("IDIFF_NO_WINO43H") or os.environ.get("IDIFF_NO_WINO43"))
+               else "3x3 convs: Winograd F(4x4,3x3), fp32 transforms, contraction on pairs of fp16 values -- 22 significand bits, 3 products, fp32 accumulate")
+_GEMM_ARITH = ("1x1/attention/dense contractions: fp32 MFMA" if os.environ.get("IDIFF_NO_SPLIT")
+               else "1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate")
+DTYPE = f"f32 ({_CONV_ARITH}; {_GEMM_ARITH})"
 WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=1e-5, B=128 -> S 4480x3072 + centred spectrum + ID"
 # PMC traffic tables (separate FETCH_SIZE / WRITE_SIZE passes, scripts/profile_round.sh), each stamped with the sha256 of the kernel
 # source it was measured on: F(4x4,3x3) (the dominant kernel) and F(2x2,3x3)
