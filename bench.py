@@ -613,7 +613,7 @@ def main(argv=None, workload_factory=Workload):
     if parallel.launched():
         parallel.check_world(args.gpus, int(os.environ["WORLD_SIZE"]), need_devices=args.device != "cpu")
     rank, world, local_rank = parallel.init_from_env(backend="gloo" if args.device == "cpu" else None)
-    dev = torch.device(args.device) if args.device else torch.device(f"cuda:{local_rank}")
+    dev = torch.device(args.device) if args.device else torch.device(f"cuda:{parallel.device_ordinal(local_rank)}")
     if dev.type == "cuda":
         torch.cuda.set_device(dev)
         # one process per GPU: every rank launches from its own host thread; the few CPU-side tensor ops (ID rule, pinned

@@ -66,7 +66,7 @@ def main(argv=None):
             parallel.check_world(flags.gpus, int(os.environ["WORLD_SIZE"]))
     rank, world, local_rank = parallel.init_from_env()
     if world > 1:
-        config.device = f"cuda:{local_rank}"
+        config.device = f"cuda:{parallel.device_ordinal(local_rank)}"
     if flags.mode == 'manifold_dimension':
         run_lib.get_manifold_dimension(config, name=flags.log_name)
     else:

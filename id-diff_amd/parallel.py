@@ -58,6 +58,17 @@ def visible_devices():
     return torch.cuda.device_count()
 
 
+def shares_card():
+    """IDIFF_DIST_BACKEND=gloo on a GPU box: the rehearsal mode in which several ranks share the visible card(s)."""
+    return os.environ.get("IDIFF_DIST_BACKEND") == "gloo"
+
+
+def device_ordinal(local_rank):
+    """The device of this rank: its LOCAL_RANK -- wrapped over the visible cards only in the card-sharing rehearsal mode."""
+    n = visible_devices()
+    return local_rank % n if (shares_card() and n) else local_rank
+
+
 def check_world(requested, world, need_devices=True):
     """A world that is not the one asked for is an error, never a warning: a scaling run whose ``--gpus 8`` leg silently ran
     one rank would report a one-GPU number under an eight-GPU label.  With ``need_devices`` this rank's device ordinal
@@ -65,7 +76,7 @@ def check_world(requested, world, need_devices=True):
     if world != requested:
         raise SystemExit(f"error: --gpus {requested} but the launcher started WORLD_SIZE {world} rank(s)")
     local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
-    if need_devices and os.environ.get("IDIFF_DIST_BACKEND") != "gloo" and visible_devices() <= local_rank:
+    if need_devices and not shares_card() and visible_devices() <= local_rank:
         raise SystemExit(f"error: {int(os.environ.get('LOCAL_WORLD_SIZE', world))} devices needed, {visible_devices()} visible "
                          f"(LOCAL_RANK {local_rank} has no device)")
 
@@ -81,7 +92,7 @@ def launch_local_ranks(script, argv, n, need_devices=True, timeout=None):
     (the remaining ranks are terminated then), else 0."""
     if n < 1:
         raise SystemExit(f"error: --gpus {n}")
-    if need_devices and visible_devices() < n:
+    if need_devices and visible_devices() < (1 if shares_card() else n):
         raise SystemExit(f"error: {n} devices needed, {visible_devices()} visible")
     with socket.socket() as s:                       # a free rendezvous port on the loop-back interface
         s.bind(("127.0.0.1", 0))

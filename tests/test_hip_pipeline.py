@@ -419,8 +419,31 @@ def test_bench_gpus_beyond_the_visible_devices_is_an_error_not_a_one_rank_line()
     it ran ONE rank and printed n_gpus 1."""
     import subprocess
     n = torch.cuda.device_count()
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "IDIFF_DIST_BACKEND")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and f"{n + 1} devices needed, {n} visible" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_the_card_rehearsal():
+    """IDIFF_DIST_BACKEND=gloo: `python bench.py --gpus 2` on a one-GPU box starts two rank processes that share the card
+    (the HIP path of each rank, the point sharding and the all-gather of spectra + IDs as on two GPUs; only the transport
+    differs).  The line says so: process_group gloo, both ranks on the same ordinal."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["IDIFF_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-extras", "--no-cpu-baseline", "--no-probe"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    n = torch.cuda.device_count()
+    assert line["n_gpus"] == 2 and line["config"]["process_group"] == "gloo"
+    assert line["config"]["rank_devices"] == ["cuda:0", f"cuda:{1 % n}"]
+    assert len(line["id_estimates_all_ranks"]) == 2 and all(3000 < d <= 3072 for d in line["id_estimates_all_ranks"])
+    assert line["value"] == pytest.approx(2 * line["config"]["rows_per_point"] / (line["ms_per_step"] * 1e-3), rel=1e-6)
