@@ -306,6 +306,12 @@ constexpr int SP = BK;
 __device__ __forceinline__ int split_swz(int row) { return (row ^ (row >> 2)) & 3; }
 
 __device__ __forceinline__ void split4(const float4 v, uint2 &p1, uint2 &p2, uint2 &p3) {
+#ifdef IDIFF_IGEMM_DIAG_NO_CUT   // timing-only build (scripts/igemm_ab.py): no cutting arithmetic, results wrong by construction
+  p1 = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+  p2 = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+  p3 = p1;
+  return;
+#endif
   const float x[4] = {v.x, v.y, v.z, v.w};
   uint32_t t1[4], t2[4], t3[4];
 #pragma unroll
@@ -537,7 +543,11 @@ igemm_pipe_kernel(const IgemmParams p) {
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s)
 #pragma unroll
+#ifdef IDIFF_IGEMM_DIAG_ONE_PRODUCT   // timing-only build: one of the six partial products (and a third of the fragment reads)
+        for (int t = 0; t < 1; ++t)
+#else
         for (int t = 0; t < 6; ++t)
+#endif
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -582,7 +592,11 @@ igemm_pipe_kernel(const IgemmParams p) {
       // resident workgroups keep the matrix pipe busy meanwhile
       if (kt + 1 < nkt) stage(0);
       IDIFF_PH(2)
+#ifdef IDIFF_IGEMM_DIAG_NO_FETCH   // timing-only build: operands fetched for the first two k-tiles only
+      if (kt + 2 < nkt) ++f_kt;
+#else
       if (kt + 2 < nkt) fetch();
+#endif
       IDIFF_PH(3)
       __syncthreads();
       IDIFF_PH(4)
