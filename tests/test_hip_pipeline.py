@@ -447,3 +447,27 @@ def test_bench_two_ranks_sharing_the_card_rehearsal():
     assert line["config"]["rank_devices"] == ["cuda:0", f"cuda:{1 % n}"]
     assert len(line["id_estimates_all_ranks"]) == 2 and all(3000 < d <= 3072 for d in line["id_estimates_all_ranks"])
     assert line["value"] == pytest.approx(2 * line["config"]["rows_per_point"] / (line["ms_per_step"] * 1e-3), rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_rccl():
+    """The driver's launch line for N > 1, at the N this box has: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` -- one rank per GPU, RCCL process group (also at N = 1), one
+    JSON line from rank 0."""
+    import json
+    import subprocess
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "IDIFF_DIST_BACKEND")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1",
+                        "--warmup", "0", "--no-extras", "--no-cpu-baseline", "--no-probe"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == n and line["config"]["process_group"] == "nccl" and line["config"]["launched_by"] == "external launcher"
+    assert line["config"]["rank_devices"] == [f"cuda:{i}" for i in range(n)]
+    assert len(line["id_estimates_all_ranks"]) == n
+    assert line["value"] == pytest.approx(n * line["config"]["rows_per_point"] / (line["ms_per_step"] * 1e-3), rel=1e-6)
