@@ -32,6 +32,9 @@ _SIGNATURES = {
     "idiff_last_error": (ctypes.c_char_p, []),
     "idiff_source_stamp": (ctypes.c_char_p, []),
     "idiff_set_option": (c_i, [ctypes.c_char_p, c_i]),
+    "idiff_gemm_pairs_ok": (c_i, [c_i, c_i, c_i, c_i]),
+    "idiff_gemm_pairs_scale_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
+    "idiff_gemm_pairs_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p, c_p]),
     "idiff_set_thread_option": (c_i, [ctypes.c_char_p, c_i, c_i]),
     "idiff_upfirdn2d_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 14 + [c_p]),
     "idiff_fused_bias_act_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
@@ -291,6 +294,65 @@ def gemm(a, bt, out=None, epilogue=None, M=None, N=None, K=None, lda=None, ldb=N
     _check(lib().idiff_gemm_f32(a.data_ptr(), lda, stride_a, bt.data_ptr(), ldb, stride_b, out.data_ptr(), ldc, stride_c,
                                 M, N, K, batch, ep, _stream()), "idiff_gemm_f32")
     return out
+
+
+def gemm_pairs_ok(M, N, K, batch=1):
+    """True when gemm_pairs serves this shape (IDIFF_NO_PAIRS / IDIFF_NO_SPLIT / IDIFF_NO_PIPE turn it off)."""
+    return bool(lib().idiff_gemm_pairs_ok(M, N, K, batch))
+
+
+def gemm_pairs_scale(w):
+    """Device tensor {s, 1 / s}: the power of two a weight [rows, K] is multiplied by before its cut into fp16 pairs (once per weight)."""
+    _dev(w, "w")
+    out = torch.empty(2, device=w.device, dtype=torch.float32)
+    _check(lib().idiff_gemm_pairs_scale_f32(w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], out.data_ptr(), _stream()),
+           "idiff_gemm_pairs_scale_f32")
+    return out
+
+
+def gemm_pairs(a, bt, w_scale, out, epilogue=None, weight_is_a=False, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
+               batch=1, stride_a=0, stride_b=0, stride_c=0):
+    """out[b] = epilogue(a[b] @ bt[b].T) on fp16 pairs (three matrix instructions per block instead of six).  One operand is a
+    weight -- ``bt``, or ``a`` with ``weight_is_a`` -- whose ``w_scale`` comes from gemm_pairs_scale; the other an activation of
+    order one (a GroupNorm's output): see idiff_gemm_pairs_f32.  2-D tensors by default, explicit geometry for batched views."""
+    explicit = M is not None
+    _dev(a, "a", contiguous=not explicit); _dev(bt, "bt", contiguous=not explicit); _dev(out, "out", contiguous=not explicit)
+    _dev(w_scale, "w_scale")
+    if M is None:
+        M, K = a.shape
+        N = bt.shape[0]
+        if bt.shape[1] != K or out.shape[0] != M or out.shape[1] != N:
+            raise RuntimeError(f"gemm_pairs: shapes {tuple(a.shape)} x {tuple(bt.shape)}^T -> {tuple(out.shape)}")
+        lda, ldb, ldc = a.stride(0), bt.stride(0), out.stride(0)
+    ep = ctypes.byref(epilogue) if epilogue is not None else None
+    _check(lib().idiff_gemm_pairs_f32(a.data_ptr(), lda, stride_a, bt.data_ptr(), ldb, stride_b, w_scale.data_ptr(), int(bool(weight_is_a)),
+                                      out.data_ptr(), ldc, stride_c, M, N, K, batch, ep, _stream()), "idiff_gemm_pairs_f32")
+    return out
+
+
+def gemm_normed(cache, a, w, out, epilogue=None):
+    """out = epilogue(a @ w.T) for ``a`` [M, K] = the output of a GroupNorm (order one by construction) and a weight ``w`` [N, K]:
+    on fp16 pairs where that form serves the shape, else on gemm's six bf16 products.  ``cache``: a dict that lives as long as
+    the weights (the executor's pack), holding each weight's power-of-two scale."""
+    M, K = a.shape
+    if not gemm_pairs_ok(M, w.shape[0], K):
+        return gemm(a, w, out=out, epilogue=epilogue)
+    return gemm_pairs(a, w, _pairs_scale_of(cache, w), out, epilogue=epilogue)
+
+
+def _pairs_scale_of(cache, w):
+    sc = cache.setdefault("pairs_scale", {})
+    if id(w) not in sc:
+        sc[id(w)] = (gemm_pairs_scale(w), w)                  # the weight itself keeps the id unique while the entry lives
+    return sc[id(w)][0]
+
+
+def gemm_weight_times_normed_t(cache, w, x, out, B, HW, C):
+    """out[b] = w [C, C] @ x[b]^T for x [B, HW, C] = the output of a GroupNorm: V^T of an attention block, K-contiguous for P.V."""
+    kw = dict(M=C, N=HW, K=C, lda=C, ldb=C, ldc=HW, batch=B, stride_a=0, stride_b=HW * C, stride_c=C * HW)
+    if not gemm_pairs_ok(C, HW, C, B):
+        return gemm(w, x, out=out, **kw)
+    return gemm_pairs(w, x, _pairs_scale_of(cache, w), out, weight_is_a=True, **kw)
 
 
 def gemm_2src(a1, a2, bt, out, epilogue=None):

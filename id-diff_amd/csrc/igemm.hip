@@ -54,6 +54,8 @@ struct IgemmParams {
   uint32_t a2_bytes;
   uint32_t c_bytes, res_bytes;  // extents of one batch slice of C and of the residual; buf_ep = they fit a buffer descriptor
   int buf_ep;
+  const float *pair_scale;      // fp16-pair form: device pointer to {s, 1 / s}, s the power of two the WEIGHT operand is multiplied by
+  int pair_on_a;                //   before its cut: Bt, or A when pair_on_a (the weight is the left operand: V^T = Wv n^T)
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -325,6 +327,25 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &p1, uint2 &p2, uin
   p2 = make_uint2((t2[0] >> 16) | t2[1], (t2[2] >> 16) | t2[3]);
   p3 = make_uint2((t3[0] >> 16) | (t3[1] & 0xffff0000u), (t3[2] >> 16) | (t3[3] & 0xffff0000u));
 }
+// ---- fp16-pair products (SPLIT == 2): an fp32 operand as hi = fp16(v), lo = fp16(v - hi) (22 significand bits), a product as
+// lo hi + hi lo + hi hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- THREE matrix instructions per 32 x 32 x 16 block where
+// the bf16 cut needs six, and 3.5 vector instructions per element to cut where that needs 6.5.  The matrix pipes are what the
+// six-product form runs out of (profiles/HISTORY_r04.md: 180 us of pipe time at 2.4 GHz per [573440 x 256] x [256 x 256]^T launch,
+// ~270 at the clock the chip holds under that load), so this is the form that is faster, not another tiling.  fp16 has 5 exponent
+// bits: the caller vouches for the ranges (include/idiff_hip.h, idiff_gemm_pairs_f32) -- A as it is, |a| < 65504 and of order one
+// (below 0.25 the low half goes subnormal: absolute error 2^-25 per element instead of relative 2^-22), Bt multiplied by the power
+// of two that brings its largest element into [2^11, 2^12) and the sums divided by it again, exactly.
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void pair4(const float4 v, uint2 &hi, uint2 &lo) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const f2 v01 = {v.x, v.y}, v23 = {v.z, v.w};
+  const h2 h01 = __builtin_convertvector(v01, h2), h23 = __builtin_convertvector(v23, h2);
+  const f2 r01 = v01 - __builtin_convertvector(h01, f2), r23 = v23 - __builtin_convertvector(h23, f2);   // exact
+  const h2 l01 = __builtin_convertvector(r01, h2), l23 = __builtin_convertvector(r23, h2);
+  hi = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+  lo = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
+}
 bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
@@ -332,7 +353,7 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t b
   return __builtin_bit_cast(float4, v);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF, bool SPLIT>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF, int SPLIT>   // SPLIT: 0 fp32 MFMA, 1 three bf16, 2 fp16 pairs
 __global__ void __launch_bounds__(WARPS_M *WARPS_N * 64, (DBUF || SPLIT) ? 2 : 4)
 igemm_pipe_kernel(const IgemmParams p) {
 #ifdef IDIFF_IGEMM_PHASES
@@ -349,9 +370,10 @@ igemm_pipe_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *As = lds;
   float *Bs = lds + (DBUF ? 2 : 1) * BM * LDS_PITCH;
-  // SPLIT: three bf16 planes per operand and buffer, [buffer][plane][row][SP]
+  // SPLIT: three bf16 (two fp16) planes per operand and buffer, [buffer][plane][row][SP]
+  constexpr int PLANES = SPLIT == 2 ? 2 : 3;
   unsigned short *As16 = reinterpret_cast<unsigned short *>(lds);
-  unsigned short *Bs16 = As16 + (DBUF ? 2 : 1) * 3 * BM * SP;
+  unsigned short *Bs16 = As16 + (DBUF ? 2 : 1) * PLANES * BM * SP;
 
   const int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
@@ -463,7 +485,31 @@ igemm_pipe_kernel(const IgemmParams p) {
   // ROW_STEP is a multiple of 16, so the swizzle of a thread's rows is one constant
   static_assert(ROW_STEP % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "split-plane swizzle");
   const int kc_sw = (((kc >> 3) ^ split_swz(row_base)) << 3) + (kc & 7);
+  const float pair_w = SPLIT == 2 ? p.pair_scale[0] : 1.f;
+  const float pair_sa = (SPLIT == 2 && p.pair_on_a) ? pair_w : 1.f, pair_s = (SPLIT == 2 && !p.pair_on_a) ? pair_w : 1.f;
   auto stage = [&](int buf) {
+    if (SPLIT == 2) {
+      unsigned short *a_dst = As16, *b_dst = Bs16;
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) {
+        uint2 hi, lo;
+        const float4 av = a_reg[i];
+        pair4(make_float4(av.x * pair_sa, av.y * pair_sa, av.z * pair_sa, av.w * pair_sa), hi, lo);
+        unsigned short *d = a_dst + (row_base + i * ROW_STEP) * SP + kc_sw;
+        *reinterpret_cast<uint2 *>(d) = hi;
+        *reinterpret_cast<uint2 *>(d + BM * SP) = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < B_PER_T; ++i) {
+        uint2 hi, lo;
+        const float4 w = b_reg[i];
+        pair4(make_float4(w.x * pair_s, w.y * pair_s, w.z * pair_s, w.w * pair_s), hi, lo);
+        unsigned short *d = b_dst + (row_base + i * ROW_STEP) * SP + kc_sw;
+        *reinterpret_cast<uint2 *>(d) = hi;
+        *reinterpret_cast<uint2 *>(d + BN * SP) = lo;
+      }
+      return;
+    }
     if (SPLIT) {
       unsigned short *a_dst = As16 + buf * 3 * BM * SP, *b_dst = Bs16 + buf * 3 * BN * SP;
 #pragma unroll
@@ -520,7 +566,38 @@ igemm_pipe_kernel(const IgemmParams p) {
       if (kt + 1 < nkt) stage(buf ^ 1);   // tile kt+1: loaded one iteration ago
       if (kt + 2 < nkt) fetch();          // tile kt+2: lands while this tile's 64 MFMAs run
     }
-    if (SPLIT) {
+    if (SPLIT == 2) {
+      const int c0 = (lane >> 5) ^ split_swz(frag_row);
+      const unsigned short *a16 = As16 + (wm0 + frag_row) * SP, *b16 = Bs16 + (wn0 + frag_row) * SP;
+      halfx8 af[BK / 16][TM][2], bf[BK / 16][TN][2];
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) af[s][i][q] = *reinterpret_cast<const halfx8 *>(a16 + (q * BM + i * 32) * SP + ((c0 ^ (2 * s)) << 3));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) bf[s][j][q] = *reinterpret_cast<const halfx8 *>(b16 + (q * BN + j * 32) * SP + ((c0 ^ (2 * s)) << 3));
+      }
+      constexpr int QA[3] = {1, 0, 0}, QB[3] = {0, 1, 0};     // lo hi, hi lo, hi hi
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (decltype(first)::value && s == 0 && t == 0) {
+                const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i][QA[t]], bf[s][j][QB[t]], zero, 0, 0, 0);
+              } else {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i][QA[t]], bf[s][j][QB[t]], acc[i][j], 0, 0, 0);
+              }
+            }
+    } else if (SPLIT) {
       // lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8 h + e] and B[k = 8 h + e][column r], e = 0 .. 7
       // chunk (lane >> 5) + 2 s of row frag_row (+ multiples of 32: same swizzle): c0 for s = 0, c0 ^ 2 for s = 1
       const int c0 = (lane >> 5) ^ split_swz(frag_row);
@@ -612,6 +689,15 @@ igemm_pipe_kernel(const IgemmParams p) {
   const uint64_t ph_loop1 = __builtin_amdgcn_s_memtime();
 #endif
 
+  if (SPLIT == 2) {
+    const float inv = p.pair_scale[1];               // a power of two: exact
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+  }
   float *Cb = p.C + (int64_t)batch * p.strideC;
   const idiff_epilogue &ep = p.ep;
   const int col_l = lane & 31, row_l = (lane >> 5) * 4;
@@ -865,11 +951,11 @@ igemm_pipe_kernel(const IgemmParams p) {
 }
 #undef IDIFF_PH
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF = true, bool SPLIT = false>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool CONV, bool DBUF = true, int SPLIT = 0>
 int launch_pipe(IgemmParams &p, int batch, hipStream_t st) {
   p.tiles_m = idiff::ceil_div(p.M, BM);
   p.tiles_n = idiff::ceil_div(p.N, BN);
-  constexpr size_t stage_bytes = SPLIT ? (size_t)(DBUF ? 2 : 1) * (BM + BN) * 3 * SP * sizeof(unsigned short)
+  constexpr size_t stage_bytes = SPLIT ? (size_t)(DBUF ? 2 : 1) * (BM + BN) * (SPLIT == 2 ? 2 : 3) * SP * sizeof(unsigned short)
                                        : (size_t)(DBUF ? 2 : 1) * (BM + BN) * LDS_PITCH * sizeof(float);
   // (the epilogue turns the accumulators through one 32 x WTN fp32 patch per wave in the same memory)
   constexpr size_t patch_bytes = (size_t)WARPS_M * WARPS_N * 32 * (BN / WARPS_N) * sizeof(float);
@@ -917,11 +1003,11 @@ int dispatch_pipe(IgemmParams &p, int batch, hipStream_t st) {
     // the matrix instructions of tile t by sched_group_barrier was built and measured: 118-128 TFLOP/s against 140-180 for
     // this one -- at 32 k per tile a 128 x 128 workgroup asks the L2 for 32 KB per 1600 matrix-pipe cycles, which is what
     // bounds it, not the instruction mix.)
-    if (p.N > 64 && wg_big >= 256) return launch_pipe<128, 128, 2, 2, CONV, false, true>(p, batch, st);
-    if (p.N <= 32 && p.M >= 4096) return launch_pipe<128, 32, 4, 1, CONV, false, true>(p, batch, st);
+    if (p.N > 64 && wg_big >= 256) return launch_pipe<128, 128, 2, 2, CONV, false, 1>(p, batch, st);
+    if (p.N <= 32 && p.M >= 4096) return launch_pipe<128, 32, 4, 1, CONV, false, 1>(p, batch, st);
     const int64_t wg_mid_s = (int64_t)idiff::ceil_div(p.M, 128) * idiff::ceil_div(p.N, 64) * batch;
-    if (wg_mid_s >= 256 || p.M >= 4096) return launch_pipe<128, 64, 2, 2, CONV, false, true>(p, batch, st);
-    return launch_pipe<64, 64, 2, 2, CONV, false, true>(p, batch, st);
+    if (wg_mid_s >= 256 || p.M >= 4096) return launch_pipe<128, 64, 2, 2, CONV, false, 1>(p, batch, st);
+    return launch_pipe<64, 64, 2, 2, CONV, false, 1>(p, batch, st);
   }
   // >= 4 workgroups per CU available: single LDS buffer, 128 registers, four resident workgroups per CU
   // (measured 135-142 TFLOP/s vs 124-135 for the double-buffered two-workgroup form)
@@ -1009,6 +1095,70 @@ IDIFF_API int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const
   if (ep && ep->colstats) return fail("gemm: colstats requested for a problem the pipelined kernel does not take "
                                       "(ask idiff_gemm_colstats_split first)");
   return vec ? dispatch<false, true>(p, batch, st) : dispatch<false, false>(p, batch, st);
+}
+
+namespace {
+// {s, 1 / s} with s the power of two that brings max |Bt| into [2^11, 2^12) (1 for an all-zero matrix); one workgroup
+__global__ void __launch_bounds__(256) pairs_scale_kernel(const float *__restrict__ bt, int64_t ldb, int N, int K, float *__restrict__ out) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < (int64_t)N * K; i += 256) m = fmaxf(m, fabsf(bt[(i / K) * ldb + (i % K)]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float mx = red[0];
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &e);          // mx = f * 2^e, f in [0.5, 1)
+    const int sh = mx > 0.f && mx < INFINITY ? 12 - e : 0;        // mx * 2^sh in [2^11, 2^12)
+    out[0] = ldexpf(1.f, sh);
+    out[1] = ldexpf(1.f, -sh);
+  }
+}
+bool pairs_geometry_ok(int M, int N, int K, int batch) {
+  if (M <= 0 || N <= 64 || K <= 0 || K % 4 || batch <= 0 || batch > 65535) return false;
+  const int want = idiff::option_value(idiff::OPT_PAIRS_MIN_TILES);                  // tests: serve small problems too
+  return (int64_t)idiff::ceil_div(M, 128) * idiff::ceil_div(N, 128) * batch >= (want > 0 ? want : 256);   // the 128 x 128 tiles fill the chip
+}
+}  // namespace
+
+IDIFF_API int idiff_gemm_pairs_ok(int M, int N, int K, int batch) {
+  if (idiff::option(idiff::OPT_NO_PIPE) || idiff::option(idiff::OPT_NO_SPLIT) || idiff::option(idiff::OPT_NO_PAIRS)) return 0;
+  return pairs_geometry_ok(M, N, K, batch) ? 1 : 0;
+}
+
+IDIFF_API int idiff_gemm_pairs_scale_f32(const float *Bt, int64_t ldb, int N, int K, float *scale, void *stream) {
+  using namespace idiff;
+  if (!Bt || !scale) return fail("gemm_pairs_scale: null pointer");
+  if (N <= 0 || K <= 0 || ldb < K) return fail("gemm_pairs_scale: bad shape N=%d K=%d ldb=%lld", N, K, (long long)ldb);
+  hipLaunchKernelGGL(pairs_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Bt, ldb, N, K, scale);
+  return launch_status("gemm_pairs_scale");
+}
+
+IDIFF_API int idiff_gemm_pairs_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt, int64_t ldb, int64_t strideB,
+                                   const float *w_scale, int weight_is_a, float *C, int64_t ldc, int64_t strideC, int M, int N, int K,
+                                   int batch, const idiff_epilogue *ep, void *stream) {
+  using namespace idiff;
+  if (M < 0 || N < 0 || K <= 0 || batch < 0) return fail("gemm_pairs: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  if (M == 0 || N == 0 || batch == 0) return 0;
+  if (!A || !Bt || !C || !w_scale) return fail("gemm_pairs: null pointer");
+  if (lda < K || ldb < K || ldc < N) return fail("gemm_pairs: leading dimension smaller than the row length");
+  if (!pairs_geometry_ok(M, N, K, batch)) return fail("gemm_pairs: M=%d N=%d K=%d batch=%d not served (ask idiff_gemm_pairs_ok)", M, N, K, batch);
+  const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) && (strideB % 4 == 0) && aligned16(A) && aligned16(Bt);
+  const int64_t a_bytes = ((int64_t)(M - 1) * lda + K) * 4, b_bytes = ((int64_t)(N - 1) * ldb + K) * 4;
+  if (!vec || a_bytes >= BUF_LIMIT || b_bytes >= BUF_LIMIT)
+    return fail("gemm_pairs: operands must be 16-byte aligned with row pitches and batch strides that are multiples of 4, one "
+                "batch slice inside 4 GiB");
+  if (ep && ep->colstats && batch != 1) return fail("gemm_pairs: colstats only for unbatched problems");
+  IgemmParams p = {};
+  p.A = A; p.Bt = Bt; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.strideA = strideA; p.strideB = strideB; p.strideC = strideC;
+  p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes; p.pair_scale = w_scale; p.pair_on_a = weight_is_a ? 1 : 0;
+  fill_epilogue(p, ep);
+  return launch_pipe<128, 128, 2, 2, false, false, 2>(p, batch, (hipStream_t)stream);
 }
 
 IDIFF_API int idiff_gemm_2src_f32(const float *A1, const float *A2, int64_t lda, int K1, const float *Bt, int64_t ldb,

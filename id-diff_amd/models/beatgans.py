@@ -218,10 +218,9 @@ class BeatGANsUNetModel(HipScoreModel):
         wqk, bqk, wv, bv, wo, bo = pk["lin"][key]
         dev = x.buf.device
         qk = torch.empty(B * HW, 2 * C, device=dev, dtype=torch.float32)
-        _lib.gemm(n.buf.view(-1, C), wqk, out=qk, epilogue=_lib.make_epilogue(bias=bqk))
+        _lib.gemm_normed(pk, n.buf.view(-1, C), wqk, qk, epilogue=_lib.make_epilogue(bias=bqk))    # n: a GroupNorm's output
         vt = torch.empty(B, C, HW, device=dev, dtype=torch.float32)
-        _lib.gemm(wv, n.buf, out=vt, M=C, N=HW, K=C, lda=C, ldb=C, ldc=HW, batch=B, stride_a=0, stride_b=HW * C,
-                  stride_c=C * HW)
+        _lib.gemm_weight_times_normed_t(pk, wv, n.buf, vt, B, HW, C)
         logits = torch.empty(B, HW, HW, device=dev, dtype=torch.float32)
         _lib.gemm(qk, qk[:, C:], out=logits, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B,
                   stride_a=HW * 2 * C, stride_b=HW * 2 * C, stride_c=HW * HW)

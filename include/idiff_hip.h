@@ -46,7 +46,9 @@ const char *idiff_source_stamp(void);
  * stream beside the next panel's factorisation; 5 % at D = 12288 when the helper gets a hardware queue of its own, 50 %
  * SLOWER when the runtime maps it onto the caller's queue, which happens once a process has made a few streams),
  * IDIFF_NO_WINO43 (3x3 convolutions on the F(2x2,3x3) kernel instead of F(4x4,3x3)), IDIFF_NO_WINO43H (F(4x4,3x3) with its
- * contractions on the fp32 matrix cores instead of fp16 pairs).
+ * contractions on the fp32 matrix cores instead of fp16 pairs), IDIFF_NO_PAIRS (idiff_gemm_pairs_ok answers 0: the 1x1
+ * projections behind a GroupNorm stay on idiff_gemm_f32's six-product form), IDIFF_PAIRS_MIN_TILES (tests: the number of 128 x 128
+ * tiles from which idiff_gemm_pairs_ok answers 1; default 256).
  * Returns the previous value, -1 for an unknown name.  No reference counterpart. */
 int idiff_set_option(const char *name, int value);
 
@@ -142,6 +144,26 @@ typedef struct idiff_epilogue {
 int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt, int64_t ldb, int64_t strideB,
                    float *C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch,
                    const idiff_epilogue *ep, void *stream);
+
+/* The batched contraction of idiff_gemm_f32, C[b] = epilogue(A[b] (M x K) * Bt[b]^T (Bt is N x K)), with every fp32 operand element
+ * as a PAIR of fp16 values (hi = fp16(v), lo = fp16(v - hi): 22 significand bits) and a product as lo*hi + hi*lo + hi*hi on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation -- three matrix instructions where idiff_gemm_f32's exact bf16 cut needs six, and
+ * the matrix pipes are what that form runs out of (1.36-1.64x faster on the q / k / v projections of models/layerspp.py:66-98 at
+ * BASELINE sizes, scripts/gemm_pairs_probe.py).  fp16 has a 5-bit exponent, so the CALLER vouches for the ranges: one operand is an
+ * ACTIVATION, used as it is, and must be of order one -- |x| < 65504 (beyond: +-inf, the outputs NaN), and an element below 0.25
+ * carries an absolute error of 2^-25 instead of a relative 2^-22: the output of a GroupNorm is the intended operand; the other is
+ * a WEIGHT (Bt, or A when weight_is_a != 0 -- V^T = Wv n^T of the attention block), multiplied by w_scale[0], the power of two that
+ * idiff_gemm_pairs_scale_f32 computes once per weight (max |w| -> [2^11, 2^12)), the sums by w_scale[1] = 1 / w_scale[0], exactly.
+ * w_scale is a DEVICE pointer to those two floats.  Measured against an fp64 contraction of the same fp32 operands: 1.0e-7 where the
+ * six-product form gives 1.3e-7 (a GroupNorm's output x N(0, 1/K) weights; tests/test_hip_ops.py).  idiff_gemm_pairs_ok: 1 when the
+ * shape is served (N > 64, K % 4 == 0, at least 256 tiles of 128 x 128 over the batch; 0 under IDIFF_NO_PAIRS / IDIFF_NO_SPLIT /
+ * IDIFF_NO_PIPE).  Operands 16-byte aligned, row pitches and batch strides multiples of 4, one batch slice inside 4 GiB.  Same
+ * epilogue, same column-statistics layout as idiff_gemm_f32 (idiff_gemm_colstats_split; unbatched only). */
+int idiff_gemm_pairs_ok(int M, int N, int K, int batch);
+int idiff_gemm_pairs_scale_f32(const float *w, int64_t ldw, int rows, int K, float *w_scale, void *stream);
+int idiff_gemm_pairs_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt, int64_t ldb, int64_t strideB,
+                         const float *w_scale, int weight_is_a, float *C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch,
+                         const idiff_epilogue *ep, void *stream);
 
 /* The same contraction with A given as two row-major matrices of equal row pitch, A = [A1 (M x K1) | A2 (M x (K - K1))]:
  * the 1x1 shortcut of a residual block whose input is torch.cat([h, skip], dim=1) (models/ncsnpp.py:376-385 with

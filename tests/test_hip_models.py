@@ -388,7 +388,7 @@ def wino43_everywhere(monkeypatch):
     from id_diff_amd.models import ncsnpp as hip_ncsnpp
     monkeypatch.setattr(hip_ncsnpp, "WINO43_MIN_WORKGROUPS", 1)
     monkeypatch.setattr(hip_ncsnpp, "WINO43_PAIRS_MIN_WORKGROUPS", 1)
-    calls = {"n": 0, "pairs": 0}
+    calls = {"n": 0, "pairs": 0, "gemm_pairs": 0}
     orig = _lib.conv2d_winograd43
 
     def counted(*a, **k):
@@ -396,7 +396,16 @@ def wino43_everywhere(monkeypatch):
         calls["pairs"] += bool(k.get("pairs"))
         return orig(*a, **k)
     monkeypatch.setattr(_lib, "conv2d_winograd43", counted)
-    return calls
+    # ... and the attention blocks' projections of a GroupNorm's output through the fp16-pair GEMM (from 256 tiles on in production)
+    orig_gp = _lib.gemm_pairs
+
+    def counted_gp(*a, **k):
+        calls["gemm_pairs"] += 1
+        return orig_gp(*a, **k)
+    monkeypatch.setattr(_lib, "gemm_pairs", counted_gp)
+    prev = _lib.set_option("IDIFF_PAIRS_MIN_TILES", 1)
+    yield calls
+    _lib.set_option("IDIFF_PAIRS_MIN_TILES", prev)
 
 
 def test_wide_ncsnpp_golden_through_winograd43(golden, wino43_everywhere):
@@ -411,6 +420,7 @@ def test_wide_ncsnpp_golden_through_winograd43(golden, wino43_everywhere):
     raw = model(x, t * 999)
     assert wino43_everywhere["n"] >= 8, wino43_everywhere            # the 3x3 convs of the levels of 8x8 pixels and larger
     assert wino43_everywhere["pairs"] >= 8, wino43_everywhere        # ... all fed by a GroupNorm: contraction on fp16 pairs
+    assert wino43_everywhere["gemm_pairs"] >= 2, wino43_everywhere   # q|k and V^T of every attention block
     assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
     y = mutils.get_score_fn(sde_lib.VESDE(0.01, 50, 1000), model)(x, t)
     assert rel_err(y.cpu(), z["score"]) < NET_RTOL

@@ -167,6 +167,94 @@ def test_gemm_writes_only_its_block(M, N, K, grp):
     assert bool(torch.isnan(got[:M, N:]).all()) and bool(torch.isnan(got[M:]).all())
 
 
+@pytest.mark.parametrize("M,N,K,wscale", [(32768, 256, 256, 1 / 16), (40000, 512, 256, 3e-3), (33000, 128, 128, 40.0), (65536, 256, 32 * 9, 1.0)])
+def test_gemm_pairs_vs_cpu(M, N, K, wscale):
+    """idiff_gemm_pairs_f32 (fp16 pairs, three matrix instructions per block): operands as the executor hands them over -- A the
+    output of a GroupNorm + SiLU (order one, exact zeros, channels of very different gain), the weight of any magnitude (its
+    power-of-two scale comes from idiff_gemm_pairs_scale_f32); every epilogue term; M not a multiple of the tile; against fp64 of
+    the same fp32 operands, beside the six-product form on the same inputs."""
+    assert _lib.gemm_pairs_ok(M, N, K)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.logspace(-1.5, 0.5, K)[torch.randperm(K, generator=g)]
+    a = F.silu(F.group_norm(a.reshape(M // 8, 8, K).permute(0, 2, 1), 32, torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3))
+    a = a.permute(0, 2, 1).reshape(M, K).contiguous()
+    a[::7, ::5] = 0.0
+    w, b = torch.randn(N, K, generator=g) * wscale, torch.randn(N, generator=g)
+    grp = 100
+    ngrp = (M + grp - 1) // grp
+    rb, rsc = torch.randn(ngrp, N, generator=g), torch.rand(ngrp, generator=g) + 0.5
+    res = torch.randn(M, N, generator=g)
+    ad, wd = a.to(DEV), w.to(DEV)
+    sc = _lib.gemm_pairs_scale(wd)
+    s0, s1 = sc.cpu().tolist()
+    assert s0 * s1 == 1.0 and 2048 <= float(w.abs().max()) * s0 < 4096 and np.log2(s0) == round(np.log2(s0))
+    ep = _lib.make_epilogue(bias=b.to(DEV), rowbias=rb.to(DEV), rows_per_group=grp, act="silu", residual=res.to(DEV), out_scale=0.75,
+                            rowscale=rsc.to(DEV))
+    out = torch.full((M, N), float("nan"), device=DEV)
+    _lib.gemm_pairs(ad, wd, sc, out, epilogue=ep)
+    rows = torch.arange(M) // grp
+    lin = a.double() @ w.double().T
+    ref = (F.silu(lin + b.double() + rb.double()[rows]) + res.double()) * 0.75 * rsc.double()[rows][:, None]
+    six = _lib.gemm(ad, wd, epilogue=ep)
+    e_pairs, e_six = rel_err(out.cpu(), ref), rel_err(six.cpu(), ref)
+    assert e_pairs < 2e-6 and e_pairs < 3 * e_six + 1e-7, (e_pairs, e_six)
+    # the contraction alone, where no O(1) epilogue term hides its error
+    raw = torch.empty(M, N, device=DEV)
+    _lib.gemm_pairs(ad, wd, sc, raw)
+    assert rel_err(raw.cpu(), lin) < 5e-7
+    assert float((raw.cpu().double() - lin).abs().max()) < 1e-5 * float(lin.abs().max())
+
+
+def test_gemm_pairs_weight_on_the_left_batched():
+    """V^T[b] = Wv n[b]^T of an attention block: the weight is the LEFT operand (broadcast over the batch), the activation the
+    right one, one 256 x 256 x 256 contraction per image."""
+    g = torch.Generator().manual_seed(8)
+    B, HW, C = 70, 256, 256
+    assert _lib.gemm_pairs_ok(C, HW, C, B)
+    n = F.group_norm(torch.randn(B, C, HW, generator=g) * 3 + 1, 32).permute(0, 2, 1).contiguous()        # [B, HW, C]
+    wv = torch.randn(C, C, generator=g) * 0.02
+    nd, wd = n.to(DEV), wv.to(DEV)
+    vt = torch.full((B, C, HW), float("nan"), device=DEV)
+    _lib.gemm_weight_times_normed_t({}, wd, nd, vt, B, HW, C)
+    ref = torch.einsum("oc,bpc->bop", wv.double(), n.double())
+    assert rel_err(vt.cpu(), ref) < 5e-7
+    six = torch.empty_like(vt)
+    _lib.gemm(wd, nd, out=six, M=C, N=HW, K=C, lda=C, ldb=C, ldc=HW, batch=B, stride_a=0, stride_b=HW * C, stride_c=C * HW)
+    assert rel_err(vt.cpu(), ref) < 3 * rel_err(six.cpu(), ref) + 1e-7
+
+
+def test_gemm_pairs_limits_and_colstats():
+    """Beyond fp16's range the high half is +-inf and the outputs NaN (loud, as the fp16-pair convolution); shapes the form does not
+    serve are refused; epilogue.colstats has the 128-row tile layout of idiff_gemm_colstats_split."""
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 256 * 140, 256, 256
+    a = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / 16).to(DEV)
+    sc = _lib.gemm_pairs_scale(w)
+    out = torch.empty(M, N, device=DEV)
+    _lib.gemm_pairs(a * 1e5, w, sc, out)
+    assert bool(torch.isnan(out).any())
+    _lib.gemm_pairs(a * 300, w, sc, out)
+    assert bool(torch.isfinite(out).all())
+    assert not _lib.gemm_pairs_ok(1000, 256, 256) and not _lib.gemm_pairs_ok(M, 64, 256) and not _lib.gemm_pairs_ok(M, 256, 30)
+    assert _lib.gemm_pairs_ok(256, 256, 256, 64) and not _lib.gemm_pairs_ok(256, 256, 256, 63)
+    with pytest.raises(RuntimeError, match="not served"):
+        _lib.gemm_pairs(a[:1000], w, sc, out[:1000])
+    prev = _lib.set_option("IDIFF_NO_PAIRS", 1)
+    try:
+        assert not _lib.gemm_pairs_ok(M, N, K)
+    finally:
+        _lib.set_option("IDIFF_NO_PAIRS", prev)
+    HW = 256
+    ns = _lib.gemm_colstats_split(M, N, K, K, K, HW)
+    assert ns == 2
+    cs = torch.full((M // HW * ns * N * 2,), float("nan"), device=DEV, dtype=torch.float64)
+    _lib.gemm_pairs(a, w, sc, out, epilogue=_lib.make_epilogue(bias=torch.randn(N, generator=g).to(DEV), rows_per_group=HW, colstats=cs))
+    ref = out.double().reshape(M // HW, ns, 128, N)
+    np.testing.assert_allclose(cs.view(M // HW, ns, N, 2)[..., 0].cpu().numpy(), ref.sum(2).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(cs.view(M // HW, ns, N, 2)[..., 1].cpu().numpy(), (ref * ref).sum(2).cpu().numpy(), rtol=1e-12, atol=1e-9)
+
+
 def test_gemm_batched_strided():
     g = torch.Generator().manual_seed(6)
     B, HW, C = 3, 64, 16
