@@ -56,7 +56,7 @@ _CONV_ARITH = ("3x3 convs: Winograd F(4x4,3x3), fp32 transforms, fp32 MFMA contr
                else "3x3 convs: Winograd F(4x4,3x3), fp32 transforms, contraction on pairs of fp16 values -- 22 significand bits, 3 products, fp32 accumulate")
 _GEMM_ARITH = ("1x1/attention/dense contractions: fp32 MFMA" if os.environ.get("IDIFF_NO_SPLIT")
                else "1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate"
-               + ("" if os.environ.get("IDIFF_NO_PAIRS") else "; the q/k/v projections of a GroupNorm's output: pairs of fp16 values, 3 products"))
+               + ("" if os.environ.get("IDIFF_NO_PAIRS") else "; the attention projections of a GroupNorm's output and the shortcut contractions (power-of-two rms scale): pairs of fp16 values, 3 products"))
 DTYPE = f"f32 ({_CONV_ARITH}; {_GEMM_ARITH})"
 WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=1e-5, B=128 -> S 4480x3072 + centred spectrum + ID"
 # PMC traffic tables (separate FETCH_SIZE / WRITE_SIZE passes, scripts/profile_round.sh), each stamped with the sha256 of the kernel
@@ -81,6 +81,9 @@ def source_sha256(rels):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
+
+
+PAIRS_GEMM = "igemm_pipe_kernel on fp16 pairs (attention projections of a GroupNorm's output; shortcut contractions with an rms scale)"
 
 
 class KernelProbe:
@@ -143,12 +146,17 @@ class KernelProbe:
             group = "igemm_pipe_kernel K<=128 (1x1 / NIN)" if K <= 128 else "igemm_pipe_kernel K>=256 (1x1 / NIN / attention products)"
             return group, (2.0 * batch * M * N * K, 4.0 * batch * (M * K + N * K + M * N) + res), f"{M}x{N}x{K}"
 
+        def gemm_pairs_2src(a1, a2, act_scale, bt, w_scale, out, epilogue=None):
+            M, K1 = a1.shape
+            K, N = K1 + a2.shape[1], bt.shape[0]
+            return PAIRS_GEMM, (2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)), f"2src {M}x{N}x{K}"
+
         def gemm_pairs(a, bt, w_scale, out, epilogue=None, weight_is_a=False, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
-                       batch=1, stride_a=0, stride_b=0, stride_c=0):
+                       batch=1, stride_a=0, stride_b=0, stride_c=0, act_scale=None):
             if M is None:
                 M, K = a.shape
                 N = bt.shape[0]
-            return ("igemm_pipe_kernel on fp16 pairs (q / k / v projections of a GroupNorm's output)",
+            return (PAIRS_GEMM,
                     (2.0 * batch * M * N * K, 4.0 * (batch * (M * N + (N * K if weight_is_a else M * K)) + (M * K if weight_is_a else N * K))), f"{M}x{N}x{K}")
 
         def gemm_2src(a1, a2, bt, out, epilogue=None):
@@ -164,7 +172,7 @@ class KernelProbe:
             return "softmax_rows", 8.0 * rows * cols, f"{rows}x{cols}"
 
         for name, fn in (("conv2d_winograd", wino), ("conv2d_winograd43", wino43), ("groupnorm_apply", gn_apply), ("groupnorm_apply_colstats", gn_apply_cs),
-                         ("gemm", gemm), ("gemm_2src", gemm_2src), ("gemm_pairs", gemm_pairs),
+                         ("gemm", gemm), ("gemm_2src", gemm_2src), ("gemm_pairs", gemm_pairs), ("gemm_pairs_2src", gemm_pairs_2src),
                          ("upfirdn2d_raw", ufd), ("softmax_rows", softmax)):
             self._wrap(name, fn)
 
@@ -236,7 +244,6 @@ def roofline_report(probe):
         kernels.append({"kernel": "winograd_kernel (F(2x2,3x3): the 4x4 maps and launches too small for the 4x4 form)", "bound": "mfma",
                         "achieved": t22, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": t22 / FP32_MFMA_PEAK_TFLOPS,
                         "launches_sampled": dom22["launches"], "avg_launch_us": dom22["avg_us"]})
-    PAIRS_GEMM = "igemm_pipe_kernel on fp16 pairs (q / k / v projections of a GroupNorm's output)"
     for name in ("gn_apply_rows", "igemm_pipe_kernel K<=128 (1x1 / NIN)", "igemm_pipe_kernel K>=256 (1x1 / NIN / attention products)",
                  "igemm_pipe_kernel two-source shortcut", PAIRS_GEMM, "upfirdn2d_nhwc", "softmax_rows"):
         g = probe.group(name)

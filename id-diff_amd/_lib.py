@@ -34,7 +34,9 @@ _SIGNATURES = {
     "idiff_set_option": (c_i, [ctypes.c_char_p, c_i]),
     "idiff_gemm_pairs_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "idiff_gemm_pairs_scale_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
-    "idiff_gemm_pairs_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "idiff_gemm_pairs_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "idiff_pairs_act_scale_f32": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "idiff_gemm_pairs_2src_f32": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i64, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
     "idiff_set_thread_option": (c_i, [ctypes.c_char_p, c_i, c_i]),
     "idiff_upfirdn2d_f32": (c_i, [c_p, c_p, c_p] + [c_i] * 14 + [c_p]),
     "idiff_fused_bias_act_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
@@ -311,7 +313,7 @@ def gemm_pairs_scale(w):
 
 
 def gemm_pairs(a, bt, w_scale, out, epilogue=None, weight_is_a=False, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
-               batch=1, stride_a=0, stride_b=0, stride_c=0):
+               batch=1, stride_a=0, stride_b=0, stride_c=0, act_scale=None):
     """out[b] = epilogue(a[b] @ bt[b].T) on fp16 pairs (three matrix instructions per block instead of six).  One operand is a
     weight -- ``bt``, or ``a`` with ``weight_is_a`` -- whose ``w_scale`` comes from gemm_pairs_scale; the other an activation of
     order one (a GroupNorm's output): see idiff_gemm_pairs_f32.  2-D tensors by default, explicit geometry for batched views."""
@@ -326,7 +328,32 @@ def gemm_pairs(a, bt, w_scale, out, epilogue=None, weight_is_a=False, M=None, N=
         lda, ldb, ldc = a.stride(0), bt.stride(0), out.stride(0)
     ep = ctypes.byref(epilogue) if epilogue is not None else None
     _check(lib().idiff_gemm_pairs_f32(a.data_ptr(), lda, stride_a, bt.data_ptr(), ldb, stride_b, w_scale.data_ptr(), int(bool(weight_is_a)),
-                                      out.data_ptr(), ldc, stride_c, M, N, K, batch, ep, _stream()), "idiff_gemm_pairs_f32")
+                                      _ptr(act_scale), out.data_ptr(), ldc, stride_c, M, N, K, batch, ep, _stream()), "idiff_gemm_pairs_f32")
+    return out
+
+
+def pairs_act_scale(stats1, C1, stats2, C2, B, HW):
+    """Device tensor whose first two floats are {s, 1 / s}, s the power of two that brings the root mean square of a tensor (or of
+    cat[x1, x2]) into [0.71, 1.41), from the column sums ``stats = (ws, nsplit)`` its producing contraction(s) wrote."""
+    out = torch.empty(8, device=stats1[0].device, dtype=torch.float32)
+    _check(lib().idiff_pairs_act_scale_f32(stats1[0].data_ptr(), stats1[1], C1, _ptr(stats2[0]) if stats2 is not None else None,
+                                           stats2[1] if stats2 is not None else 0, C2, B, HW, out.data_ptr(), _stream()),
+           "idiff_pairs_act_scale_f32")
+    return out
+
+
+def gemm_pairs_2src(a1, a2, act_scale, bt, w_scale, out, epilogue=None):
+    """out = epilogue([a1 | a2] @ bt.T) on fp16 pairs; ``act_scale`` from pairs_act_scale over both sources, ``w_scale`` from
+    gemm_pairs_scale(bt)."""
+    _dev(a1, "a1"); _dev(a2, "a2"); _dev(bt, "bt"); _dev(out, "out"); _dev(act_scale, "act_scale"); _dev(w_scale, "w_scale")
+    M, K1 = a1.shape
+    K = K1 + a2.shape[1]
+    if a2.shape[0] != M or a1.stride(0) != a2.stride(0) or bt.shape[1] != K:
+        raise RuntimeError(f"gemm_pairs_2src: shapes {tuple(a1.shape)} | {tuple(a2.shape)} x {tuple(bt.shape)}^T")
+    ep = ctypes.byref(epilogue) if epilogue is not None else None
+    _check(lib().idiff_gemm_pairs_2src_f32(a1.data_ptr(), a2.data_ptr(), a1.stride(0), K1, act_scale.data_ptr(), bt.data_ptr(), bt.stride(0),
+                                           w_scale.data_ptr(), out.data_ptr(), out.stride(0), M, bt.shape[0], K, ep, _stream()),
+           "idiff_gemm_pairs_2src_f32")
     return out
 
 

@@ -54,8 +54,8 @@ struct IgemmParams {
   uint32_t a2_bytes;
   uint32_t c_bytes, res_bytes;  // extents of one batch slice of C and of the residual; buf_ep = they fit a buffer descriptor
   int buf_ep;
-  const float *pair_scale;      // fp16-pair form: device pointer to {s, 1 / s}, s the power of two the WEIGHT operand is multiplied by
-  int pair_on_a;                //   before its cut: Bt, or A when pair_on_a (the weight is the left operand: V^T = Wv n^T)
+  const float *scale_a, *scale_b;   // fp16-pair form: device pointers to {s, 1 / s}, the power of two A / Bt is multiplied by before
+                                    // its cut (NULL: 1); the sums are multiplied by the product of the inverses
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -485,8 +485,7 @@ igemm_pipe_kernel(const IgemmParams p) {
   // ROW_STEP is a multiple of 16, so the swizzle of a thread's rows is one constant
   static_assert(ROW_STEP % 16 == 0 && BM % 32 == 0 && BN % 32 == 0, "split-plane swizzle");
   const int kc_sw = (((kc >> 3) ^ split_swz(row_base)) << 3) + (kc & 7);
-  const float pair_w = SPLIT == 2 ? p.pair_scale[0] : 1.f;
-  const float pair_sa = (SPLIT == 2 && p.pair_on_a) ? pair_w : 1.f, pair_s = (SPLIT == 2 && !p.pair_on_a) ? pair_w : 1.f;
+  const float pair_sa = (SPLIT == 2 && p.scale_a) ? p.scale_a[0] : 1.f, pair_s = (SPLIT == 2 && p.scale_b) ? p.scale_b[0] : 1.f;
   auto stage = [&](int buf) {
     if (SPLIT == 2) {
       unsigned short *a_dst = As16, *b_dst = Bs16;
@@ -690,7 +689,7 @@ igemm_pipe_kernel(const IgemmParams p) {
 #endif
 
   if (SPLIT == 2) {
-    const float inv = p.pair_scale[1];               // a power of two: exact
+    const float inv = (p.scale_a ? p.scale_a[1] : 1.f) * (p.scale_b ? p.scale_b[1] : 1.f);    // powers of two: exact
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1139,8 +1138,8 @@ IDIFF_API int idiff_gemm_pairs_scale_f32(const float *Bt, int64_t ldb, int N, in
 }
 
 IDIFF_API int idiff_gemm_pairs_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt, int64_t ldb, int64_t strideB,
-                                   const float *w_scale, int weight_is_a, float *C, int64_t ldc, int64_t strideC, int M, int N, int K,
-                                   int batch, const idiff_epilogue *ep, void *stream) {
+                                   const float *w_scale, int weight_is_a, const float *act_scale, float *C, int64_t ldc, int64_t strideC,
+                                   int M, int N, int K, int batch, const idiff_epilogue *ep, void *stream) {
   using namespace idiff;
   if (M < 0 || N < 0 || K <= 0 || batch < 0) return fail("gemm_pairs: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   if (M == 0 || N == 0 || batch == 0) return 0;
@@ -1156,9 +1155,84 @@ IDIFF_API int idiff_gemm_pairs_f32(const float *A, int64_t lda, int64_t strideA,
   IgemmParams p = {};
   p.A = A; p.Bt = Bt; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
   p.strideA = strideA; p.strideB = strideB; p.strideC = strideC;
-  p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes; p.pair_scale = w_scale; p.pair_on_a = weight_is_a ? 1 : 0;
+  p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
+  p.scale_a = weight_is_a ? w_scale : act_scale; p.scale_b = weight_is_a ? act_scale : w_scale;
   fill_epilogue(p, ep);
   return launch_pipe<128, 128, 2, 2, false, false, 2>(p, batch, (hipStream_t)stream);
+}
+
+IDIFF_API int idiff_gemm_pairs_2src_f32(const float *A1, const float *A2, int64_t lda, int K1, const float *act_scale, const float *Bt,
+                                        int64_t ldb, const float *w_scale, float *C, int64_t ldc, int M, int N, int K,
+                                        const idiff_epilogue *ep, void *stream) {
+  using namespace idiff;
+  if (M < 0 || N < 0 || K <= 0 || K1 <= 0 || K1 >= K) return fail("gemm_pairs_2src: bad sizes M=%d N=%d K=%d K1=%d", M, N, K, K1);
+  if (M == 0 || N == 0) return 0;
+  if (!A1 || !A2 || !Bt || !C || !w_scale) return fail("gemm_pairs_2src: null pointer");
+  if (K1 % BK) return fail("gemm_pairs_2src: the split column K1 = %d must be a multiple of %d", K1, BK);
+  if (lda < K1 || lda < K - K1 || ldb < K || ldc < N) return fail("gemm_pairs_2src: leading dimension smaller than the row length");
+  if (!pairs_geometry_ok(M, N, K, 1)) return fail("gemm_pairs_2src: M=%d N=%d K=%d not served (ask idiff_gemm_pairs_ok)", M, N, K);
+  const int64_t a1_bytes = ((int64_t)(M - 1) * lda + K1) * 4, a2_bytes = ((int64_t)(M - 1) * lda + (K - K1)) * 4;
+  const int64_t b_bytes = ((int64_t)(N - 1) * ldb + K) * 4;
+  const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A1) && aligned16(A2) && aligned16(Bt);
+  if (!vec || a1_bytes >= BUF_LIMIT || a2_bytes >= BUF_LIMIT || b_bytes >= BUF_LIMIT)
+    return fail("gemm_pairs_2src: operands must be 16-byte aligned with row pitches that are multiples of 4 and lie inside 4 GiB");
+  IgemmParams p = {};
+  p.A = A1; p.A2 = A2; p.K1 = K1; p.Bt = Bt; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.a_bytes = (uint32_t)a1_bytes; p.a2_bytes = (uint32_t)a2_bytes; p.b_bytes = (uint32_t)b_bytes;
+  p.scale_a = act_scale; p.scale_b = w_scale;
+  fill_epilogue(p, ep);
+  return launch_pipe<128, 128, 2, 2, false, false, 2>(p, 1, (hipStream_t)stream);
+}
+
+namespace {
+// {s, 1 / s} with s the power of two nearest to 1 / rms of the tensor(s) whose per-tile column sums (sum, sum of squares; fp64)
+// the producing contractions wrote: out = [s, 1 / s, <fp64 accumulator>, <block counter>] (8 floats, zeroed by the launcher)
+__global__ void __launch_bounds__(256) pairs_act_scale_kernel(const double *__restrict__ ws1, int64_t n1, const double *__restrict__ ws2,
+                                                              int64_t n2, double count, float *__restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n1; i += stride) acc += ws1[2 * i + 1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) acc += ws2[2 * i + 1];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double *total = reinterpret_cast<double *>(out + 2);
+    unsigned int *done = reinterpret_cast<unsigned int *>(out + 4);
+    atomicAdd(total, red[0]);
+    __threadfence();
+    if (atomicAdd(done, 1u) == gridDim.x - 1) {
+      __threadfence();
+      const double ms = *reinterpret_cast<volatile double *>(total) / count;      // mean square
+      int sh = 0;
+      if (ms > 0.0 && ms < 1e300) {
+        int e = 0;
+        (void)frexp(sqrt(ms), &e);                  // rms = f * 2^e, f in [0.5, 1): rms * 2^-e in [0.5, 1), * 2^(1-e) in [1, 2)
+        sh = -e + ((sqrt(ms) * ldexp(1.0, -e) < 0.70710678118654752) ? 1 : 0);   // rms * 2^sh in [0.707, 1.414)
+      }
+      out[0] = ldexpf(1.f, sh);
+      out[1] = ldexpf(1.f, -sh);
+    }
+  }
+}
+}  // namespace
+
+IDIFF_API int idiff_pairs_act_scale_f32(const double *ws1, int nsplit1, int C1, const double *ws2, int nsplit2, int C2, int B, int HW,
+                                        float *out, void *stream) {
+  using namespace idiff;
+  if (!ws1 || !out || nsplit1 <= 0 || C1 <= 0 || B <= 0 || HW <= 0 || (ws2 && (nsplit2 <= 0 || C2 <= 0)))
+    return fail("pairs_act_scale: bad arguments");
+  const int64_t n1 = (int64_t)B * nsplit1 * C1, n2 = ws2 ? (int64_t)B * nsplit2 * C2 : 0;
+  hipError_t e = hipMemsetAsync(out, 0, 32, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("pairs_act_scale: hipMemsetAsync: %s", hipGetErrorString(e));
+  const int blocks = (int)std::min<int64_t>(512, (n1 + n2 + 255) / 256);
+  hipLaunchKernelGGL(pairs_act_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws1, n1, ws2, n2,
+                     (double)B * HW * (C1 + (ws2 ? C2 : 0)), out);
+  return launch_status("pairs_act_scale");
 }
 
 IDIFF_API int idiff_gemm_2src_f32(const float *A1, const float *A2, int64_t lda, int K1, const float *Bt, int64_t ldb,

@@ -162,8 +162,21 @@ int idiff_gemm_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt
 int idiff_gemm_pairs_ok(int M, int N, int K, int batch);
 int idiff_gemm_pairs_scale_f32(const float *w, int64_t ldw, int rows, int K, float *w_scale, void *stream);
 int idiff_gemm_pairs_f32(const float *A, int64_t lda, int64_t strideA, const float *Bt, int64_t ldb, int64_t strideB,
-                         const float *w_scale, int weight_is_a, float *C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch,
-                         const idiff_epilogue *ep, void *stream);
+                         const float *w_scale, int weight_is_a, const float *act_scale, float *C, int64_t ldc, int64_t strideC,
+                         int M, int N, int K, int batch, const idiff_epilogue *ep, void *stream);
+
+/* The activation operand of the pair form when it is NOT a GroupNorm's output: act_scale (NULL above = 1) is a device pointer to
+ * {s, 1 / s}, s the power of two the activation is multiplied by before its cut, so that its ROOT MEAN SQUARE lands in [0.71, 1.41):
+ * the pair then carries 22 bits relative to the tensor's own scale whatever that scale is (elements below rms / 4: absolute error
+ * 2^-25 rms), and the range bound becomes max |x| < 65504 rms.  idiff_pairs_act_scale_f32 derives it on the device from the per-tile
+ * column sums (sum, sum of squares) that the contraction(s) producing the tensor -- or the two tensors of a concatenation -- left for
+ * the GroupNorm that reads them as well (idiff_epilogue.colstats: [B, nsplit, C, 2] fp64); `out`: 8 floats, {s, 1 / s} in front.
+ * idiff_gemm_pairs_2src_f32: the two-source contraction of idiff_gemm_2src_f32 ([A1 | A2], the shortcut of a residual block on
+ * torch.cat([h, skip]), models/ncsnpp.py:376-385) on pairs, one act_scale for both sources.  K1 % 32 == 0. */
+int idiff_pairs_act_scale_f32(const double *ws1, int nsplit1, int C1, const double *ws2, int nsplit2, int C2, int B, int HW, float *out,
+                              void *stream);
+int idiff_gemm_pairs_2src_f32(const float *A1, const float *A2, int64_t lda, int K1, const float *act_scale, const float *Bt, int64_t ldb,
+                              const float *w_scale, float *C, int64_t ldc, int M, int N, int K, const idiff_epilogue *ep, void *stream);
 
 /* The same contraction with A given as two row-major matrices of equal row pitch, A = [A1 (M x K1) | A2 (M x (K - K1))]:
  * the 1x1 shortcut of a residual block whose input is torch.cat([h, skip], dim=1) (models/ncsnpp.py:376-385 with

@@ -223,6 +223,46 @@ def test_gemm_pairs_weight_on_the_left_batched():
     assert rel_err(vt.cpu(), ref) < 3 * rel_err(six.cpu(), ref) + 1e-7
 
 
+@pytest.mark.parametrize("mag", [1e-4, 1.0, 3e3])
+def test_gemm_pairs_with_activation_scale_two_sources(mag):
+    """Operands that are NOT a GroupNorm's output (the residual stream of a U-Net block and its skip connection) at any magnitude:
+    the power-of-two scale that idiff_pairs_act_scale_f32 derives from the producers' column sums brings the root mean square of
+    cat[x1, x2] to about one, and the pair form keeps 22 bits relative to that scale -- one-source and two-source contraction."""
+    g = torch.Generator().manual_seed(5)
+    B, HW, C1, C2, N = 160, 256, 128, 128, 256
+    M = B * HW
+    x1 = (torch.randn(M, C1, generator=g) * mag).to(DEV)
+    x2 = (torch.randn(M, C2, generator=g) * mag * 0.3 + 0.1 * mag).to(DEV)
+    w = (torch.randn(N, C1 + C2, generator=g) / 16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV) * mag
+
+    def colsums(x, C):          # what a producing contraction's epilogue leaves: [B, nsplit, C, 2] fp64 per 128-row tile
+        t = x.double().reshape(B, HW // 128, 128, C)
+        return (torch.stack([t.sum(2), (t * t).sum(2)], -1).contiguous().reshape(-1), HW // 128)
+    st1, st2 = colsums(x1, C1), colsums(x2, C2)
+    act = _lib.pairs_act_scale(st1, C1, st2, C2, B, HW)
+    s0, s1 = act[:2].cpu().tolist()
+    rms = float(torch.cat([x1, x2], 1).double().pow(2).mean().sqrt())
+    assert s0 * s1 == 1.0 and np.log2(s0) == round(np.log2(s0)) and 0.70 < rms * s0 < 1.42, (s0, rms)
+    wsc = _lib.gemm_pairs_scale(w)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    _lib.gemm_pairs_2src(x1, x2, act, w, wsc, out, epilogue=_lib.make_epilogue(bias=bias))
+    ref = torch.cat([x1, x2], 1).double().cpu() @ w.double().cpu().T + bias.double().cpu()
+    six = torch.empty(M, N, device=DEV)
+    _lib.gemm_2src(x1, x2, w, six, epilogue=_lib.make_epilogue(bias=bias))
+    e3, e6 = rel_err(out.cpu(), ref), rel_err(six.cpu(), ref)
+    assert e3 < 5e-7 and e3 < 3 * e6 + 1e-7, (e3, e6)
+    # one source
+    act1 = _lib.pairs_act_scale(st1, C1, None, 0, B, HW)
+    w1 = w[:, :C1].contiguous()
+    o1 = torch.empty(M, N, device=DEV)
+    _lib.gemm_pairs(x1, w1, _lib.gemm_pairs_scale(w1), o1, act_scale=act1)
+    assert rel_err(o1.cpu(), x1.double().cpu() @ w1.double().cpu().T) < 5e-7
+    if mag == 1.0:
+        zero = (torch.zeros(B * 2 * C1 * 2, dtype=torch.float64, device=DEV), 2)
+        assert _lib.pairs_act_scale(zero, C1, None, 0, B, HW)[:2].cpu().tolist() == [1.0, 1.0]      # an all-zero tensor: scale 1
+
+
 def test_gemm_pairs_limits_and_colstats():
     """Beyond fp16's range the high half is +-inf and the outputs NaN (loud, as the fp16-pair convolution); shapes the form does not
     serve are refused; epilogue.colstats has the 128-row tile layout of idiff_gemm_colstats_split."""
