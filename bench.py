@@ -56,7 +56,7 @@ _CONV_ARITH = ("3x3 convs: Winograd F(4x4,3x3), fp32 transforms, fp32 MFMA contr
                else "3x3 convs: Winograd F(4x4,3x3), fp32 transforms, contraction on pairs of fp16 values -- 22 significand bits, 3 products, fp32 accumulate")
 _GEMM_ARITH = ("1x1/attention/dense contractions: fp32 MFMA" if os.environ.get("IDIFF_NO_SPLIT")
                else "1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate"
-               + ("" if os.environ.get("IDIFF_NO_PAIRS") else "; the attention projections of a GroupNorm's output and the shortcut contractions (power-of-two rms scale): pairs of fp16 values, 3 products"))
+               + ("" if os.environ.get("IDIFF_NO_PAIRS") else "; the q/k/v projections of a GroupNorm's output: pairs of fp16 values, 3 products"))
 DTYPE = f"f32 ({_CONV_ARITH}; {_GEMM_ARITH})"
 WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=1e-5, B=128 -> S 4480x3072 + centred spectrum + ID"
 # PMC traffic tables (separate FETCH_SIZE / WRITE_SIZE passes, scripts/profile_round.sh), each stamped with the sha256 of the kernel
@@ -83,7 +83,7 @@ def source_sha256(rels):
     return h.hexdigest()
 
 
-PAIRS_GEMM = "igemm_pipe_kernel on fp16 pairs (attention projections of a GroupNorm's output; shortcut contractions with an rms scale)"
+PAIRS_GEMM = "igemm_pipe_kernel on fp16 pairs (q / k / v projections of a GroupNorm's output)"
 
 
 class KernelProbe:
