@@ -2,8 +2,10 @@
 
 Key values of /root/reference/configs/dimension_estimation/extra_experiments/styleGAN/style_gan_base.py:22-95,
 style_gan_BeatGAN.py:19-82 and style_gan_64d_BeatGAN.py:18-24.  The authors' ``gan_64d_train.npy`` is not in the
-repository (GanDataset.py:19), so ``data.npy_path`` is None and the ``Gan`` data module synthesises 64x64 images
-from a fixed smooth decoder of 64-dimensional latents; set ``data.npy_path`` to use the real file.
+repository (GanDataset.py:19), so THIS config sets ``data.synthetic = True`` and the ``Gan`` data module generates 64x64
+images from a fixed smooth decoder of 64-dimensional latents.  With the real file: set ``data.synthetic = False`` and
+``data.data_path`` (the reference's keys ``data_path`` / ``style_gan`` / ``latent_dim`` are honoured as in GanDataset.py:14-22;
+a missing file raises).
 """
 from ....default import get_default_configs
 from ....config_dict import ConfigDict
@@ -19,7 +21,7 @@ def get_config():
     training.sde = 'vesde'
     training.continuous = True
     config.validation.batch_size = 256
-    config.data = ConfigDict(datamodule='Gan', dataset='style_gan', npy_path=None, data_samples=64, latent_dim=latent_dim,
+    config.data = ConfigDict(datamodule='Gan', dataset='style_gan', synthetic=True, data_path=None, style_gan=True, data_samples=64, latent_dim=latent_dim,
                              data_seed=0, split=[0.8, 0.1, 0.1], image_size=64, effective_image_size=64,
                              shape=[3, 64, 64], centered=False, num_channels=3, use_data_mean=False,
                              return_labels=False)

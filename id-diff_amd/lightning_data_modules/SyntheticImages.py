@@ -2,7 +2,7 @@
 network): the reference's ``image`` / ``Gan`` data modules (ImageDatasets.py:10-61, GanDataset.py:9-29) read
 MNIST folders / the authors' StyleGAN ``.npy``; here images are a fixed random smooth decoder applied to
 latents z in R^latent_dim, float32 in [0, 1], shape ``config.data.shape`` -- an image manifold of known
-intrinsic dimension <= latent_dim.  ``Gan`` also accepts a real ``.npy`` via ``data.npy_path``.
+intrinsic dimension <= latent_dim.  (The ``Gan`` data module of the reference lives in GanDataset.py.)
 """
 import numpy as np
 import torch
@@ -48,30 +48,3 @@ class SyntheticImageDataset(Dataset):
 class SyntheticImageDataModule(utils.SplitDataModule):
     def make_dataset(self):
         return SyntheticImageDataset(self.config)
-
-
-class NpyImageDataset(Dataset):
-    """GanDataset.py:17-22: images stored as one ``.npy`` [N, H, W, C] uint8 or [N, C, H, W] float."""
-
-    def __init__(self, path):
-        arr = np.load(path, mmap_mode="r")
-        self.arr = arr
-
-    def __getitem__(self, index):
-        a = np.asarray(self.arr[index])
-        t = torch.from_numpy(a.copy())
-        if t.dtype == torch.uint8:
-            t = t.float() / 255.0
-        if t.ndim == 3 and t.shape[-1] in (1, 3):
-            t = t.permute(2, 0, 1)
-        return t.float().contiguous()
-
-    def __len__(self):
-        return len(self.arr)
-
-
-@utils.register_lightning_datamodule(name='Gan')
-class GanDataModule(utils.SplitDataModule):
-    def make_dataset(self):
-        path = self.config.data.get('npy_path', None)
-        return NpyImageDataset(path) if path else SyntheticImageDataset(self.config)

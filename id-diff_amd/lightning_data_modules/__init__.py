@@ -1,2 +1,2 @@
 from . import utils  # noqa: F401
-from . import KSphereDataset, SyntheticImages, ImageDatasets  # noqa: F401
+from . import KSphereDataset, SyntheticImages, ImageDatasets, GanDataset  # noqa: F401

@@ -260,6 +260,59 @@ def test_image_folder_datamodule(tmp_path):
         dutils.create_lightning_datamodule(cfg).setup()
 
 
+def test_gan_datamodule_reads_the_reference_files(tmp_path):
+    """The 'Gan' data module = GanDataset.py:9-68: `data.data_path` / `data.latent_dim` / `data.style_gan` name the file
+    (style_gan_horvat/gan_<d>d_train.npy, or latent_dim_<d>/data.pt), the tensors come back as stored, the split is
+    int(s0*l) / int(s1*l) / rest, and a missing file RAISES -- generated images only on the explicit `data.synthetic = True`."""
+    from id_diff_amd.lightning_data_modules import utils as dutils
+    from id_diff_amd.lightning_data_modules.GanDataset import GanDataset
+    rng = np.random.default_rng(0)
+    arr = rng.random((21, 3, 8, 8))                                  # float64 on disk: `.float()` as GanDataset.py:20
+    (tmp_path / 'style_gan_horvat').mkdir()
+    np.save(tmp_path / 'style_gan_horvat' / 'gan_7d_train.npy', arr)
+    pt = torch.randn(10, 3, 8, 8)
+    (tmp_path / 'latent_dim_7').mkdir()
+    torch.save(pt, tmp_path / 'latent_dim_7' / 'data.pt')
+    # the key set of the authors' config (configs/.../styleGAN/style_gan_base.py:78-95)
+    cfg = ConfigDict(data=ConfigDict(datamodule='Gan', data_path=str(tmp_path), latent_dim=7, style_gan=True, split=[0.95, 0.05, 0.0],
+                                     shape=[3, 8, 8], image_size=8, centered=False, num_channels=3),
+                     training=ConfigDict(batch_size=4, workers=4), validation=ConfigDict(batch_size=2, workers=4),
+                     eval=ConfigDict(batch_size=2, workers=4))
+    ds = GanDataset(cfg)
+    assert len(ds) == 21 and ds[3].dtype == torch.float32
+    np.testing.assert_array_equal(ds[3].numpy(), arr[3].astype(np.float32))
+    torch.manual_seed(5)
+    dm = dutils.create_lightning_datamodule(cfg)
+    assert type(dm).__name__ == 'SyntheticDataModule'                # the reference's class name for this module
+    dm.setup()
+    assert (len(dm.train_data), len(dm.valid_data), len(dm.test_data)) == (19, 1, 1)   # int(.95*21), int(.05*21), the rest
+    torch.manual_seed(5)
+    ref_train = torch.utils.data.random_split(ds, [19, 1, 1])[0]     # same generator state -> same permutation as the reference's call
+    assert list(dm.train_data.indices) == list(ref_train.indices)
+    assert next(iter(dm.train_dataloader())).shape == (4, 3, 8, 8)
+    cfg.data.style_gan = False
+    ds_pt = GanDataset(cfg)
+    assert len(ds_pt) == 10 and torch.equal(ds_pt[2], pt[2])
+    cfg.data.latent_dim = 64                                         # style_gan_64d_BeatGAN.py:18 -- the file is not there
+    for flag in (True, False):
+        cfg.data.style_gan = flag
+        with pytest.raises(FileNotFoundError, match="gan_64d_train.npy" if flag else "latent_dim_64/data.pt"):
+            dutils.create_lightning_datamodule(cfg).setup()
+    del cfg.data['style_gan']
+    with pytest.raises(AttributeError, match="style_gan"):
+        dutils.create_lightning_datamodule(cfg).setup()
+    # this repo's own config 5 asks for generated images explicitly; an authors' config never carries that key
+    own = read_config('configs/dimension_estimation/extra_experiments/styleGAN/style_gan_64d_BeatGAN.py')
+    assert own.data.synthetic is True and own.data.datamodule == 'Gan'
+    own.data.data_samples = 10
+    dm = dutils.create_lightning_datamodule(own)
+    dm.setup()
+    assert dm.dataset[0].shape == (3, 64, 64)
+    own.data.synthetic = False                                       # ... and without it the reference's contract holds
+    with pytest.raises(FileNotFoundError, match="data_path"):
+        dutils.create_lightning_datamodule(own).setup()
+
+
 def test_lightning_checkpoint_round_trip(tmp_path, monkeypatch):
     """A checkpoint shaped the way Lightning writes the reference's (BaseSdeGenerativeModel.py:17 save_hyperparameters:
     `score_model.*` keys + a pickled ml_collections.ConfigDict) loads with strict=True although neither ml_collections nor
