@@ -357,12 +357,12 @@ def gemm_pairs_2src(a1, a2, act_scale, bt, w_scale, out, epilogue=None):
     return out
 
 
-def gemm_normed(cache, a, w, out, epilogue=None):
+def gemm_normed(cache, a, w, out, epilogue=None, pairs=True):
     """out = epilogue(a @ w.T) for ``a`` [M, K] = the output of a GroupNorm (order one by construction) and a weight ``w`` [N, K]:
     on fp16 pairs where that form serves the shape, else on gemm's six bf16 products.  ``cache``: a dict that lives as long as
     the weights (the executor's pack), holding each weight's power-of-two scale."""
     M, K = a.shape
-    if not gemm_pairs_ok(M, w.shape[0], K):
+    if not pairs or not gemm_pairs_ok(M, w.shape[0], K):     # `pairs`: the caller's range verdict (models/base.py: pairs_admissible)
         return gemm(a, w, out=out, epilogue=epilogue)
     return gemm_pairs(a, w, _pairs_scale_of(cache, w), out, epilogue=epilogue)
 
@@ -374,10 +374,10 @@ def _pairs_scale_of(cache, w):
     return sc[id(w)][0]
 
 
-def gemm_weight_times_normed_t(cache, w, x, out, B, HW, C):
+def gemm_weight_times_normed_t(cache, w, x, out, B, HW, C, pairs=True):
     """out[b] = w [C, C] @ x[b]^T for x [B, HW, C] = the output of a GroupNorm: V^T of an attention block, K-contiguous for P.V."""
     kw = dict(M=C, N=HW, K=C, lda=C, ldb=C, ldc=HW, batch=B, stride_a=0, stride_b=HW * C, stride_c=C * HW)
-    if not gemm_pairs_ok(C, HW, C, B):
+    if not pairs or not gemm_pairs_ok(C, HW, C, B):
         return gemm(w, x, out=out, **kw)
     return gemm_pairs(w, x, _pairs_scale_of(cache, w), out, weight_is_a=True, **kw)
 

@@ -75,14 +75,23 @@ class ScoreMatrixBuilder:
             return rows
         return min(rows, max(128, (2240 * 3072) // sample_numel))
 
-    def build(self, x, batchsize, t=None, noise=None, generator=None, seed=None, row_range=None):
+    def build(self, x, batchsize, t=None, noise=None, generator=None, seed=None, row_range=None, safe=False):
         """x: one sample on the device; returns S [M, D] fp32 (rows in the reference's order), or only the rows
         ``row_range = (lo, hi)`` of it (row-sharded pipeline: with ``seed`` the draws of a row do not depend on who
         computes it).
 
+        ``safe=True``: the same point with every contraction on the range-unlimited route (fp32-contraction Winograd, six-product
+        GEMMs: ``IDIFF_NO_WINO43H`` / ``IDIFF_NO_PAIRS`` for this host thread's launches only).  The drivers call it ONCE for a
+        point whose score matrix came back non-finite from the default fp16-pair route, before they give up on the point: the
+        reference evaluates any checkpoint in fp32 (models/layerspp.py:242-274), so a range limit of ours must not turn into an error
+        of the user's.  Position-keyed noise (``seed`` / ``noise``) makes the re-run the same matrix.
+
         Noise: ``noise`` (explicit draws, for parity tests) > ``seed`` (in-kernel Philox stream, the default of the
         drivers: independent of the launch-set size; for D % 4 != 0 a torch generator keyed by the seed, same property) >
         ``generator`` (torch.randn, consumed launch set by launch set: the caller owns reproducibility)."""
+        if safe:
+            with _lib.thread_option("IDIFF_NO_WINO43H", 1), _lib.thread_option("IDIFF_NO_PAIRS", 1):
+                return self.build(x, batchsize, t=t, noise=noise, generator=generator, seed=seed, row_range=row_range)
         _, _, rows = batching(tuple(x.shape), batchsize)
         D = x.numel()
         t = self.eps if t is None else t
@@ -165,11 +174,12 @@ class SpectrumPipeline:
         # evaluations instead of beside them (+35 ms per point under torch.distributed.run, same kernels, same durations).
         prio = int(os.environ.get("IDIFF_SIDE_STREAM_PRIORITY", "-1"))
         self.side = torch.cuda.Stream(device=device, priority=prio) if overlap else None
-        self.pending = []         # [sv, S or None, pinned failure flag, event after the flag copy]: S is held until the flag is read
+        self.pending = []         # [sv, S or None, pinned failure flag, event after the flag copy, rebuild]: S is held until the flag is read
         self.deferred = None      # (S, ready event) of the last submitted point, not yet enqueued
         self.resolved = 0         # spectra that needed a fallback form of the eigensolver (fail-soft, see _reap)
+        self.rebuilt = 0          # points whose score matrix was non-finite on the default route and was built again on the safe one
 
-    def _launch(self, S, ready):
+    def _launch(self, S, ready, rebuild=None):
         stream = self.side if self.side is not None else torch.cuda.current_stream()
         if self.side is not None:
             self.side.wait_event(ready)                  # S is complete on the producing stream
@@ -183,7 +193,7 @@ class SpectrumPipeline:
             done.record()
         if self.side is not None:
             S.record_stream(self.side)                   # keep S alive until the side stream is done with it
-        self.pending.append([sv, S, flag, done])
+        self.pending.append([sv, S, flag, done, rebuild])
 
     def _reap(self, block):
         """Reads the failure flags of the spectra that have completed (all of them with ``block``).  A flagged spectrum is
@@ -199,20 +209,32 @@ class SpectrumPipeline:
                 break                                    # in stream order: later ones are not done either
             if bool(entry[2][0]):
                 stream = self.side if self.side is not None else torch.cuda.current_stream()
+                S = entry[1]
+                if entry[4] is not None and not bool(torch.isfinite(S).all()):
+                    # not the eigensolver: the score matrix itself is non-finite.  One re-run of the point on the range-unlimited
+                    # route (ScoreMatrixBuilder.build(safe=True)), on the caller's stream like every build, before that becomes an error
+                    warn_non_finite_point()
+                    S = entry[4]()
+                    self.rebuilt += 1
+                    torch.cuda.current_stream().synchronize()   # the rare path: S (and any filter bank packed for it) is complete
+                    with torch.cuda.stream(stream):
+                        entry[0] = _lib.spectrum(S, full=True)
                 with torch.cuda.stream(stream):
-                    entry[0] = _lib.resolve_failed_spectrum(entry[1], full=True,
-                                                            log=None if parallel.rank_world()[0] == 0 else (lambda msg: None))
-                self.resolved += 1
-            entry[1] = None
+                    if bool(torch.isnan(entry[0]).any()):
+                        entry[0] = _lib.resolve_failed_spectrum(S, full=True,
+                                                                log=None if parallel.rank_world()[0] == 0 else (lambda msg: None))
+                        self.resolved += 1
+            entry[1] = entry[4] = None
 
-    def submit(self, S):
+    def submit(self, S, rebuild=None):
+        """``rebuild``: a callable returning this point's S again on the safe route (see ``_reap``); without it a non-finite S raises."""
         self._reap(block=False)
         if self.side is None:
-            self._launch(S, None)
+            self._launch(S, None, rebuild)
             return
         ready = torch.cuda.Event()
         ready.record()
-        previous, self.deferred = self.deferred, (S, ready)
+        previous, self.deferred = self.deferred, (S, ready, rebuild)
         if previous is not None:
             self._launch(*previous)
 
@@ -228,7 +250,14 @@ class SpectrumPipeline:
         return out
 
 
-def row_sharded_spectrum(S_local, total_rows, ops=None, block_rows=None):
+def warn_non_finite_point():
+    import warnings
+    if parallel.rank_world()[0] == 0:
+        warnings.warn("id-diff_amd: a point's score matrix came back non-finite from the default (fp16-pair) route; building the "
+                      "point again with every contraction on the fp32 route (IDIFF_NO_WINO43H / IDIFF_NO_PAIRS for this re-run)")
+
+
+def row_sharded_spectrum(S_local, total_rows, ops=None, block_rows=None, rebuild=None):
     """Singular values (descending, fp32, [D]) of the column-centred [total_rows, D] matrix whose rows are spread over
     the ranks of the default process group (this rank holds ``S_local``); every rank returns the full spectrum.
 
@@ -239,7 +268,8 @@ def row_sharded_spectrum(S_local, total_rows, ops=None, block_rows=None):
     all-reduce of block b is asynchronous and runs while the matrix cores compute block b + 1; the lower triangle is
     mirrored once at the end.  With one rank this is the same arithmetic as
     ``_lib.spectrum``.  ``ops`` = (column_sums, gram_rows, symmetrize, sym_eigvals) defaults to the HIP stages; the CPU
-    process-group test injects plain-torch stand-ins to check the reduction logic without a GPU."""
+    process-group test injects plain-torch stand-ins to check the reduction logic without a GPU.  ``rebuild``: a callable that returns
+    this rank's rows again on the safe route; used once, on every rank, when any rank's Gram comes out non-finite."""
     col_sums, gram_rows, symmetrize, eigvals = ops if ops is not None else (
         _lib.column_sums, _lib.centered_gram_rows, _lib.symmetrize_upper, _lib.sym_eigvals)
     D = S_local.shape[1]
@@ -278,6 +308,13 @@ def row_sharded_spectrum(S_local, total_rows, ops=None, block_rows=None):
         if grouped:
             torch.distributed.all_reduce(failed, op=torch.distributed.ReduceOp.MAX)
         if bool(failed.item()):
+            if rebuild is not None:
+                bad = (~torch.isfinite(S_local).all()).to(torch.int32).reshape(1)
+                if grouped:
+                    torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+                if bool(bad.item()):                         # the same branch on every rank: the flag is reduced
+                    warn_non_finite_point()
+                    return row_sharded_spectrum(rebuild(), total_rows, ops=ops, block_rows=block_rows, rebuild=None)
             eig = _resolve_failed_eigvals(reduced_gram, eigvals, grouped)
     return eig.clamp_min(0.0).sqrt().flip(0).to(torch.float32)
 
@@ -403,8 +440,9 @@ def get_manifold_dimension(config, name=None, return_svd=False, return_dims=Fals
         with torch.no_grad():
             for p, (x, batchsize) in enumerate(points):
                 rows = batching(tuple(x.shape), batchsize)[2]
-                S_local = builder.build(x.to(device), batchsize, seed=point_seed(p), row_range=parallel.my_rows(rows, rank, world))
-                spectra.append(row_sharded_spectrum(S_local, rows))
+                kw = dict(seed=point_seed(p), row_range=parallel.my_rows(rows, rank, world))
+                S_local = builder.build(x.to(device), batchsize, **kw)
+                spectra.append(row_sharded_spectrum(S_local, rows, rebuild=lambda x=x, b=batchsize, kw=kw: builder.build(x.to(device), b, safe=True, **kw)))
         info = {'singular_values': [s.tolist() for s in checked_spectra(torch.stack(spectra))]}
         if return_svd:
             return info
@@ -432,7 +470,8 @@ def get_manifold_dimension(config, name=None, return_svd=False, return_dims=Fals
         else:
             for p in mine:
                 x, batchsize = points[p]
-                pipe.submit(builder.build(x.to(device), batchsize, seed=point_seed(p)))
+                pipe.submit(builder.build(x.to(device), batchsize, seed=point_seed(p)),
+                            rebuild=lambda x=x, b=batchsize, sd=point_seed(p): builder.build(x.to(device), b, seed=sd, safe=True))
             local = pipe.results()
     n_sv = points[0][0].numel()              # fixed-width rows for the exchange (a rank without points takes part too)
     local = torch.stack(local) if local else torch.empty(0, n_sv, device=device)
@@ -491,8 +530,9 @@ def conditional_spectra(builder, loader, num_datapoints, seed=42, levels=None, n
             for p in mine:
                 x, _, batchsize = points[p]
                 z = None if noise is None else noise(level, p).to(device)
-                pipe.submit(builder.build(x.to(device), batchsize, t=float(t_slice), noise=z,
-                                          seed=seed + 1000003 * (p + 1) + 7919 * level))
+                kw = dict(t=float(t_slice), noise=z, seed=seed + 1000003 * (p + 1) + 7919 * level)
+                pipe.submit(builder.build(x.to(device), batchsize, **kw),
+                            rebuild=lambda x=x, b=batchsize, kw=kw: builder.build(x.to(device), b, safe=True, **kw))
             local = pipe.results()
         if points:
             n_sv = points[0][0].numel()

@@ -208,6 +208,7 @@ class BeatGANsUNetModel(HipScoreModel):
         """AttentionBlock._forward (BeatGANsblocks.py:433-443) with QKVAttentionLegacy (:466-491), one head."""
         B, HW, C = x.buf.shape[0], x.H * x.W, x.C
         n = self._gn_act(x, mod.norm, None)
+        pairs = self.pairs_admissible(mod.norm, n.norm[1], transform=False)
         key = (id(mod), "qkv")
         if key not in pk["lin"]:
             w = mod.qkv.weight.detach().float().view(3 * C, C)
@@ -218,9 +219,9 @@ class BeatGANsUNetModel(HipScoreModel):
         wqk, bqk, wv, bv, wo, bo = pk["lin"][key]
         dev = x.buf.device
         qk = torch.empty(B * HW, 2 * C, device=dev, dtype=torch.float32)
-        _lib.gemm_normed(pk, n.buf.view(-1, C), wqk, qk, epilogue=_lib.make_epilogue(bias=bqk))    # n: a GroupNorm's output
+        _lib.gemm_normed(pk, n.buf.view(-1, C), wqk, qk, epilogue=_lib.make_epilogue(bias=bqk), pairs=pairs)    # n: a GroupNorm's output
         vt = torch.empty(B, C, HW, device=dev, dtype=torch.float32)
-        _lib.gemm_weight_times_normed_t(pk, wv, n.buf, vt, B, HW, C)
+        _lib.gemm_weight_times_normed_t(pk, wv, n.buf, vt, B, HW, C, pairs=pairs)
         logits = torch.empty(B, HW, HW, device=dev, dtype=torch.float32)
         _lib.gemm(qk, qk[:, C:], out=logits, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B,
                   stride_a=HW * 2 * C, stride_b=HW * 2 * C, stride_c=HW * HW)

@@ -159,10 +159,13 @@ def _pad4(c):
 class _T:
     """An NHWC activation: buffer [B, H*W, C] + geometry (+ the per-tile column sums [B, nsplit, C, 2] its producing
     contraction wrote through epilogue.colstats, which let the consuming GroupNorm skip its statistics pass)."""
-    __slots__ = ("buf", "H", "W", "C", "stats")
+    __slots__ = ("buf", "H", "W", "C", "stats", "norm")
 
-    def __init__(self, buf, H, W, C, stats=None):
+    def __init__(self, buf, H, W, C, stats=None, norm=None):
         self.buf, self.H, self.W, self.C, self.stats = buf, H, W, C, stats
+        # set on the output of a GroupNorm (and kept through the resamplers): (module, elements per normalised group, absolute gain of
+        # what followed, modulated?) -- what HipScoreModel.pairs_admissible needs to decide whether the consumer may run on fp16 pairs
+        self.norm = norm
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -325,6 +328,10 @@ class NCSNpp(HipScoreModel):
         pk["fir_down"] = torch.tensor(k, device=dev)
         pk["fir_up"] = torch.tensor(k * 4.0, device=dev)
         pk["fir_len"] = int(k.shape[0])
+        # absolute gain of the resamplers (bound of |output| / max|input|): the whole tap sum without zero insertion, the largest
+        # polyphase tap sum with it
+        pk["fir_gain"] = {"down": float(np.abs(k).sum()), "pre_conv": float(np.abs(k).sum()),
+                          "up": float(max(np.abs(4.0 * k[py::2, px::2]).sum() for py in (0, 1) for px in (0, 1)))}
         dense_w, dense_b, off = [], [], 0
         for i, mod in enumerate(M):
             if isinstance(mod, (ResnetBlockBigGANpp, ResnetBlockDDPMpp)):
@@ -357,6 +364,7 @@ class NCSNpp(HipScoreModel):
         HW = x.H * x.W
         C2 = x2.C if x2 is not None else 0
         G = gn.num_groups
+        norm = (gn, ((x.C + C2) // G) * HW, 1.0, mod is not None)
         if x.stats is not None and (x2 is None or x2.stats is not None) and x.C + C2 <= 1024 and B <= 65535:
             # both sources carry the column sums their producing contraction wrote: no pass over the activations, and the
             # statistics are finished inside the apply kernel (one launch per GroupNorm)
@@ -364,6 +372,7 @@ class NCSNpp(HipScoreModel):
             y = self._new(B, x.H, x.W, x.C + C2, x.buf)
             _lib.groupnorm_apply_colstats(x.buf, x.C, x2.buf if x2 is not None else None, C2, B, HW, G, x.stats[0], x.stats[1],
                                           ws2, ns2, gn.eps, gn.weight.detach(), gn.bias.detach(), act, y.buf, mod=mod)
+            y.norm = norm
             return y
         stats = torch.empty(B * G * 2, device=x.buf.device, dtype=torch.float32)
         if x.stats is not None and (x2 is None or x2.stats is not None):
@@ -376,16 +385,22 @@ class NCSNpp(HipScoreModel):
         y = self._new(B, x.H, x.W, x.C + C2, x.buf)
         _lib.groupnorm_apply(x.buf, x.C, x2.buf if x2 is not None else None, C2, B, HW, G, stats,
                              gn.weight.detach(), gn.bias.detach(), act, y.buf, mod=mod)
+        y.norm = norm
         return y
 
     def _conv(self, x, wt, bias, stride=1, pad=1, pad_hi=None, stats=False, normed=False, **ep):
         """``stats=True``: the output feeds a GroupNorm -> ask the epilogue for its per-tile column sums.
         ``normed=True``: the input is the output of a GroupNorm (+ activation, + FIR resampling), i.e. bounded by
         sqrt(group size) * |gamma| + |beta| -- only then may the F(4x4, 3x3) contraction run on fp16 pairs, whose transformed input
-        must stay below 65504 (include/idiff_hip.h); any other input takes the fp32 contraction."""
+        must stay below 65504 (include/idiff_hip.h), and only if THIS checkpoint's gamma / beta keep that bound inside the range
+        (base.HipScoreModel.pairs_admissible, decided once per layer at pack time); any other input takes the fp32 contraction."""
         B = x.buf.shape[0]
         cout, kh, kw, cin = wt.shape
         assert cin == x.C, (cin, x.C)
+        if normed:
+            assert x.norm is not None, "normed=True on a tensor that is not a GroupNorm's (resampled) output"
+            gn, group_elems, gain, modulated = x.norm
+            normed = self.pairs_admissible(gn, group_elems, gain=gain, transform=True, modulated=modulated)
         ph = pad if pad_hi is None else pad_hi
         OH = (x.H + pad + ph - kh) // stride + 1
         OW = (x.W + pad + ph - kw) // stride + 1
@@ -462,12 +477,15 @@ class NCSNpp(HipScoreModel):
         OW = _lib.upfirdn2d_out_size(x.W, up, down, p0, p1, n)
         y = self._new(B, OH, OW, x.C, x.buf)
         _lib.upfirdn2d_raw(x.buf, k, y.buf, B, x.H, x.W, x.C, up, up, down, down, p0, p1, p0, p1)
+        if x.norm is not None:
+            y.norm = (x.norm[0], x.norm[1], x.norm[2] * pk["fir_gain"][mode], x.norm[3])
         return y
 
     def _box(self, x, up):
         B = x.buf.shape[0]
         y = self._new(B, x.H * 2 if up else x.H // 2, x.W * 2 if up else x.W // 2, x.C, x.buf)
         _lib.resample2x_nhwc(x.buf, y.buf, B, x.H, x.W, x.C, up)
+        y.norm = x.norm                                        # nearest x2 / 2x2 mean: never beyond the input's range
         return y
 
     def _add(self, a, b, scale):
@@ -529,6 +547,7 @@ class NCSNpp(HipScoreModel):
         mod = self.all_modules[idx]
         B, HW, C = x.buf.shape[0], x.H * x.W, x.C
         n = self._gn_act(x, mod.GroupNorm_0, None)
+        pairs = self.pairs_admissible(mod.GroupNorm_0, n.norm[1], transform=False)
         if (idx, "qk") not in pk["nin"]:
             wq, bq = self._nin_w(pk, (idx, 0), mod.NIN_0)
             wk, bk = self._nin_w(pk, (idx, 1), mod.NIN_1)
@@ -538,10 +557,10 @@ class NCSNpp(HipScoreModel):
         w3, b3 = self._nin_w(pk, (idx, 3), mod.NIN_3)
         dev = x.buf.device
         qk = torch.empty(B * HW, 2 * C, device=dev, dtype=torch.float32)
-        _lib.gemm_normed(pk, n.buf.view(-1, C), wqk, qk, epilogue=_lib.make_epilogue(bias=bqk))    # n: a GroupNorm's output
+        _lib.gemm_normed(pk, n.buf.view(-1, C), wqk, qk, epilogue=_lib.make_epilogue(bias=bqk), pairs=pairs)    # n: a GroupNorm's output
         # V^T[b] = Wv^T-panel [C, Cin] x n[b]^T -> [C, HW], K-contiguous for the P.V product (bias deferred)
         vt = torch.empty(B, C, HW, device=dev, dtype=torch.float32)
-        _lib.gemm_weight_times_normed_t(pk, wv, n.buf, vt, B, HW, C)
+        _lib.gemm_weight_times_normed_t(pk, wv, n.buf, vt, B, HW, C, pairs=pairs)
         logits = torch.empty(B, HW, HW, device=dev, dtype=torch.float32)
         _lib.gemm(qk, qk[:, C:], out=logits, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B,
                   stride_a=HW * 2 * C, stride_b=HW * 2 * C, stride_c=HW * HW)

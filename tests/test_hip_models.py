@@ -433,6 +433,98 @@ def test_wide_ncsnpp_golden_through_winograd43(golden, wino43_everywhere):
     assert rel_err(raw32.cpu(), z["model_out"]) < NET_RTOL
 
 
+def _scaled_gamma_pair(z, factor, which="GroupNorm_1.weight"):
+    """(oracle model, HIP model on the GPU, name) of the nf = 128 golden configuration with ONE GroupNorm's gamma multiplied by `factor`."""
+    cfg = ncsnpp_config(**overrides_from_golden(z))
+    ref_model = omodels.create_model(cfg)
+    fill_from_seed(ref_model, int(z["seed"]))
+    sd = ref_model.state_dict()
+    name = next(k for k in sd if k.endswith(which))
+    with torch.no_grad():
+        sd[name].mul_(factor)
+    ref_model.load_state_dict(sd)
+    ref_model.eval()
+    model = mutils.create_model(cfg)
+    model.load_state_dict(sd)
+    return cfg, ref_model, model.to(DEV).eval(), name
+
+
+def test_out_of_range_groupnorm_is_routed_to_fp32_at_pack_time(golden, wino43_everywhere, factor=500.0):
+    """VERDICT r4 #2 / ADVICE: the fp16-pair route is taken per LAYER only when that layer's gamma / beta keep the transformed input
+    inside fp16's range (base.HipScoreModel.pairs_admissible).  A checkpoint with one GroupNorm's gamma x 500 gets exactly that
+    layer's convolution on the fp32 contraction, with a warning, and the score agrees with the oracle's at NET_RTOL -- the reference evaluates any checkpoint in fp32 (models/layerspp.py:242-274)."""
+    z = golden("ncsnpp_wide.npz")
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    _, ref_plain, model_plain, _ = _scaled_gamma_pair(z, 1.0)
+    model_plain(x.to(DEV), (t * 999).to(DEV))
+    plain = dict(wino43_everywhere)
+    cfg, ref_model, model, name = _scaled_gamma_pair(z, factor)
+    with pytest.warns(UserWarning, match="runs on the fp32 route"):
+        raw = model(x.to(DEV), (t * 999).to(DEV))
+    scaled = {k: wino43_everywhere[k] - plain[k] for k in plain}
+    assert scaled["n"] == plain["n"] and scaled["pairs"] == plain["pairs"] - 1, (plain, scaled, name)   # one layer moved, same kernel family
+    with torch.no_grad():
+        ref = ref_model(x, t * 999)
+    assert bool(torch.isfinite(raw).all()) and rel_err(raw.cpu(), ref) < NET_RTOL
+    # a second forward does not warn again (decided once per layer, kept in the pack)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model(x.to(DEV), (t * 999).to(DEV))
+    # the rule itself: bound = (sqrt(group elements) max|gamma| + max|beta|) x FIR gain x 29.34 (transform) < 60000, tensor scale >= 2^-6
+    from id_diff_amd.models import base
+    gn = torch.nn.GroupNorm(32, 128).to(DEV)
+    assert model.pairs_admissible(gn, 4 * 1024) and model.pairs_admissible(gn, 16 * 1024, gain=1.0)       # gamma 1: 29.34 x 128 = 3756
+    with torch.no_grad():
+        gn.weight.fill_(17.0)
+    with pytest.warns(UserWarning):
+        assert not model.pairs_admissible(gn, 16 * 1024)                                                   # 29.34 x 128 x 17 = 63.8k
+    assert model.pairs_admissible(gn, 16 * 1024, transform=False) and model.pairs_admissible(gn, 16 * 1024, modulated=True)
+    with torch.no_grad():
+        gn.weight.fill_(1e-3)
+    with pytest.warns(UserWarning):
+        assert not model.pairs_admissible(gn, 4 * 1024)                                                    # the whole tensor below 2^-6
+    assert abs(base.F43_INPUT_GAIN - 29.34) < 0.01
+
+
+def test_non_finite_point_is_rebuilt_on_the_fp32_route(golden, wino43_everywhere, monkeypatch):
+    """The second line of defence (the modulated norms of BeatGANs have no pack-time bound): with the bound check switched OFF, a
+    gamma x 1e5 layer overflows the pair kernel, the point's S comes back NaN, and SpectrumPipeline builds the point ONCE more under
+    IDIFF_NO_WINO43H / IDIFF_NO_PAIRS (ScoreMatrixBuilder.build(safe=True)) instead of raising: finite spectrum, a warning, rows equal
+    to the oracle's at NET_RTOL."""
+    from id_diff_amd.models import base
+    monkeypatch.setattr(base, "PAIRS_BOUND_CHECK", False)
+    z = golden("ncsnpp_wide.npz")
+    cfg, ref_model, model, _ = _scaled_gamma_pair(z, 1e5)
+    sde = sde_lib.VESDE(0.01, 50, 1000)
+    builder = dim_reduction.ScoreMatrixBuilder(mutils.get_score_fn(sde, model), sde, 1e-5, torch.device(DEV))
+    x0 = torch.from_numpy(z["x"])[0].to(DEV)
+    B = 16                                                             # 3x8x8 sample: 64 // 16 + 1 = 5 -> 20 batches, 304 rows
+    with torch.no_grad():
+        S_bad = builder.build(x0, B, seed=77)
+        assert not bool(torch.isfinite(S_bad).all())                   # the documented failure of the pair kernel: NaN, never finite-wrong
+        pipe = dim_reduction.SpectrumPipeline(torch.device(DEV))
+        pipe.submit(S_bad, rebuild=lambda: builder.build(x0, B, seed=77, safe=True))
+        with pytest.warns(UserWarning, match="fp32 route"):
+            (sv,) = pipe.results()
+        assert pipe.rebuilt == 1 and bool(torch.isfinite(sv).all())
+        S_ok = builder.build(x0, B, seed=77, safe=True)
+        np.testing.assert_allclose(_lib.spectrum(S_ok, full=True).cpu().numpy(), sv.cpu().numpy(), rtol=1e-6)
+        # rows of the safe build against the oracle on the same draws
+        n = 8
+        vec_t = torch.full((n,), 1e-5, device=DEV)
+        _, std = sde.marginal_prob(torch.ones((), device=DEV), vec_t)
+        batch, zz = torch.empty(n, x0.numel(), device=DEV), torch.empty(n, x0.numel(), device=DEV)
+        _lib.perturb_randn(x0.reshape(-1).contiguous(), std.contiguous(), None, batch, n, x0.numel(), 0, 77, z_out=zz)
+        ref_rows = osde.get_score_fn(osde.VESDE(0.01, 50, 1000), ref_model)(batch.cpu().view(n, *x0.shape), vec_t.cpu())
+    assert rel_err(S_ok[:n].cpu(), ref_rows.reshape(n, -1)) < NET_RTOL
+    # without a rebuild closure the old contract holds: a non-finite score matrix is an error, not a spectrum
+    pipe2 = dim_reduction.SpectrumPipeline(torch.device(DEV))
+    pipe2.submit(S_bad)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        pipe2.results()
+
+
 def test_wide_beatgans_golden_through_winograd43(golden, wino43_everywhere):
     z = golden("beatgans_wide.npz")
     model = mutils.create_model(beatgans_config(**overrides_from_golden(z)))

@@ -110,6 +110,121 @@ def test_config5_pipeline_end_to_end_vs_oracle(tmp_path):
     assert plot_utils.plot_dims(info)[1][0] == odim.estimate_dim(ref64.tolist())
 
 
+# ------------------------------------------------------------------------------------------ BASELINE config 3, the headline
+class _RouteCounter:
+    """Counts the launches of the contraction entry points by form, so that a test can assert WHICH kernels served a workload."""
+    NAMES = ("conv2d_winograd43", "conv2d_winograd", "conv2d_nhwc", "gemm_pairs", "gemm", "gemm_2src")
+
+    def __init__(self):
+        self.n = {"wino43_pairs": 0, "wino43_fp32": 0, "wino22": 0, "igemm_conv": 0, "gemm_pairs": 0, "gemm": 0, "gemm_2src": 0}
+        self._orig = {}
+
+    def __enter__(self):
+        def wrap(name, key):
+            orig = getattr(_lib, name)
+            self._orig[name] = orig
+
+            def counted(*a, **k):
+                self.n[key(*a, **k)] += 1
+                return orig(*a, **k)
+            setattr(_lib, name, counted)
+        wrap("conv2d_winograd43", lambda *a, pairs=False, **k: "wino43_pairs" if pairs else "wino43_fp32")
+        wrap("conv2d_winograd", lambda *a, **k: "wino22")
+        wrap("conv2d_nhwc", lambda *a, **k: "igemm_conv")
+        wrap("gemm_pairs", lambda *a, **k: "gemm_pairs")
+        wrap("gemm", lambda *a, **k: "gemm")
+        wrap("gemm_2src", lambda *a, **k: "gemm_2src")
+        return self
+
+    def __exit__(self, *exc):
+        for name, orig in self._orig.items():
+            setattr(_lib, name, orig)
+        return False
+
+
+def test_config3_full_size_production_routing_vs_oracle(golden):
+    """The configuration the headline number is quoted on, at FULL size, through the routing the drivers use by default, against the
+    CPU oracle on identical draws.  One point of bench.py's workload (nf = 128 NCSN++, init_scale = 1, seed-0
+    weights, bench image 1, the bench's point seed): S 4480 x 3072 in two 2240-row launch sets, 3x3 convs on the fp16-pair F(4x4,3x3)
+    kernel, q / k / v projections on pair GEMMs -- the launch counters are asserted so the routing cannot change silently.
+
+    The oracle side was computed once in the build container (tests/golden/make_cfg3_point.py: the oracle network on the draws of
+    oracle/philox.py, 883 s on 8 cores) and is a fixture: 192 rows of its S over both launch sets, the fp32 gesdd spectrum exactly as
+    dim_reduction.py:193-198, the fp64 spectrum, the IDs, the column means.  Checked here:
+      (0) oracle/philox.py IS the device stream (z_out of the kernel against it);
+      (a) the 192 rows at NET_RTOL;  the column means of the whole matrix;
+      (b) the HIP spectrum of the HIP-built S against the oracle's spectrum of the oracle's S at the north star's 1e-4, all 3072;
+      (c) the integer ID equal to the reference rule's on both oracle spectra, with the margin between the two largest gaps printed."""
+    from golden.make_cfg3_point import IMAGE_INDEX, POINT_SEED, T, cfg3, data_point, oracle_model
+    from helpers import weight_abs_sums
+    from oracle import philox
+    z = golden("cfg3_point.npz")
+    cfg = cfg3()
+    ref_model = oracle_model(cfg)
+    if str(z["torch_version"]) == torch.__version__:
+        np.testing.assert_allclose(weight_abs_sums(ref_model), z["weight_abs_sums"], rtol=1e-12)   # the fixture's weights, rebuilt from the seed
+    else:
+        np.testing.assert_allclose(weight_abs_sums(ref_model), z["weight_abs_sums"], rtol=1e-6)
+    x0 = data_point()
+    np.testing.assert_array_equal(x0.numpy(), z["x0"])
+    assert int(z["point_seed"]) == POINT_SEED and IMAGE_INDEX == 1
+    model = mutils.create_model(cfg)
+    model.load_state_dict(ref_model.state_dict())
+    model = model.to(DEV).eval()
+    sde, eps = sde_lib.configure_sde(cfg)
+    assert abs(eps - T) < 1e-12
+    score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
+    builder = dim_reduction.ScoreMatrixBuilder(score_fn, sde, eps, DEV)         # the drivers' defaults
+    assert builder.rows_per_launch(4480, 3072) == 2240
+    xd = x0.to(DEV)
+    with torch.no_grad():
+        builder.build(xd, 128, seed=POINT_SEED)                                  # first call packs the filter banks
+        with _RouteCounter() as routes:
+            S = builder.build(xd, 128, seed=POINT_SEED)
+    _note(f"config 3: routing per point {routes.n}")
+    # two launch sets x (88 GroupNorm-fed 3x3 convs on fp16 pairs; 6 attention blocks x {q|k, V^T} on pair GEMMs); no conv on the
+    # fp32 F(4x4) or the F(2x2) kernel; the stem, the three stride-2 convs and the 128 -> 3 head on the implicit-GEMM entry point
+    assert routes.n["wino43_pairs"] == 2 * 88 and routes.n["wino43_fp32"] == 0 and routes.n["wino22"] == 0, routes.n
+    assert routes.n["gemm_pairs"] == 2 * 6 * 2, routes.n
+    assert routes.n["igemm_conv"] == 2 * 5, routes.n
+    assert S.shape == (4480, 3072) and bool(torch.isfinite(S).all())
+
+    # (0) the CPU restatement of the Philox stream against the kernel's own draws (float part: a few ulp of logf / sincosf)
+    for row0, n in ((0, 64), (2230, 20), (4470, 10)):
+        _, zdev = _philox_rows(xd, sde, eps, POINT_SEED, row0, n)
+        zcpu = philox.normal_rows(POINT_SEED, 3072, row0, n)
+        assert float(np.abs(zdev.cpu().numpy() - zcpu).max()) < 4e-6
+    # (a) rows
+    rows = torch.from_numpy(z["rows"].astype(np.int64))
+    got = S[rows.to(DEV)].cpu()
+    ref_rows = torch.from_numpy(z["S_rows"])
+    err = rel_err(got, ref_rows)
+    worst = max(rel_err(got[i], ref_rows[i]) for i in range(len(rows)))
+    _note(f"config 3: 192 rows vs the oracle: rel err {err:.2e} (worst single row {worst:.2e})")
+    assert err < NET_RTOL and worst < NET_RTOL
+    colmean = S.double().mean(dim=0).cpu().numpy()
+    assert float(np.linalg.norm(colmean - z["colmean"]) / np.linalg.norm(z["colmean"])) < NET_RTOL
+    centred = S.double() - S.double().mean(dim=0, keepdim=True)
+    fro2 = float((centred * centred).sum())
+    assert abs(fro2 / float(z["fro2"]) - 1.0) < 1e-4
+    # (b) spectrum: ours (fp64 Gram route on the GPU) of OUR S against the reference recipe on the ORACLE's S
+    sv = _lib.spectrum(S).cpu().numpy().astype(np.float64)
+    dev64, dev32 = np.abs(sv / z["sv_f64"] - 1.0), np.abs(sv / z["sv_f32"].astype(np.float64) - 1.0)
+    _note(f"config 3: singular values vs oracle fp64 SVD max rel {dev64.max():.2e} (at {int(dev64.argmax())}), vs oracle fp32 gesdd {dev32.max():.2e}")
+    assert dev64.max() < 1e-4 and dev32.max() < 1e-4
+    # (c) the integer
+    mine = plot_utils.estimate_dim(sv.tolist())
+    gaps = sv[1:-1] - sv[2:]
+    order = np.argsort(-gaps)[:2]
+    _note(f"config 3: ID {mine} (oracle fp32 {int(z['id_f32'])}, fp64 {int(z['id_f64'])}); largest gaps at i = {int(order[0]) + 1} ({gaps[order[0]]:.3f}) "
+          f"and i = {int(order[1]) + 1} ({gaps[order[1]]:.3f}); oracle: i = {int(z['gap_index'][0])} ({float(z['gap_value'][0]):.3f}), "
+          f"i = {int(z['gap_index'][1])} ({float(z['gap_value'][1]):.3f})")
+    assert mine == int(z["id_f32"]) == int(z["id_f64"]) == odim.estimate_dim(z["sv_f32"].tolist())
+    # not a coin flip: the runner-up gap is far below the winner on both sides (a tie would be decided by rounding noise)
+    assert gaps[order[1]] < 0.5 * gaps[order[0]] and float(z["gap_value"][1]) < 0.5 * float(z["gap_value"][0])
+    assert int(order[0]) + 1 == int(z["gap_index"][0])
+
+
 # ------------------------------------------------------------------------------------------ f1: artefacts in, figures out
 def _f1_config(tmp_path, z):
     cfg = ncsnpp_config(**overrides_from_golden(z))
