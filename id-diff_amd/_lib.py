@@ -13,7 +13,10 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "csrc", "libidiff_hip.so")
+# IDIFF_LIB_VARIANT=<name>: a diagnostic / A-B build made by csrc/build.sh with IDIFF_VARIANT=<name> (scripts/_variant.py); the
+# production library is never overwritten by such a build and never reports variant flags (checked in lib())
+_VARIANT = os.environ.get("IDIFF_LIB_VARIANT", "")
+_LIB_PATH = os.path.join(_HERE, "csrc", f"libidiff_hip.{_VARIANT}.so" if _VARIANT else "libidiff_hip.so")
 _lib = None
 
 ACT = {None: 0, "none": 0, "linear": 0, "silu": 1, "swish": 1, "elu": 2, "relu": 3, "lrelu": 4}
@@ -31,6 +34,7 @@ _SIGNATURES = {
     "idiff_abi_version": (c_i, []),
     "idiff_last_error": (ctypes.c_char_p, []),
     "idiff_source_stamp": (ctypes.c_char_p, []),
+    "idiff_variant_flags": (ctypes.c_char_p, []),
     "idiff_set_option": (c_i, [ctypes.c_char_p, c_i]),
     "idiff_gemm_pairs_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "idiff_gemm_pairs_scale_f32": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
@@ -146,6 +150,14 @@ def lib():
         if built != tree:
             raise RuntimeError(f"{_LIB_PATH} was built from other sources (stamp {built}, tree {tree}): rebuild it with "
                                "`python -c 'import __graft_entry__ as g; g.build()'`")
+        flags = handle.idiff_variant_flags().decode()
+        if flags and not _VARIANT:
+            raise RuntimeError(f"{_LIB_PATH} is a diagnostic build (compiled with {flags!r}): its kernels may be wrong by construction. "
+                               "Rebuild the product library with `python -c 'import __graft_entry__ as g; g.build()'`")
+        if _VARIANT:
+            import sys
+            print(f"[id-diff_amd] DIAGNOSTIC library {os.path.basename(_LIB_PATH)} (flags: {flags or 'none'}) -- not the product",
+                  file=sys.stderr, flush=True)
         _lib = handle
     return _lib
 

@@ -64,6 +64,10 @@ int set_dynamic_lds_once(AttrGuard &g, const void *const *fns, int n_fns, int by
 IDIFF_API int idiff_abi_version(void) { return IDIFF_ABI_VERSION; }
 // sha256 (first 16 hex digits) of csrc/*.hip, csrc/*.h and include/idiff_hip.h at build time (csrc/build.sh)
 IDIFF_API const char *idiff_source_stamp(void) { return IDIFF_SOURCE_STAMP; }
+#ifndef IDIFF_VARIANT_FLAGS
+#define IDIFF_VARIANT_FLAGS ""
+#endif
+IDIFF_API const char *idiff_variant_flags(void) { return IDIFF_VARIANT_FLAGS; }
 IDIFF_API const char *idiff_last_error(void) { return idiff::g_err; }
 
 // Debug switch by its environment-variable name ("IDIFF_NO_WINOGRAD", ...): returns the previous value, -1 if unknown.

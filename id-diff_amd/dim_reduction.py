@@ -126,9 +126,16 @@ class ScoreMatrixBuilder:
                 else:
                     z = torch.randn(n, D, device=self.device, dtype=torch.float32, generator=generator)
                 _lib.perturb(xf, z, std.contiguous(), coeff, batch, n, D)
-            score = self.score_fn(batch.view(n, *x.shape), vec_t)
-            S[lo - r_lo:lo - r_lo + n].copy_(score.reshape(n, D))
+            self._score_into(S[lo - r_lo:lo - r_lo + n], batch.view(n, *x.shape), vec_t)
         return S
+
+    def _score_into(self, rows, batch, vec_t):
+        """Scores of ``batch`` into ``rows`` (a row block of S): written there by the network's last kernel when the model takes an
+        output buffer (the image models), copied otherwise."""
+        if getattr(self.score_fn, "accepts_out", False):
+            self.score_fn(batch, vec_t, out=rows)
+        else:
+            rows.copy_(self.score_fn(batch, vec_t).reshape(rows.shape))
 
     def _build_concurrent(self, x, xf, S, r_lo, r_hi, step, D, t, noise, seed):
         """The launch sets of one point dealt round-robin to ``concurrent_sets`` worker streams; the caller's stream waits
@@ -149,8 +156,7 @@ class ScoreMatrixBuilder:
                     _lib.perturb_randn(xf, std.contiguous(), coeff, batch, n, D, lo, seed)
                 else:
                     _lib.perturb(xf, noise[lo:lo + n].reshape(n, D).contiguous(), std.contiguous(), coeff, batch, n, D)
-                score = self.score_fn(batch.view(n, *x.shape), vec_t)
-                S[lo - r_lo:lo - r_lo + n].copy_(score.reshape(n, D))
+                self._score_into(S[lo - r_lo:lo - r_lo + n], batch.view(n, *x.shape), vec_t)
         for w in self._workers:
             cur.wait_stream(w)
         return S

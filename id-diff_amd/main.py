@@ -55,15 +55,16 @@ def main(argv=None):
         raise SystemExit(f"mode {flags.mode!r} is outside the scope of id-diff_amd (the MI355X build covers "
                          f"{', '.join(_HOT_MODES)}); use the reference for training / sampling / evaluation")
     if flags.gpus is not None:
+        need_devices = not str(getattr(config, "device", "cuda")).startswith("cpu")     # the same answer in the launcher and in the ranks
         if flags.gpus > 1 and not parallel.launched():
             # become the launcher: nothing in this process has touched the GPU; fresh rank processes, never an exec
             rc = parallel.launch_local_ranks(os.path.abspath(__file__), list(sys.argv[1:] if argv is None else argv), flags.gpus,
-                                             need_devices=not str(getattr(config, "device", "cuda")).startswith("cpu"))
+                                             need_devices=need_devices)
             if rc:
                 raise SystemExit(rc)
             return
         if parallel.launched():
-            parallel.check_world(flags.gpus, int(os.environ["WORLD_SIZE"]))
+            parallel.check_world(flags.gpus, int(os.environ["WORLD_SIZE"]), need_devices=need_devices)
     rank, world, local_rank = parallel.init_from_env()
     if world > 1:
         config.device = f"cuda:{parallel.device_ordinal(local_rank)}"

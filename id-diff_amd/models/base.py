@@ -90,6 +90,17 @@ class HipScoreModel(nn.Module):
         return cache[key]
 
     @staticmethod
+    def _out_buffer(out, B, C, H, W, device):
+        """The NCHW output tensor of an image model: the caller's ``out`` (e.g. the rows of the device-resident score matrix, so
+        that the last kernel of the network writes S directly) after checking it is what that kernel will write, else a new one."""
+        if out is None:
+            return torch.empty(B, C, H, W, device=device, dtype=torch.float32)
+        _lib._dev(out, "out")
+        if out.numel() != B * C * H * W or out.device != device:
+            raise RuntimeError(f"out: expected {B * C * H * W} contiguous fp32 values on {device}, got {tuple(out.shape)} on {out.device}")
+        return out.view(B, C, H, W)
+
+    @staticmethod
     def _check_inputs(x, t):
         """Device / dtype checks; returns contiguous views (the reference's ops call .contiguous() themselves)."""
         _lib._dev(x, "x", contiguous=False)

@@ -260,7 +260,9 @@ class BeatGANsUNetModel(HipScoreModel):
         return x
 
     # -------------------------------------------------------------------------------------------- forward
-    def forward(self, x, t, out_rowscale=None):
+    forward_accepts_out = True
+
+    def forward(self, x, t, out_rowscale=None, out=None):
         x, t = self._check_inputs(x, t)
         if x.ndim != 4 or x.shape[1] != self.channels:
             raise RuntimeError(f"BeatGANsUNetModel: expected [B, {self.channels}, H, W], got {tuple(x.shape)}")
@@ -294,6 +296,6 @@ class BeatGANsUNetModel(HipScoreModel):
         n = self._gn_act(h, self.out[0], "silu")
         w, b = self._cw(pk, self.out[2])
         h = self._conv(n, w, b, normed=True)
-        out = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+        out = self._out_buffer(out, B, C, H, W, dev)
         _lib.nhwc_to_nchw(h.buf, out, B, C, H * W, h.C, out_rowscale)
         return out

@@ -588,7 +588,11 @@ class NCSNpp(HipScoreModel):
         return self._box(x, False)                                       # avg_pool2d(2)
 
     # -------------------------------------------------------------------------------------------- forward
-    def forward(self, x, time_cond, out_rowscale=None):
+    forward_accepts_out = True
+
+    def forward(self, x, time_cond, out_rowscale=None, out=None):
+        """``out``: optional contiguous fp32 buffer of B * C * H * W values that receives the NCHW result (the drivers pass the rows
+        of S: no copy of the scores afterwards)."""
         x, time_cond = self._check_inputs(x, time_cond)
         if x.ndim != 4 or x.shape[1] != self.channels:
             raise RuntimeError(f"ncsnpp: expected [B, {self.channels}, H, W], got {tuple(x.shape)}")
@@ -686,6 +690,6 @@ class NCSNpp(HipScoreModel):
                 h = pyr
         assert not hs
         c_out = getattr(self, "out_channels", C)
-        out = torch.empty(B, c_out, H, W, device=dev, dtype=torch.float32)
+        out = self._out_buffer(out, B, c_out, H, W, dev)
         _lib.nhwc_to_nchw(h.buf, out, B, c_out, H * W, h.C, out_rowscale)
         return out

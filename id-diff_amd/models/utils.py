@@ -46,10 +46,19 @@ def get_score_fn(sde, model, conditional=False, train=False, continuous=True):
         raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
     get_model_fn(model, train=train)
 
-    def score_fn(x, t):
+    accepts_out = bool(getattr(model, "forward_accepts_out", False))
+
+    def score_fn(x, t, out=None):
+        """``out`` (not in the reference): a buffer for the scores -- the drivers pass the rows of S -- for models whose last kernel
+        can write there (``score_fn.accepts_out``)."""
         labels = t * (sde.N - 1)
         std = sde.marginal_prob(torch.zeros((), device=t.device), t)[1]
         model.eval()
+        if out is not None:
+            if not accepts_out:
+                raise RuntimeError(f"{type(model).__name__}.forward takes no output buffer")
+            return model(x, labels, out_rowscale=-1.0 / std, out=out)
         return model(x, labels, out_rowscale=-1.0 / std)
 
+    score_fn.accepts_out = accepts_out
     return score_fn

@@ -32,6 +32,10 @@ const char *idiff_last_error(void);
 /* First 16 hex digits of the sha256 over the sources the library was built from (csrc/build.sh); the Python binding
  * compares it with the tree and refuses a stale libidiff_hip.so. */
 const char *idiff_source_stamp(void);
+/* "" for the product library.  A diagnostic / A-B build (csrc/build.sh with IDIFF_VARIANT=<name> IDIFF_VARIANT_FLAGS=...: timing-only
+ * kernels, stamped kernels, lifted scratch limit) reports its extra compile flags here, is written to libidiff_hip.<name>.so only,
+ * and the Python binding loads it only when IDIFF_LIB_VARIANT=<name> asks for it -- never from the production path. */
+const char *idiff_variant_flags(void);
 
 /* Debug / A-B switches, named like the environment variables that initialise them at load time:
  * IDIFF_NO_WINOGRAD (3x3 convs on the implicit GEMM), IDIFF_NO_COLSTATS, IDIFF_NO_PIPE, IDIFF_SCALAR_EPILOGUE,

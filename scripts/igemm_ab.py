@@ -1,19 +1,12 @@
 """Builds of the split-precision igemm compared on ONE box: python scripts/igemm_ab.py "<flags 1>" "<flags 2>" ...
-Each entry rebuilds the library with the flags ("" = as committed; IDIFF_IGEMM_DIAG_* make timing-only kernels whose results are
+Each entry builds a variant library (scripts/_variant.py) with the flags ("" = as committed; IDIFF_IGEMM_DIAG_* make timing-only kernels whose results are
 wrong by construction) and times the 1x1 / NIN / attention contractions of one nf = 128 NCSN++ forward at B = 2240."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "id-diff_amd", "csrc", "build.sh")
 
-def build(extra):
-    src = open(BUILD).read()
-    patched = src.replace("extra=\"\"", "extra=\"%s\"" % extra) if extra else src
-    tmp = BUILD + ".ab.sh"
-    open(tmp, "w").write(patched)
-    try:
-        subprocess.run(["bash", tmp], check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, IDIFF_SCRATCH_LIMIT="100000"))
-    finally:
-        os.remove(tmp)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _variant import build_variant, remove_variant, run_child   # builds go to libidiff_hip.<name>.so, never to the product library
+VARIANT = "igemm_ab"
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
@@ -58,7 +51,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 args = sys.argv[1:]
 try:
     for flags in args:
-        build(flags)
-        subprocess.run([sys.executable, os.path.abspath(__file__), "child", flags or "(as committed)"], check=False)
+        build_variant(VARIANT, flags, scratch_limit=100000)
+        run_child(__file__, VARIANT, flags or "(as committed)")
 finally:
-    build("")
+    remove_variant(VARIANT)

@@ -1,19 +1,12 @@
 """Alternating-build A/B of winograd43_kernel on ONE box: python scripts/wino43_ab.py "<flags A>" "<flags B>" [rounds]
-e.g.  "" "-DIDIFF_W43_DYADIC_POINTS"   or   "-DIDIFF_W43_SCR_UNIT=168" "".  Each round rebuilds the library with the flags and times
+e.g.  "" "-DIDIFF_W43_DYADIC_POINTS"   or   "-DIDIFF_W43_SCR_UNIT=168" "".  Each round builds a variant library (scripts/_variant.py) with the flags and times
 the F(4x4) convolutions of one nf = 128 NCSN++ forward at B = 2240 (scripts/wino43_probe.py's shape table), F(2x2) beside it."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "id-diff_amd", "csrc", "build.sh")
 
-def build(extra):
-    src = open(BUILD).read()
-    patched = src.replace('&& extra="-Xclang', '&& extra="%s -Xclang' % extra) if extra else src
-    tmp = BUILD + ".ab.sh"
-    open(tmp, "w").write(patched)
-    try:
-        subprocess.run(["bash", tmp], check=True, stdout=subprocess.DEVNULL)
-    finally:
-        os.remove(tmp)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _variant import build_variant, remove_variant, run_child   # builds go to libidiff_hip.<name>.so, never to the product library
+VARIANT = "wino43_ab"
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
@@ -47,7 +40,7 @@ rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 try:
     for r in range(rounds):
         for flags in (A, Bf):
-            build(flags)
-            subprocess.run([sys.executable, os.path.abspath(__file__), "child", flags or "(default)"], check=False)
+            build_variant(VARIANT, flags)
+            run_child(__file__, VARIANT, flags or "(default)")
 finally:
-    build("")
+    remove_variant(VARIANT)

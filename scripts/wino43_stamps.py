@@ -1,20 +1,12 @@
 """Where a workgroup of winograd43_kernel spends its life (diagnostic build -DIDIFF_W43_STAMP: s_memrealtime at start, loop start,
 loop end, end + the CU it ran on): prologue / K loop / tail per workgroup, and the gap between consecutive workgroups on one CU.
-Run on the GPU box: python scripts/wino43_stamps.py   (rebuilds the library in place twice)."""
+Run on the GPU box: python scripts/wino43_stamps.py   (builds a separate diagnostic library, libidiff_hip.<variant>.so)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "id-diff_amd", "csrc", "build.sh")
 
-def build(extra):
-    src = open(BUILD).read()
-    patched = src.replace('&& extra="-Xclang', '&& extra="%s -Xclang' % extra) if extra else src
-    tmp = BUILD + ".stamp.sh"
-    open(tmp, "w").write(patched)
-    try:
-        # the stamps cost a few registers: the diagnostic build may spill a little more than the 64 B the product build allows
-        subprocess.run(["bash", tmp], check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, IDIFF_SCRATCH_LIMIT="256" if extra else "64"))
-    finally:
-        os.remove(tmp)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _variant import build_variant, remove_variant, run_child   # builds go to libidiff_hip.<name>.so, never to the product library
+VARIANT = "wino43_stamps"
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
@@ -56,7 +48,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 
 try:
-    build("-DIDIFF_W43_STAMP")
-    subprocess.run([sys.executable, os.path.abspath(__file__), "child"], check=False)
+    build_variant(VARIANT, "-DIDIFF_W43_STAMP", scratch_limit=256)
+    run_child(__file__, VARIANT)
 finally:
-    build("")
+    remove_variant(VARIANT)

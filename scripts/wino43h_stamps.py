@@ -3,17 +3,10 @@ kernel start, loop start, loop end, and at the tail's phases), with the epilogue
 bias, column sums) and of its second (residual, scale, column sums).  Run on the GPU box: python scripts/wino43h_stamps.py"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "id-diff_amd", "csrc", "build.sh")
 
-def build(extra):
-    src = open(BUILD).read()
-    patched = src.replace('extra=""', 'extra="%s"' % extra) if extra else src
-    tmp = BUILD + ".stamp.sh"
-    open(tmp, "w").write(patched)
-    try:
-        subprocess.run(["bash", tmp], check=True, stdout=subprocess.DEVNULL)
-    finally:
-        os.remove(tmp)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _variant import build_variant, remove_variant, run_child   # builds go to libidiff_hip.<name>.so, never to the product library
+VARIANT = "wino43h_stamps"
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
@@ -60,7 +53,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 
 try:
-    build("-DIDIFF_W43H_STAMP")
-    subprocess.run([sys.executable, os.path.abspath(__file__), "child"], check=False)
+    build_variant(VARIANT, "-DIDIFF_W43H_STAMP")
+    run_child(__file__, VARIANT)
 finally:
-    build("")
+    remove_variant(VARIANT)

@@ -1,20 +1,13 @@
 """The clock the chip holds INSIDE winograd_kernel (MI355X_MICROARCH.md, 'DVFS give-back' item 6): a diagnostic build
 (-DIDIFF_WINO_STAMP: every workgroup stamps s_memtime and s_memrealtime around its lifetime into a buffer of its own) runs
 back-to-back launches on random data for ~2 s, then clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, median over the
-workgroups of the last launch.  Run on the GPU box:  python scripts/wino_clock.py   (rebuilds the library in place twice)."""
+workgroups of the last launch.  Run on the GPU box:  python scripts/wino_clock.py   (builds a separate diagnostic library, libidiff_hip.<variant>.so)."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "id-diff_amd", "csrc", "build.sh")
 
-def build(extra):
-    src = open(BUILD).read()
-    patched = src.replace('[ "$s" = winograd ] && extra="', '[ "$s" = winograd ] && extra="%s ' % extra) if extra else src
-    tmp = BUILD + ".clock.sh"
-    open(tmp, "w").write(patched)
-    try:
-        subprocess.run(["bash", tmp], check=True, stdout=subprocess.DEVNULL)
-    finally:
-        os.remove(tmp)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _variant import build_variant, remove_variant, run_child   # builds go to libidiff_hip.<name>.so, never to the product library
+VARIANT = "wino_clock"
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
@@ -49,7 +42,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 
 try:
-    build("-DIDIFF_WINO_STAMP")
-    subprocess.run([sys.executable, os.path.abspath(__file__), "child"], check=False)
+    build_variant(VARIANT, "-DIDIFF_WINO_STAMP")
+    run_child(__file__, VARIANT)
 finally:
-    build("")
+    remove_variant(VARIANT)

@@ -1,19 +1,12 @@
 """Where a step of winograd_split_kernel spends its cycles: a diagnostic build (-DIDIFF_SPLIT_PHASES) stamps s_memtime
 between the phases of every step (each stamp waits for the wave's LDS traffic, so it perturbs the schedule by ~10 %).
-Run on the GPU box:  python scripts/wino_split_phases.py   (rebuilds the library in place twice)."""
+Run on the GPU box:  python scripts/wino_split_phases.py   (builds a separate diagnostic library, libidiff_hip.<variant>.so)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "id-diff_amd", "csrc", "build.sh")
 
-def build(extra):
-    src = open(BUILD).read()
-    patched = src.replace('[ "$s" = winograd ] && extra="', '[ "$s" = winograd ] && extra="%s ' % extra) if extra else src
-    tmp = BUILD + ".phases.sh"
-    open(tmp, "w").write(patched)
-    try:
-        subprocess.run(["bash", tmp], check=True, stdout=subprocess.DEVNULL)
-    finally:
-        os.remove(tmp)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _variant import build_variant, remove_variant, run_child   # builds go to libidiff_hip.<name>.so, never to the product library
+VARIANT = "wino_split_phases"
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
@@ -48,7 +41,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 
 try:
-    build("-DIDIFF_SPLIT_PHASES")
-    subprocess.run([sys.executable, os.path.abspath(__file__), "child"], check=False)
+    build_variant(VARIANT, "-DIDIFF_SPLIT_PHASES")
+    run_child(__file__, VARIANT)
 finally:
-    build("")
+    remove_variant(VARIANT)

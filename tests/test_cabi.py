@@ -103,3 +103,23 @@ def test_thread_option_acts_on_the_calling_thread_only():
     with pytest.raises(KeyError):
         with _lib.thread_option("IDIFF_NO_SUCH_SWITCH", 1):
             pass
+
+
+def test_diagnostic_builds_cannot_reach_the_production_path(library):
+    """probe scripts used to rebuild libidiff_hip.so in place with timing-only kernels.  Now a build with extra flags must
+    name a variant (its own file), the product library reports no variant flags, and no probe script patches or rewrites build.sh."""
+    import subprocess
+    library.idiff_variant_flags.restype = ctypes.c_char_p
+    assert library.idiff_variant_flags() == b""
+    build_sh = os.path.join(ROOT, "id-diff_amd", "csrc", "build.sh")
+    out = subprocess.run(["bash", build_sh], env=dict(os.environ, IDIFF_VARIANT_FLAGS="-DIDIFF_W43H_DIAG_NO_U", IDIFF_VARIANT=""),
+                         capture_output=True, text=True)
+    assert out.returncode == 4 and "must name its own output file" in out.stderr          # refused before anything is compiled
+    out = subprocess.run(["bash", build_sh], env=dict(os.environ, IDIFF_VARIANT="../x"), capture_output=True, text=True)
+    assert out.returncode == 4
+    scripts = os.path.join(ROOT, "scripts")
+    for name in os.listdir(scripts):
+        if name.endswith(".py") and name != "_variant.py":
+            text = open(os.path.join(scripts, name)).read()
+            assert "build.sh" not in text or "_variant" in text, f"scripts/{name} drives build.sh itself"
+            assert "IDIFF_SCRATCH_LIMIT" not in text, f"scripts/{name} lifts the scratch limit of a build it does not name"

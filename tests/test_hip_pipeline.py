@@ -467,6 +467,17 @@ def _get_from_live_workers(q, procs, timeout):
     raise AssertionError(f"no answer from the workers within {timeout} s")
 
 
+def _terminate(procs):
+    """Exactly the processes this test started (by handle, never by pattern), if any is still alive."""
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+
+
 def test_bench_main_two_ranks_real_workload_one_gpu():
     """bench.main() with the REAL config-3 workload at world size 2 (two processes sharing this card, gloo moving the
     device tensors): barrier / timed region / exchange of spectra and int32 IDs / all-reduce-MAX of the time / rank-0-only
@@ -478,10 +489,13 @@ def test_bench_main_two_ranks_real_workload_one_gpu():
     procs = [ctx.Process(target=_bench_two_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(_get_from_live_workers(q, procs, 900) for _ in range(2))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        got = dict(_get_from_live_workers(q, procs, 900) for _ in range(2))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        _terminate(procs)               # a failed assertion must not leave the surviving rank waiting in a barrier on the card
     assert got[1] is None
     line = got[0]
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak" and line["config"]["process_group"] == "gloo"
@@ -522,9 +536,12 @@ def test_row_sharded_spectrum_and_exchange_on_one_rank_rccl():
     q = ctx.Queue()
     p = ctx.Process(target=_rows_rccl_worker, args=(39500 + (os.getpid() % 2000), q))
     p.start()
-    backend, err, same, dims = q.get(timeout=300)
-    p.join(timeout=120)
-    assert p.exitcode == 0
+    try:
+        backend, err, same, dims = _get_from_live_workers(q, [p], 300)
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    finally:
+        _terminate([p])
     assert backend == "nccl" and err < 1e-4 and same and dims == [20]
 
 
