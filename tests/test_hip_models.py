@@ -473,17 +473,19 @@ def test_out_of_range_groupnorm_is_routed_to_fp32_at_pack_time(golden, wino43_ev
         model(x.to(DEV), (t * 999).to(DEV))
     # the rule itself: bound = (sqrt(group elements) max|gamma| + max|beta|) x FIR gain x 29.34 (transform) < 60000, tensor scale >= 2^-6
     from id_diff_amd.models import base
-    gn = torch.nn.GroupNorm(32, 128).to(DEV)
+    def gn_with(gamma):                                     # the verdict is kept per module in the pack: a fresh module per question
+        g = torch.nn.GroupNorm(32, 128).to(DEV)
+        with torch.no_grad():
+            g.weight.fill_(gamma)
+        return g
+    gn = gn_with(1.0)
     assert model.pairs_admissible(gn, 4 * 1024) and model.pairs_admissible(gn, 16 * 1024, gain=1.0)       # gamma 1: 29.34 x 128 = 3756
-    with torch.no_grad():
-        gn.weight.fill_(17.0)
+    gn = gn_with(17.0)
     with pytest.warns(UserWarning):
         assert not model.pairs_admissible(gn, 16 * 1024)                                                   # 29.34 x 128 x 17 = 63.8k
-    assert model.pairs_admissible(gn, 16 * 1024, transform=False) and model.pairs_admissible(gn, 16 * 1024, modulated=True)
-    with torch.no_grad():
-        gn.weight.fill_(1e-3)
+    assert model.pairs_admissible(gn, 16 * 1024, transform=False) and model.pairs_admissible(gn_with(17.0), 16 * 1024, modulated=True)
     with pytest.warns(UserWarning):
-        assert not model.pairs_admissible(gn, 4 * 1024)                                                    # the whole tensor below 2^-6
+        assert not model.pairs_admissible(gn_with(1e-3), 4 * 1024)                                         # the whole tensor below 2^-6
     assert abs(base.F43_INPUT_GAIN - 29.34) < 0.01
 
 
