@@ -182,10 +182,11 @@ def test_config3_full_size_production_routing_vs_oracle(golden):
         with _RouteCounter() as routes:
             S = builder.build(xd, 128, seed=POINT_SEED)
     _note(f"config 3: routing per point {routes.n}")
-    # two launch sets x (88 GroupNorm-fed 3x3 convs on fp16 pairs; 6 attention blocks x {q|k, V^T} on pair GEMMs); no conv on the
-    # fp32 F(4x4) or the F(2x2) kernel; the stem, the three stride-2 convs and the 128 -> 3 head on the implicit-GEMM entry point
+    # two launch sets x (88 GroupNorm-fed 3x3 convs on fp16 pairs; the five 256-token attention blocks' {q|k, V^T} and the 16-token
+    # middle block's q|k on pair GEMMs -- its V^T has N = 16 tokens, below the pair form's N > 64, and stays on six products); no conv on
+    # the fp32 F(4x4) or the F(2x2) kernel; the stem, the three stride-2 convs and the 128 -> 3 head on the implicit-GEMM entry point
     assert routes.n["wino43_pairs"] == 2 * 88 and routes.n["wino43_fp32"] == 0 and routes.n["wino22"] == 0, routes.n
-    assert routes.n["gemm_pairs"] == 2 * 6 * 2, routes.n
+    assert routes.n["gemm_pairs"] == 2 * (5 * 2 + 1), routes.n
     assert routes.n["igemm_conv"] == 2 * 5, routes.n
     assert S.shape == (4480, 3072) and bool(torch.isfinite(S).all())
 
