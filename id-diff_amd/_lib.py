@@ -79,6 +79,8 @@ _SIGNATURES = {
     "idiff_groupnorm_apply_colstats_f32": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_p, c_i64,
                                                  c_i, c_p, c_p]),
     "idiff_softmax_rows_f32": (c_i, [c_p, c_p, c_i64, c_i, c_f, c_p]),
+    "idiff_attention256_ok": (c_i, [c_i, c_i, c_i]),
+    "idiff_attention256_f32": (c_i, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "idiff_affine_act_f32": (c_i, [c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_i64, c_p]),
     "idiff_add_scale_f32": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_p]),
     "idiff_fourier_embed_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
@@ -546,6 +548,33 @@ def groupnorm_apply_colstats(x, C, x2, C2, B, HW, G, ws1, ns1, ws2, ns2, eps, ga
 def softmax_rows(x, y, rows, cols, scale):
     _check(lib().idiff_softmax_rows_f32(x.data_ptr(), y.data_ptr(), rows, cols, scale, _stream()),
            "idiff_softmax_rows_f32")
+
+
+def attention256_ok(B, tokens, C):
+    """True when the one-launch attention serves this shape (256 tokens, 128 / 256 channels; off under IDIFF_NO_FUSED_ATTN / IDIFF_NO_PAIRS)."""
+    return bool(lib().idiff_attention256_ok(B, tokens, C))
+
+
+def pairs_scale_from_rows(w, bias=None, extra=1.0):
+    """Device tensor {s, 1 / s}: the power of two that brings the output of ``w @ n + bias`` -- n a GroupNorm's output, unit variance per
+    element by construction -- to a root mean square near one: rms^2 = mean_i |w_i|^2 (+ mean b^2).  Computed on the device, once per
+    weight (no host synchronisation).  ``extra``: a known factor of the input's scale (GroupNorm gamma's rms)."""
+    ms = (w.double() ** 2).sum(dim=1).mean() * float(extra) ** 2
+    if bias is not None:
+        ms = ms + (bias.double() ** 2).mean()
+    e = torch.round(-0.5 * torch.log2(ms.clamp_min(1e-300))).clamp(-24, 24)
+    s = torch.exp2(e)
+    return torch.stack([s, 1.0 / s]).to(torch.float32).contiguous()
+
+
+def attention256(qk, vt, out, B, C, s_qk, s_v, scale, bias_v=None):
+    """out [B * 256, C] = softmax(q k^T * scale) v (+ bias_v) per sample; qk [B * 256, 2 C] (q | k), vt [B, C, 256]."""
+    _dev(qk, "qk"); _dev(vt, "vt"); _dev(out, "out"); _dev(s_qk, "s_qk"); _dev(s_v, "s_v")
+    if qk.shape != (B * 256, 2 * C) or vt.shape != (B, C, 256) or out.numel() != B * 256 * C:
+        raise RuntimeError(f"attention256: shapes qk {tuple(qk.shape)}, vt {tuple(vt.shape)}, out {tuple(out.shape)} for B = {B}, C = {C}")
+    _check(lib().idiff_attention256_f32(qk.data_ptr(), qk.stride(0), vt.data_ptr(), _ptr(bias_v), s_qk.data_ptr(), s_v.data_ptr(),
+                                        out.data_ptr(), B, 256, C, float(scale), _stream()), "idiff_attention256_f32")
+    return out
 
 
 def affine_act(a, y, n, alpha=1.0, beta=0.0, act=None, rowscale=None, inner=0):

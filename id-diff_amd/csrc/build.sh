@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRC="runtime upfirdn2d fused_bias_act igemm conv_narrow norm_act rng spectrum sbr winograd winograd43 winograd43h"
+SRC="runtime upfirdn2d fused_bias_act igemm conv_narrow norm_act rng spectrum sbr winograd winograd43 winograd43h attention"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function"
 # stamp of the sources this library is built from; _lib.lib() refuses a library whose stamp differs from the tree's
 STAMP=$(cat $(ls *.hip *.h | LC_ALL=C sort) ../../include/idiff_hip.h | sha256sum | cut -c1-16)

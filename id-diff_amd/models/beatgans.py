@@ -222,14 +222,23 @@ class BeatGANsUNetModel(HipScoreModel):
         _lib.gemm_normed(pk, n.buf.view(-1, C), wqk, qk, epilogue=_lib.make_epilogue(bias=bqk), pairs=pairs)    # n: a GroupNorm's output
         vt = torch.empty(B, C, HW, device=dev, dtype=torch.float32)
         _lib.gemm_weight_times_normed_t(pk, wv, n.buf, vt, B, HW, C, pairs=pairs)
-        logits = torch.empty(B, HW, HW, device=dev, dtype=torch.float32)
-        _lib.gemm(qk, qk[:, C:], out=logits, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B,
-                  stride_a=HW * 2 * C, stride_b=HW * 2 * C, stride_c=HW * HW)
-        # (q * s) . (k * s) with s = ch^-1/4  ==  q . k * ch^-1/2
-        _lib.softmax_rows(logits, logits, B * HW, HW, float(C) ** (-0.5))
         mixed = torch.empty(B, HW, C, device=dev, dtype=torch.float32)
-        _lib.gemm(logits, vt, out=mixed, M=HW, N=C, K=HW, lda=HW, ldb=HW, ldc=C, batch=B, stride_a=HW * HW,
-                  stride_b=C * HW, stride_c=HW * C, epilogue=_lib.make_epilogue(bias=bv))  # V bias after P.V: rows of P sum to 1
+        if pairs and _lib.attention256_ok(B, HW, C):
+            # one launch, the logits never written (csrc/attention.hip); (q * s) . (k * s) with s = ch^-1/4  ==  q . k * ch^-1/2
+            skey = (id(mod), "attn_scale")
+            if skey not in pk["lin"]:
+                gam = float(torch.sqrt((mod.norm.weight.detach().double() ** 2).mean() + (mod.norm.bias.detach().double() ** 2).mean()))
+                pk["lin"][skey] = (_lib.pairs_scale_from_rows(wqk, bqk, gam), _lib.pairs_scale_from_rows(wv, bv, gam))
+            s_qk, s_v = pk["lin"][skey]
+            _lib.attention256(qk, vt, mixed, B, C, s_qk, s_v, float(C) ** (-0.5), bias_v=bv)
+        else:
+            logits = torch.empty(B, HW, HW, device=dev, dtype=torch.float32)
+            _lib.gemm(qk, qk[:, C:], out=logits, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B,
+                      stride_a=HW * 2 * C, stride_b=HW * 2 * C, stride_c=HW * HW)
+            # (q * s) . (k * s) with s = ch^-1/4  ==  q . k * ch^-1/2
+            _lib.softmax_rows(logits, logits, B * HW, HW, float(C) ** (-0.5))
+            _lib.gemm(logits, vt, out=mixed, M=HW, N=C, K=HW, lda=HW, ldb=HW, ldc=C, batch=B, stride_a=HW * HW,
+                      stride_b=C * HW, stride_c=HW * C, epilogue=_lib.make_epilogue(bias=bv))  # V bias after P.V: rows of P sum to 1
         return self._pointwise(_T(mixed, x.H, x.W, C), wo, bo, residual=x.buf, stats=True)
 
     def _resample(self, mod, x, pk):

@@ -561,13 +561,23 @@ class NCSNpp(HipScoreModel):
         # V^T[b] = Wv^T-panel [C, Cin] x n[b]^T -> [C, HW], K-contiguous for the P.V product (bias deferred)
         vt = torch.empty(B, C, HW, device=dev, dtype=torch.float32)
         _lib.gemm_weight_times_normed_t(pk, wv, n.buf, vt, B, HW, C, pairs=pairs)
-        logits = torch.empty(B, HW, HW, device=dev, dtype=torch.float32)
-        _lib.gemm(qk, qk[:, C:], out=logits, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B,
-                  stride_a=HW * 2 * C, stride_b=HW * 2 * C, stride_c=HW * HW)
-        _lib.softmax_rows(logits, logits, B * HW, HW, float(int(C) ** (-0.5)))
         mixed = torch.empty(B, HW, C, device=dev, dtype=torch.float32)
-        _lib.gemm(logits, vt, out=mixed, M=HW, N=C, K=HW, lda=HW, ldb=HW, ldc=C, batch=B,
-                  stride_a=HW * HW, stride_b=C * HW, stride_c=HW * C, epilogue=_lib.make_epilogue(bias=bv))
+        if pairs and _lib.attention256_ok(B, HW, C):
+            # QK^T -> softmax -> PV in one launch, the logits never written (csrc/attention.hip); the operands' power-of-two scales from
+            # the projections' row norms (their input n has unit variance times gamma's scale)
+            key = (idx, "attn_scale")
+            if key not in pk["nin"]:
+                gam = float(torch.sqrt((mod.GroupNorm_0.weight.detach().double() ** 2).mean() + (mod.GroupNorm_0.bias.detach().double() ** 2).mean()))
+                pk["nin"][key] = (_lib.pairs_scale_from_rows(wqk, bqk, gam), _lib.pairs_scale_from_rows(wv, bv, gam))
+            s_qk, s_v = pk["nin"][key]
+            _lib.attention256(qk, vt, mixed, B, C, s_qk, s_v, float(int(C) ** (-0.5)), bias_v=bv)
+        else:
+            logits = torch.empty(B, HW, HW, device=dev, dtype=torch.float32)
+            _lib.gemm(qk, qk[:, C:], out=logits, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B,
+                      stride_a=HW * 2 * C, stride_b=HW * 2 * C, stride_c=HW * HW)
+            _lib.softmax_rows(logits, logits, B * HW, HW, float(int(C) ** (-0.5)))
+            _lib.gemm(logits, vt, out=mixed, M=HW, N=C, K=HW, lda=HW, ldb=HW, ldc=C, batch=B,
+                      stride_a=HW * HW, stride_b=C * HW, stride_c=HW * C, epilogue=_lib.make_epilogue(bias=bv))
         rs = _INV_SQRT2 if self.skip_rescale else 1.0
         return self._pointwise(_T(mixed, x.H, x.W, C), w3, b3, residual=x.buf, out_scale=rs, stats=True)
 

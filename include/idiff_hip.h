@@ -50,7 +50,7 @@ const char *idiff_variant_flags(void);
  * stream beside the next panel's factorisation; 5 % at D = 12288 when the helper gets a hardware queue of its own, 50 %
  * SLOWER when the runtime maps it onto the caller's queue, which happens once a process has made a few streams),
  * IDIFF_NO_WINO43 (3x3 convolutions on the F(2x2,3x3) kernel instead of F(4x4,3x3)), IDIFF_NO_WINO43H (F(4x4,3x3) with its
- * contractions on the fp32 matrix cores instead of fp16 pairs), IDIFF_NO_PAIRS (idiff_gemm_pairs_ok answers 0: the 1x1
+ * contractions on the fp32 matrix cores instead of fp16 pairs), IDIFF_NO_FUSED_ATTN (idiff_attention256_ok answers 0), IDIFF_NO_PAIRS (idiff_gemm_pairs_ok answers 0: the 1x1
  * projections behind a GroupNorm stay on idiff_gemm_f32's six-product form), IDIFF_PAIRS_MIN_TILES (tests: the number of 128 x 128
  * tiles from which idiff_gemm_pairs_ok answers 1; default 256).
  * Returns the previous value, -1 for an unknown name.  No reference counterpart. */
@@ -303,6 +303,21 @@ int idiff_groupnorm_apply_colstats_f32(const float *x, int C, const float *x2, i
 
 /* Row softmax of x [rows, cols] scaled by `scale` before the exponent (layerspp.py:82-84). In place allowed. */
 int idiff_softmax_rows_f32(const float *x, float *y, int64_t rows, int cols, float scale, void *stream);
+
+/* Single-head self-attention over 256 tokens in ONE launch, the [256, 256] logits never leaving the chip (models/layerspp.py:75-91:
+ * w = einsum(q, k) * C^-1/2 -> softmax -> einsum(w, v); models/BeatGANsblocks.py:466-491, one head):
+ *     out[b, i, :] = sum_j softmax_j(q[b, i] . k[b, j] * scale) v[b, j, :]  (+ bias_v)
+ * qk: [B * 256, ld_qk] with q in columns [0, C) and k in [C, 2 C) (the stacked projection the executors already make); vt: V^T as
+ * [B, C, 256] (idiff_gemm_*'s weight-times-activation form); out: [B * 256, C].  Both contractions run on fp16 PAIRS (22
+ * significand bits, 3 products, fp32 accumulation -- idiff_gemm_pairs_f32's arithmetic), the softmax in fp32.  s_qk / s_v: DEVICE
+ * pointers to {s, 1 / s}, the power of two q and k / v are multiplied by before their cut (the caller derives them once per weight:
+ * the projections' inputs are GroupNorm outputs); s |q|, s |k|, s |v| must stay below 65504 -- beyond it the outputs are NaN,
+ * never finite-and-wrong.  idiff_attention256_ok: 1 for tokens == 256 and C in {128, 256}, 0 otherwise and under
+ * IDIFF_NO_FUSED_ATTN / IDIFF_NO_PAIRS / IDIFF_NO_SPLIT (the callers then run the three-launch form on idiff_gemm_f32).
+ * All pointers 16-byte aligned, ld_qk a multiple of 4. */
+int idiff_attention256_ok(int B, int tokens, int C);
+int idiff_attention256_f32(const float *qk, int64_t ld_qk, const float *vt, const float *bias_v, const float *s_qk, const float *s_v,
+                           float *out, int B, int tokens, int C, float scale, void *stream);
 
 /* y = act(a * alpha + beta_const) elementwise; covers `2*x - 1` (models/ncsnpp.py:264-266), SiLU/ELU of the
  * time embedding, and -out/std when `rowscale` ([n / inner]) is given: y = act(...) * rowscale[i / inner]. */

@@ -223,6 +223,73 @@ def test_gemm_pairs_weight_on_the_left_batched():
     assert rel_err(vt.cpu(), ref) < 3 * rel_err(six.cpu(), ref) + 1e-7
 
 
+@pytest.mark.parametrize("B,C,qk_gain", [(3, 256, 1.0), (5, 128, 1.0), (2, 256, 6.0), (2, 256, 0.05)])
+def test_attention256_vs_fp64(B, C, qk_gain):
+    """idiff_attention256_f32 (QK^T -> softmax -> PV in one launch, logits on chip, both contractions on fp16 pairs) against fp64 of the same
+    fp32 q, k, v, beside the three-launch form on the six-product GEMM.  Operands as the executors produce them: q | k and V^T projected
+    from a GroupNorm's output by weights of different gains (qk_gain 6: peaked softmax rows, logits up to +-60; 0.05: nearly uniform rows),
+    the operands' power-of-two scales from the projections' row norms (pairs_scale_from_rows).  Reference: layerspp.py:75-91."""
+    assert _lib.attention256_ok(B, 256, C)
+    g = torch.Generator().manual_seed(int(100 * qk_gain) + C + B)
+    HW = 256
+    n = F.group_norm(torch.randn(B, C, HW, generator=g) * 3 + 1, 32, torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2)
+    n = n.permute(0, 2, 1).contiguous()                                                   # [B, HW, C]
+    wqk = torch.randn(2 * C, C, generator=g) * (qk_gain / C ** 0.5)
+    bqk = torch.randn(2 * C, generator=g) * 0.1
+    wv, bv = torch.randn(C, C, generator=g) * (0.7 / C ** 0.5), torch.randn(C, generator=g) * 0.1
+    qk = (n.reshape(-1, C) @ wqk.T + bqk).contiguous()                                    # fp32 operands, as the projection GEMM leaves them
+    vt = torch.einsum("oc,bpc->bop", wv, n).contiguous()                                  # [B, C, HW], bias deferred
+    scale = float(C) ** -0.5
+    q64, k64 = qk[:, :C].double().reshape(B, HW, C), qk[:, C:].double().reshape(B, HW, C)
+    logits = torch.einsum("bic,bjc->bij", q64, k64) * scale
+    ref = torch.einsum("bij,bcj->bic", torch.softmax(logits, dim=-1), vt.double()) + bv.double()
+    qkd, vtd, bvd = qk.to(DEV), vt.to(DEV), bv.to(DEV)
+    gam = float(torch.sqrt((n.double() ** 2).mean()))
+    s_qk, s_v = _lib.pairs_scale_from_rows(wqk.to(DEV), bqk.to(DEV), gam), _lib.pairs_scale_from_rows(wv.to(DEV), bvd, gam)
+    for sc in (s_qk, s_v):
+        a, b_ = sc.cpu().tolist()
+        assert a * b_ == 1.0 and np.log2(a) == round(np.log2(a))
+    assert 0.5 <= float(qk.double().pow(2).mean().sqrt()) * s_qk[0].item() <= 2.0        # the estimate from the weights alone lands near one
+    out = torch.full((B * HW, C), float("nan"), device=DEV)
+    _lib.attention256(qkd, vtd, out, B, C, s_qk, s_v, scale, bias_v=bvd)
+    # the three-launch form on the same operands
+    lg = torch.empty(B, HW, HW, device=DEV)
+    _lib.gemm(qkd, qkd[:, C:], out=lg, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B, stride_a=HW * 2 * C, stride_b=HW * 2 * C, stride_c=HW * HW)
+    _lib.softmax_rows(lg, lg, B * HW, HW, scale)
+    three = torch.empty(B, HW, C, device=DEV)
+    _lib.gemm(lg, vtd, out=three, M=HW, N=C, K=HW, lda=HW, ldb=HW, ldc=C, batch=B, stride_a=HW * HW, stride_b=C * HW, stride_c=HW * C,
+              epilogue=_lib.make_epilogue(bias=bvd))
+    e_fused, e_three = rel_err(out.cpu().reshape(B, HW, C), ref), rel_err(three.cpu(), ref)
+    print(f"attention256 B={B} C={C} gain={qk_gain}: fused {e_fused:.2e}, three launches {e_three:.2e}, max |logit| {float(logits.abs().max()):.1f}")
+    assert e_fused < 2e-6 and e_fused < 3 * e_three + 2e-7, (e_fused, e_three)
+    # without the bias: the contraction's own error, no O(1) term beside it
+    _lib.attention256(qkd, vtd, out, B, C, s_qk, s_v, scale)
+    assert rel_err(out.cpu().reshape(B, HW, C), ref - bv.double()) < 3e-6
+
+
+def test_attention256_limits():
+    """What the one-launch attention refuses (the callers then take the three-launch form), its switches, and its documented failure:
+    operands beyond the fp16 range give NaN, never finite wrong numbers."""
+    assert _lib.attention256_ok(7, 256, 256) and _lib.attention256_ok(7, 256, 128)
+    assert not _lib.attention256_ok(7, 64, 256) and not _lib.attention256_ok(7, 256, 96) and not _lib.attention256_ok(7, 16, 256)
+    for name in ("IDIFF_NO_FUSED_ATTN", "IDIFF_NO_PAIRS", "IDIFF_NO_SPLIT"):
+        with _lib.thread_option(name, 1):
+            assert not _lib.attention256_ok(7, 256, 256)
+    B, C = 2, 256
+    g = torch.Generator().manual_seed(0)
+    qk, vt = torch.randn(B * 256, 2 * C, generator=g).to(DEV), torch.randn(B, C, 256, generator=g).to(DEV)
+    one = torch.tensor([1.0, 1.0], device=DEV)
+    out = torch.empty(B * 256, C, device=DEV)
+    with pytest.raises(RuntimeError, match="shapes"):
+        _lib.attention256(qk[:, :C].contiguous(), vt, out, B, C, one, one, 1 / 16)
+    _lib.attention256(qk, vt * 1e6, out, B, C, one, one, 1 / 16)                            # s |v| beyond 65504
+    assert not bool(torch.isfinite(out).all())
+    _lib.attention256(qk, vt * 1e6, out, B, C, one, torch.tensor([2.0 ** -20, 2.0 ** 20], device=DEV), 1 / 16)   # the same values with their scale
+    ref = torch.einsum("bij,bcj->bic", torch.softmax(torch.einsum("bic,bjc->bij", qk[:, :C].double().reshape(B, 256, C).cpu(),
+                                                                  qk[:, C:].double().reshape(B, 256, C).cpu()) / 16, dim=-1), (vt * 1e6).double().cpu())
+    assert rel_err(out.cpu().reshape(B, 256, C), ref) < 3e-6
+
+
 @pytest.mark.parametrize("mag", [1e-4, 1.0, 3e3])
 def test_gemm_pairs_with_activation_scale_two_sources(mag):
     """Operands that are NOT a GroupNorm's output (the residual stream of a U-Net block and its skip connection) at any magnitude:
