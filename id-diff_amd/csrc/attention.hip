@@ -9,7 +9,7 @@
 // row norms: their input is a GroupNorm's output), for the softmax rows 2^10 (they lie in [0, 1]).  Softmax itself in fp32 (expf).
 // Range: |s q|, |s k|, |s v| must stay below 65504 or the outputs are NaN -- the drivers re-run such a point on the fp32 route.
 //
-// Work split: a workgroup = (sample, 64 queries), four waves of 16 queries; all 256 keys / values of the sample pass through LDS once per
+// Work split: a workgroup = (sample, 128 queries), eight waves of 16 queries; all 256 keys / values of the sample pass through LDS once per
 // workgroup in 32-wide chunks (K: 32 channels of all keys; V^T: 32 keys of all channels), converted to pairs on the way in.
 //   phase 1  S^T[key, q] = sum_c K[key, c] Q[q, c]      A = K chunk (LDS), B = Q (registers, straight from global), 16 key blocks
 //   softmax  the 256 logits of query q sit in lanes q, q + 16, q + 32, q + 48 (64 registers each): in-lane reductions + two shuffles;
@@ -17,7 +17,8 @@
 //            be any fixed permutation of the keys as long as A uses the same one: k slot (g, j) = key 16 (2 m + j / 4) + 4 g + j % 4)
 //   phase 2  O^T[c, q] = sum_key V^T[c, key] P[key, q]   A = V^T chunk (LDS, keys stored in that slot order), B = P (registers)
 // LDS: two chunk buffers of 32 KB (hi plane | lo plane, 64 B per row, 16-byte pieces XOR-swizzled by (row >> 2) & 3: conflict-free
-// ds_read_b128); 64 KB per workgroup, two workgroups per CU.
+// ds_read_b128); 64 KB per workgroup.  The operands' conversion to pairs is vector-ALU work every workgroup of a sample repeats, so a
+// workgroup takes as many queries as the register file allows (8 waves x 224 registers).
 #include "common.h"
 
 namespace {
@@ -27,7 +28,8 @@ typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int AT_T = 256;                       // tokens
-constexpr int AT_BQ = 64;                       // queries per workgroup
+constexpr int AT_BQ = 128;                      // queries per workgroup (eight waves of 16)
+constexpr int AT_THREADS = 512;
 constexpr int AT_PLANE = AT_T * 64;             // bytes: 256 rows x 32 halves
 constexpr int AT_CHUNK = 2 * AT_PLANE;          // hi | lo
 constexpr int AT_LDS = 2 * AT_CHUNK;            // two buffers: 65,536 B
@@ -45,15 +47,30 @@ struct AttnParams {
   float scale;            // softmax scale (C^-1/2)
 };
 
-// s v -> (hi, lo) for four values
-__device__ __forceinline__ void cut4(const float4 v, const float s, halfx4 &hi, halfx4 &lo) {
-  const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
-  hi = halfx4{(_Float16)x0, (_Float16)x1, (_Float16)x2, (_Float16)x3};
-  lo = halfx4{(_Float16)(x0 - (float)hi[0]), (_Float16)(x1 - (float)hi[1]), (_Float16)(x2 - (float)hi[2]), (_Float16)(x3 - (float)hi[3])};
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+// s v -> (hi, lo) for two values: one packed conversion, the residual s v - hi in ONE mixed-precision instruction per value (fp32 x fp32 +
+// fp16, exact), one more packed conversion -- five vector instructions per two values where the plain form takes eight
+__device__ __forceinline__ void cut2(const float a, const float b, const float s, uint32_t &hi, uint32_t &lo) {
+  const f2 x = {a * s, b * s};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, h2));
+  f2 rest;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rest.x) : "v"(hi), "v"(x.x));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest.y) : "v"(hi), "v"(x.y));
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, h2));
+}
+typedef uint32_t uintx2 __attribute__((ext_vector_type(2)));
+typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void cut4(const float4 v, const float s, uintx2 &hi, uintx2 &lo) {
+  uint32_t h0, l0, h1, l1;
+  cut2(v.x, v.y, s, h0, l0);
+  cut2(v.z, v.w, s, h1, l1);
+  hi = uintx2{h0, h1}; lo = uintx2{l0, l1};
 }
 
 template <int C>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(AT_THREADS, 2)
 attention256_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char at_lds[];
   constexpr int NKC = C / 32;                   // channel chunks of phase 1
@@ -62,31 +79,31 @@ attention256_kernel(const AttnParams p) {
   static_assert(C % 32 == 0 && C >= 64 && C <= 256, "channels: a multiple of 32 in [64, 256]");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // the four workgroups of a sample read the same K and V: give them consecutive slots on ONE XCD (workgroups are dealt round-robin
+  // the two workgroups of a sample read the same K and V: give them consecutive slots on ONE XCD (workgroups are dealt round-robin
   // over the 8 XCDs, each with its own L2), so that one of them pulls the sample's rows from HBM and the others find them in that L2
   int bid = blockIdx.x;
   {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  const int b = bid >> 2, q0 = (bid & 3) * AT_BQ + wave * 16;
+  const int b = bid >> 1, q0 = (bid & 1) * AT_BQ + wave * 16;
   const int l15 = lane & 15, g = lane >> 4;
   const float s_qk = p.s_qk[0], inv_qk = p.s_qk[1], s_v = p.s_v[0], inv_v = p.s_v[1];
 
-  // ---- staging: thread (row r0 = tid / 8, piece = tid % 8) moves 16 bytes = 4 fp32 of rows r0, r0 + 32, ... per chunk
+  // ---- staging: thread (row r0 = tid / 8, piece = tid % 8) moves 16 bytes = 4 fp32 of rows r0, r0 + 64, ... per chunk
   const int piece = tid & 7, r0 = tid >> 3;
-  const float *k_src = p.qk + ((int64_t)b * AT_T + r0) * p.ld_qk + C + 4 * piece;          // + 32 kc, rows step 32 ld
-  const float *v_src = p.vt + ((int64_t)b * C + r0) * AT_T + 4 * piece;                     // + 32 m, rows step 32 * 256
-  float4 st[8];
+  const float *k_src = p.qk + ((int64_t)b * AT_T + r0) * p.ld_qk + C + 4 * piece;          // + 32 kc, rows step 64 ld
+  const float *v_src = p.vt + ((int64_t)b * C + r0) * AT_T + 4 * piece;                     // + 32 m, rows step 64 * 256
+  float4 st[4];
   auto fetch = [&](int step) __attribute__((always_inline)) {   // chunk `step`: K chunks 0 .. NKC - 1, then V chunks
     if (step < NKC) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) st[r] = *reinterpret_cast<const float4 *>(k_src + (int64_t)(32 * r) * p.ld_qk + 32 * step);
+      for (int r = 0; r < 4; ++r) st[r] = *reinterpret_cast<const float4 *>(k_src + (int64_t)(64 * r) * p.ld_qk + 32 * step);
     } else {
       const int m = step - NKC;
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (32 * r + r0 < C) st[r] = *reinterpret_cast<const float4 *>(v_src + (int64_t)(32 * r) * AT_T + 32 * m);
+      for (int r = 0; r < 4; ++r)
+        if (64 * r + r0 < C) st[r] = *reinterpret_cast<const float4 *>(v_src + (int64_t)(64 * r) * AT_T + 32 * m);
     }
   };
   // K rows: pieces 2 c16, 2 c16 + 1 make the 16-byte piece c16 (channels 8 c16 .. 8 c16 + 7).  V^T rows: the row's 32 keys are stored in
@@ -98,12 +115,12 @@ attention256_kernel(const AttnParams p) {
     const float s = step < NKC ? s_qk : s_v;
     const int rows = step < NKC ? AT_T : C;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if (32 * r + r0 < rows) {                  // (row + 32 r) >> 2 & 3 == r0 >> 2 & 3: the swizzle does not change with r
-        halfx4 hi, lo;
+    for (int r = 0; r < 4; ++r) {
+      if (64 * r + r0 < rows) {                  // (row + 64 r) >> 2 & 3 == r0 >> 2 & 3: the swizzle does not change with r
+        uintx2 hi, lo;
         cut4(st[r], s, hi, lo);
-        *reinterpret_cast<halfx4 *>(dst + r * 32 * 64) = hi;
-        *reinterpret_cast<halfx4 *>(dst + r * 32 * 64 + AT_PLANE) = lo;
+        *reinterpret_cast<uintx2 *>(dst + r * 64 * 64) = hi;
+        *reinterpret_cast<uintx2 *>(dst + r * 64 * 64 + AT_PLANE) = lo;
       }
     }
   };
@@ -129,10 +146,10 @@ attention256_kernel(const AttnParams p) {
     halfx8 qh, ql;
     {
       const float4 a = *reinterpret_cast<const float4 *>(q_src + 32 * kc), c = *reinterpret_cast<const float4 *>(q_src + 32 * kc + 4);
-      halfx4 h0, l0, h1, l1;
+      uintx2 h0, l0, h1, l1;
       cut4(a, s_qk, h0, l0); cut4(c, s_qk, h1, l1);
-      qh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-      ql = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      qh = __builtin_bit_cast(halfx8, uintx4{h0.x, h0.y, h1.x, h1.y});
+      ql = __builtin_bit_cast(halfx8, uintx4{l0.x, l0.y, l1.x, l1.y});
     }
     const int buf = kc & 1;
 #pragma unroll
@@ -150,7 +167,9 @@ attention256_kernel(const AttnParams p) {
   // ---- softmax over the 256 keys of query l15 (this lane: 64 of them; lanes l15 + 16 g' the rest)
   halfx8 ph[NVC], pl[NVC];
   {
-    const float sc = p.scale * inv_qk * inv_qk;  // logits = S / s^2 * scale
+    // logits = S / s^2 * scale; exp(x) = 2^(x log2 e) on v_exp_f32 (1 ulp; the rounding of the product matters only where the result is
+    // tiny: 6e-8 |x| relative)
+    const float sc = p.scale * inv_qk * inv_qk * 1.44269504088896340736f;
     float m = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
@@ -162,17 +181,17 @@ attention256_kernel(const AttnParams p) {
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const float e = expf((sacc[kb][i] - m) * sc); sacc[kb][i] = e; sum += e; }
+      for (int i = 0; i < 4; ++i) { const float e = __builtin_amdgcn_exp2f((sacc[kb][i] - m) * sc); sacc[kb][i] = e; sum += e; }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = AT_PSCALE / sum;
 #pragma unroll
     for (int m2 = 0; m2 < NVC; ++m2) {
-      halfx4 h0, l0, h1, l1;
+      uintx2 h0, l0, h1, l1;
       cut4(make_float4(sacc[2 * m2][0], sacc[2 * m2][1], sacc[2 * m2][2], sacc[2 * m2][3]), inv, h0, l0);
       cut4(make_float4(sacc[2 * m2 + 1][0], sacc[2 * m2 + 1][1], sacc[2 * m2 + 1][2], sacc[2 * m2 + 1][3]), inv, h1, l1);
-      ph[m2] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-      pl[m2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      ph[m2] = __builtin_bit_cast(halfx8, uintx4{h0.x, h0.y, h1.x, h1.y});
+      pl[m2] = __builtin_bit_cast(halfx8, uintx4{l0.x, l0.y, l1.x, l1.y});
     }
   }
 
@@ -214,7 +233,7 @@ int launch_attention(const AttnParams &p, hipStream_t st) {
   static idiff::AttrGuard guard;
   const void *fn = reinterpret_cast<const void *>(attention256_kernel<C>);
   if (int rc = idiff::set_dynamic_lds_once(guard, &fn, 1, AT_LDS, "attention256")) return rc;
-  hipLaunchKernelGGL(attention256_kernel<C>, dim3(p.B * (AT_T / AT_BQ)), dim3(256), AT_LDS, st, p);
+  hipLaunchKernelGGL(attention256_kernel<C>, dim3(p.B * (AT_T / AT_BQ)), dim3(AT_THREADS), AT_LDS, st, p);
   return idiff::launch_status("attention256");
 }
 
