@@ -136,21 +136,29 @@ attention256_kernel(const AttnParams p) {
     return at_lds + buf * AT_CHUNK + rb * 16 * 64 + a_off + ((g ^ ((row >> 2) & 3)) << 4);
   };
 
+  halfx8 qh, ql;
+  float4 qa, qb;                                 // the next chunk's queries, requested one step ahead like the K / V chunks
+  auto q_fetch = [&](int kc) __attribute__((always_inline)) {
+    qa = *reinterpret_cast<const float4 *>(q_src + 32 * kc); qb = *reinterpret_cast<const float4 *>(q_src + 32 * kc + 4);
+  };
+  auto q_cut = [&]() __attribute__((always_inline)) {
+    uintx2 h0, l0, h1, l1;
+    cut4(qa, s_qk, h0, l0); cut4(qb, s_qk, h1, l1);
+    qh = __builtin_bit_cast(halfx8, uintx4{h0.x, h0.y, h1.x, h1.y});
+    ql = __builtin_bit_cast(halfx8, uintx4{l0.x, l0.y, l1.x, l1.y});
+  };
   fetch(0);
+  q_fetch(0);
   stash(0);
+  q_cut();
   __syncthreads();
-  // ---- phase 1
+  // ---- phase 1.  The loads of step kc + 1 are REQUESTED before the matrix instructions of step kc and consumed behind them (the
+  // scheduling fences keep the compiler from sinking the requests down to their first use, which would expose their whole latency)
 #pragma unroll 1
   for (int kc = 0; kc < NKC; ++kc) {
-    fetch(kc + 1);                               // the next chunk (the first V chunk after the last K chunk) flies beside the contraction
-    halfx8 qh, ql;
-    {
-      const float4 a = *reinterpret_cast<const float4 *>(q_src + 32 * kc), c = *reinterpret_cast<const float4 *>(q_src + 32 * kc + 4);
-      uintx2 h0, l0, h1, l1;
-      cut4(a, s_qk, h0, l0); cut4(c, s_qk, h1, l1);
-      qh = __builtin_bit_cast(halfx8, uintx4{h0.x, h0.y, h1.x, h1.y});
-      ql = __builtin_bit_cast(halfx8, uintx4{l0.x, l0.y, l1.x, l1.y});
-    }
+    fetch(kc + 1);                               // the next chunk (the first V chunk after the last K chunk)
+    if (kc + 1 < NKC) q_fetch(kc + 1);
+    __builtin_amdgcn_sched_barrier(0);
     const int buf = kc & 1;
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
@@ -160,7 +168,9 @@ attention256_kernel(const AttnParams p) {
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, sacc[kb], 0, 0, 0);
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, sacc[kb], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     stash(kc + 1);
+    if (kc + 1 < NKC) q_cut();
     __syncthreads();
   }
 
@@ -203,6 +213,7 @@ attention256_kernel(const AttnParams p) {
   for (int m2 = 0; m2 < NVC; ++m2) {
     const int step = NKC + m2, buf = step & 1;
     if (m2 + 1 < NVC) fetch(step + 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       const char *ap = a_addr(buf, cb);
@@ -211,6 +222,7 @@ attention256_kernel(const AttnParams p) {
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[m2], oacc[cb], 0, 0, 0);
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[m2], oacc[cb], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (m2 + 1 < NVC) { stash(step + 1); __syncthreads(); }
   }
 

@@ -261,7 +261,8 @@ def test_attention256_vs_fp64(B, C, qk_gain):
               epilogue=_lib.make_epilogue(bias=bvd))
     e_fused, e_three = rel_err(out.cpu().reshape(B, HW, C), ref), rel_err(three.cpu(), ref)
     print(f"attention256 B={B} C={C} gain={qk_gain}: fused {e_fused:.2e}, three launches {e_three:.2e}, max |logit| {float(logits.abs().max()):.1f}")
-    assert e_fused < 2e-6 and e_fused < 3 * e_three + 2e-7, (e_fused, e_three)
+    # (logits of +-60 kept in fp32 cost both forms ~3e-6: 6e-8 x 60; the bar is the three-launch form's own error)
+    assert e_fused < max(2e-6, 1.2 * e_three) and e_fused < 3 * e_three + 2e-7, (e_fused, e_three)
     # without the bias: the contraction's own error, no O(1) term beside it
     _lib.attention256(qkd, vtd, out, B, C, s_qk, s_v, scale)
     assert rel_err(out.cpu().reshape(B, HW, C), ref - bv.double()) < 3e-6
