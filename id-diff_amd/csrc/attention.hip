@@ -100,8 +100,11 @@ attention256_kernel(const AttnParams p) {
   const int piece = tid & 7, r0 = tid >> 3;
   const float *k_src = p.qk + ((int64_t)b * AT_T + r0) * p.ld_qk + C + 4 * piece;          // + 32 kc, rows step 64 ld
   const float *v_src = p.vt + ((int64_t)b * C + r0) * AT_T + 4 * piece;                     // + 32 m, rows step 64 * 256
-  float4 st[4];
-  auto fetch = [&](int step) __attribute__((always_inline)) {   // chunk `step`: K chunks 0 .. NKC - 1, then V chunks
+  // st: the chunk of the NEXT step (requested one step ago), st2: the one after it (requested at the start of this step): a request has
+  // about 1.75 steps to arrive.  With one step of lead the waves sat at s_waitcnt for two thirds of their life (SQ_WAIT_ANY 66 %).
+  float4 st[4], st2[4];
+  auto fetch = [&](int step, float4 (&st)[4]) __attribute__((always_inline)) {   // chunk `step`: K chunks 0 .. NKC - 1, then V chunks
+    if (step >= NKC + NVC) return;
     if (step < NKC) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) st[r] = *reinterpret_cast<const float4 *>(k_src + (int64_t)(64 * r) * p.ld_qk + 32 * step);
@@ -116,7 +119,7 @@ attention256_kernel(const AttnParams p) {
   // matrix-instruction slot order: key 16 h + 4 gq + i (piece = 4 h + gq) -> 16-byte piece gq, half h.
   const int k_off = (((piece >> 1) ^ at_swz(r0)) << 4) + (piece & 1) * 8;
   const int v_off = (((piece & 3) ^ at_swz(r0)) << 4) + (piece >> 2) * 8;
-  auto stash = [&](int step) __attribute__((always_inline)) {
+  auto stash = [&](int step, const float4 (&st)[4]) __attribute__((always_inline)) {
     char *dst = at_lds + (step & 1) * AT_CHUNK + r0 * 64 + (step < NKC ? k_off : v_off);
     const float s = step < NKC ? s_qk : s_v;
     const int rows = step < NKC ? AT_T : C;
@@ -143,9 +146,9 @@ attention256_kernel(const AttnParams p) {
   };
 
   halfx8 qh, ql;
-  float4 qa, qb;                                 // the next chunk's queries, requested one step ahead like the K / V chunks
-  auto q_fetch = [&](int kc) __attribute__((always_inline)) {
-    qa = *reinterpret_cast<const float4 *>(q_src + 32 * kc); qb = *reinterpret_cast<const float4 *>(q_src + 32 * kc + 4);
+  float4 qa, qb, qa2, qb2;                       // the queries of the next chunk and of the one after it, like st / st2
+  auto q_fetch = [&](int kc, float4 &a, float4 &c) __attribute__((always_inline)) {
+    if (kc < NKC) { a = *reinterpret_cast<const float4 *>(q_src + 32 * kc); c = *reinterpret_cast<const float4 *>(q_src + 32 * kc + 4); }
   };
   auto q_cut = [&]() __attribute__((always_inline)) {
     uintx2 h0, l0, h1, l1;
@@ -153,17 +156,18 @@ attention256_kernel(const AttnParams p) {
     qh = __builtin_bit_cast(halfx8, uintx4{h0.x, h0.y, h1.x, h1.y});
     ql = __builtin_bit_cast(halfx8, uintx4{l0.x, l0.y, l1.x, l1.y});
   };
-  fetch(0);
-  q_fetch(0);
-  stash(0);
+  fetch(0, st);
+  q_fetch(0, qa, qb);
+  stash(0, st);
   q_cut();
+  fetch(1, st);
+  q_fetch(1, qa, qb);
   __syncthreads();
-  // ---- phase 1.  The loads of step kc + 1 are REQUESTED before the matrix instructions of step kc and consumed behind them (the
-  // scheduling fences keep the compiler from sinking the requests down to their first use, which would expose their whole latency)
+  // ---- phase 1.  The scheduling fences keep the compiler from sinking the requests down to their first use.
 #pragma unroll 1
   for (int kc = 0; kc < NKC; ++kc) {
-    fetch(kc + 1);                               // the next chunk (the first V chunk after the last K chunk)
-    if (kc + 1 < NKC) q_fetch(kc + 1);
+    fetch(kc + 2, st2);
+    q_fetch(kc + 2, qa2, qb2);
     __builtin_amdgcn_sched_barrier(0);
     const int buf = kc & 1;
     // the conversion of the next chunk goes in front of the last quarter of the matrix block: its vector instructions issue in the
@@ -171,13 +175,16 @@ attention256_kernel(const AttnParams p) {
     const halfx8 qh0 = qh, ql0 = ql;
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
-      if (kb == 12) { stash(kc + 1); if (kc + 1 < NKC) q_cut(); }
+      if (kb == 12) { stash(kc + 1, st); if (kc + 1 < NKC) q_cut(); }
       const char *ap = a_addr(buf, kb);
       const halfx8 kh = *reinterpret_cast<const halfx8 *>(ap), kl = *reinterpret_cast<const halfx8 *>(ap + AT_PLANE);
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh0, sacc[kb], 0, 0, 0);
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql0, sacc[kb], 0, 0, 0);
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh0, sacc[kb], 0, 0, 0);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st[r] = st2[r];
+    qa = qa2; qb = qb2;
     __syncthreads();
   }
 
@@ -219,17 +226,19 @@ attention256_kernel(const AttnParams p) {
 #pragma unroll
   for (int m2 = 0; m2 < NVC; ++m2) {
     const int step = NKC + m2, buf = step & 1;
-    if (m2 + 1 < NVC) fetch(step + 1);
+    fetch(step + 2, st2);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-      if (cb == (3 * NCB) / 4 && m2 + 1 < NVC) stash(step + 1);
+      if (cb == (3 * NCB) / 4 && m2 + 1 < NVC) stash(step + 1, st);
       const char *ap = a_addr(buf, cb);
       const halfx8 vh = *reinterpret_cast<const halfx8 *>(ap), vl = *reinterpret_cast<const halfx8 *>(ap + AT_PLANE);
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[m2], oacc[cb], 0, 0, 0);
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[m2], oacc[cb], 0, 0, 0);
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[m2], oacc[cb], 0, 0, 0);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st[r] = st2[r];
     if (m2 + 1 < NVC) __syncthreads();
   }
 
