@@ -163,11 +163,11 @@ attention256_kernel(const AttnParams p) {
   fetch(1, st);
   q_fetch(1, qa, qb);
   __syncthreads();
-  // ---- phase 1.  The scheduling fences keep the compiler from sinking the requests down to their first use.
-#pragma unroll 1
-  for (int kc = 0; kc < NKC; ++kc) {
-    fetch(kc + 2, st2);
-    q_fetch(kc + 2, qa2, qb2);
+  // ---- phase 1.  The scheduling fences keep the compiler from sinking the requests down to their first use.  Two steps per trip: the
+  // register sets swap ROLES (a copy st = st2 at the end of a step would wait for the request made at its start).
+  auto qk_step = [&](int kc, float4 (&cur)[4], float4 (&far)[4], float4 &ca, float4 &cb, float4 &fa, float4 &fb) __attribute__((always_inline)) {
+    fetch(kc + 2, far);
+    q_fetch(kc + 2, fa, fb);
     __builtin_amdgcn_sched_barrier(0);
     const int buf = kc & 1;
     // the conversion of the next chunk goes in front of the last quarter of the matrix block: its vector instructions issue in the
@@ -175,17 +175,28 @@ attention256_kernel(const AttnParams p) {
     const halfx8 qh0 = qh, ql0 = ql;
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
-      if (kb == 12) { stash(kc + 1, st); if (kc + 1 < NKC) q_cut(); }
+      if (kb == 12) {
+        stash(kc + 1, cur);
+        if (kc + 1 < NKC) {
+          uintx2 h0, l0, h1, l1;
+          cut4(ca, s_qk, h0, l0); cut4(cb, s_qk, h1, l1);
+          qh = __builtin_bit_cast(halfx8, uintx4{h0.x, h0.y, h1.x, h1.y});
+          ql = __builtin_bit_cast(halfx8, uintx4{l0.x, l0.y, l1.x, l1.y});
+        }
+      }
       const char *ap = a_addr(buf, kb);
       const halfx8 kh = *reinterpret_cast<const halfx8 *>(ap), kl = *reinterpret_cast<const halfx8 *>(ap + AT_PLANE);
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh0, sacc[kb], 0, 0, 0);
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql0, sacc[kb], 0, 0, 0);
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh0, sacc[kb], 0, 0, 0);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st[r] = st2[r];
-    qa = qa2; qb = qb2;
     __syncthreads();
+  };
+  static_assert(NKC % 2 == 0 && NVC % 2 == 0, "the register sets alternate: an even number of steps per phase");
+#pragma unroll 1
+  for (int kc = 0; kc < NKC; kc += 2) {
+    qk_step(kc, st, st2, qa, qb, qa2, qb2);
+    qk_step(kc + 1, st2, st, qa2, qb2, qa, qb);
   }
 
   // ---- softmax over the 256 keys of query l15 (this lane: 64 of them; lanes l15 + 16 g' the rest)
@@ -223,23 +234,25 @@ attention256_kernel(const AttnParams p) {
   floatx4 oacc[NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) oacc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int m2 = 0; m2 < NVC; ++m2) {
+  auto pv_step = [&](int m2, float4 (&cur)[4], float4 (&far)[4]) __attribute__((always_inline)) {
     const int step = NKC + m2, buf = step & 1;
-    fetch(step + 2, st2);
+    fetch(step + 2, far);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-      if (cb == (3 * NCB) / 4 && m2 + 1 < NVC) stash(step + 1, st);
+      if (cb == (3 * NCB) / 4 && m2 + 1 < NVC) stash(step + 1, cur);
       const char *ap = a_addr(buf, cb);
       const halfx8 vh = *reinterpret_cast<const halfx8 *>(ap), vl = *reinterpret_cast<const halfx8 *>(ap + AT_PLANE);
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[m2], oacc[cb], 0, 0, 0);
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[m2], oacc[cb], 0, 0, 0);
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[m2], oacc[cb], 0, 0, 0);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st[r] = st2[r];
     if (m2 + 1 < NVC) __syncthreads();
+  };
+#pragma unroll
+  for (int m2 = 0; m2 < NVC; m2 += 2) {
+    pv_step(m2, st, st2);
+    pv_step(m2 + 1, st2, st);
   }
 
   // ---- output: lane (query l15, g) holds channels 16 cb + 4 g + i
