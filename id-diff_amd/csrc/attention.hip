@@ -103,29 +103,31 @@ attention256_kernel(const AttnParams p) {
   // st: the chunk of the NEXT step (requested one step ago), st2: the one after it (requested at the start of this step): a request has
   // about 1.75 steps to arrive.  With one step of lead the waves sat at s_waitcnt for two thirds of their life (SQ_WAIT_ANY 66 %).
   float4 st[4], st2[4];
+  // Branch-free on purpose: behind a conditional request the compiler's wait-count bookkeeping falls back to "wait for everything", which
+  // exposes the latency of the request made at the start of the step.  Requests past the last chunk (and V rows beyond C) re-read a valid
+  // address and are never stored.
   auto fetch = [&](int step, float4 (&st)[4]) __attribute__((always_inline)) {   // chunk `step`: K chunks 0 .. NKC - 1, then V chunks
-    if (step >= NKC + NVC) return;
-    if (step < NKC) {
+    const int sc = step < NKC + NVC ? step : NKC + NVC - 1;
+    const bool is_k = sc < NKC;
+    const float *src = is_k ? k_src + 32 * sc : v_src + 32 * (sc - NKC);
+    const int64_t stride = is_k ? 64 * p.ld_qk : (int64_t)64 * AT_T;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) st[r] = *reinterpret_cast<const float4 *>(k_src + (int64_t)(64 * r) * p.ld_qk + 32 * step);
-    } else {
-      const int m = step - NKC;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (64 * r + r0 < C) st[r] = *reinterpret_cast<const float4 *>(v_src + (int64_t)(64 * r) * AT_T + 32 * m);
-    }
+    for (int r = 0; r < 4; ++r) st[r] = *reinterpret_cast<const float4 *>(src + (is_k ? r : r % (C / 64)) * stride);
   };
   // K rows: pieces 2 c16, 2 c16 + 1 make the 16-byte piece c16 (channels 8 c16 .. 8 c16 + 7).  V^T rows: the row's 32 keys are stored in
   // matrix-instruction slot order: key 16 h + 4 gq + i (piece = 4 h + gq) -> 16-byte piece gq, half h.
   const int k_off = (((piece >> 1) ^ at_swz(r0)) << 4) + (piece & 1) * 8;
   const int v_off = (((piece & 3) ^ at_swz(r0)) << 4) + (piece >> 2) * 8;
-  auto stash = [&](int step, const float4 (&st)[4]) __attribute__((always_inline)) {
+  // pins a requested value to the point where it is consumed: the conversions are pure register arithmetic, and without this the compiler
+  // moves them (and with them the wait for the request) up to right behind the request, a whole step early
+  auto pin = [](float4 &v) __attribute__((always_inline)) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
+  auto stash = [&](int step, float4 (&st)[4]) __attribute__((always_inline)) {
     char *dst = at_lds + (step & 1) * AT_CHUNK + r0 * 64 + (step < NKC ? k_off : v_off);
     const float s = step < NKC ? s_qk : s_v;
-    const int rows = step < NKC ? AT_T : C;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (64 * r + r0 < rows) {                  // (row + 64 r) >> 2 & 3 == r0 >> 2 & 3: the swizzle does not change with r
+      if (step < NKC || r < C / 64) {            // (row + 64 r) >> 2 & 3 == r0 >> 2 & 3: the swizzle does not change with r
+        pin(st[r]);
         uintx2 hi, lo;
         cut4(st[r], s, hi, lo);
         *reinterpret_cast<uintx2 *>(dst + r * 64 * 64) = hi;
@@ -148,7 +150,8 @@ attention256_kernel(const AttnParams p) {
   halfx8 qh, ql;
   float4 qa, qb, qa2, qb2;                       // the queries of the next chunk and of the one after it, like st / st2
   auto q_fetch = [&](int kc, float4 &a, float4 &c) __attribute__((always_inline)) {
-    if (kc < NKC) { a = *reinterpret_cast<const float4 *>(q_src + 32 * kc); c = *reinterpret_cast<const float4 *>(q_src + 32 * kc + 4); }
+    const int kk = kc < NKC ? kc : NKC - 1;      // branch-free, as fetch
+    a = *reinterpret_cast<const float4 *>(q_src + 32 * kk); c = *reinterpret_cast<const float4 *>(q_src + 32 * kk + 4);
   };
   auto q_cut = [&]() __attribute__((always_inline)) {
     uintx2 h0, l0, h1, l1;
@@ -178,6 +181,7 @@ attention256_kernel(const AttnParams p) {
       if (kb == 12) {
         stash(kc + 1, cur);
         if (kc + 1 < NKC) {
+          pin(ca); pin(cb);
           uintx2 h0, l0, h1, l1;
           cut4(ca, s_qk, h0, l0); cut4(cb, s_qk, h1, l1);
           qh = __builtin_bit_cast(halfx8, uintx4{h0.x, h0.y, h1.x, h1.y});
