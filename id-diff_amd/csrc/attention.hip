@@ -34,6 +34,10 @@ constexpr int AT_PLANE = AT_T * 64;             // bytes: 256 rows x 32 halves
 constexpr int AT_CHUNK = 2 * AT_PLANE;          // hi | lo
 constexpr int AT_LDS = 2 * AT_CHUNK;            // two buffers: 65,536 B
 constexpr float AT_PSCALE = 1024.0f;
+#ifndef IDIFF_AT_LEAD
+#define IDIFF_AT_LEAD 3
+#endif
+constexpr int AT_LEAD = IDIFF_AT_LEAD;         // operand blocks requested from LDS ahead of their matrix instructions
 
 struct AttnParams {
   const float *qk;        // [B * 256, ld_qk]: q in columns [0, C), k in [C, 2C)
@@ -176,6 +180,15 @@ attention256_kernel(const AttnParams p) {
     // the conversion of the next chunk goes in front of the last quarter of the matrix block: its vector instructions issue in the
     // shadow of the matrix instructions around them (a 16x16x32 instruction holds the SIMD's issue for 8 of its 16 cycles)
     const halfx8 qh0 = qh, ql0 = ql;
+    // the K fragments of block kb + 3 are requested from LDS as soon as block kb's registers are free: three blocks (144 matrix-core cycles)
+    // of lead for an LDS round trip under load; the fences keep that distance (left alone the compiler reads one block ahead)
+    halfx8 ah[AT_LEAD], al[AT_LEAD];
+#pragma unroll
+    for (int i = 0; i < AT_LEAD; ++i) {
+      const char *ap = a_addr(buf, i);
+      ah[i] = *reinterpret_cast<const halfx8 *>(ap); al[i] = *reinterpret_cast<const halfx8 *>(ap + AT_PLANE);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
       if (kb == 12) {
@@ -188,11 +201,15 @@ attention256_kernel(const AttnParams p) {
           ql = __builtin_bit_cast(halfx8, uintx4{l0.x, l0.y, l1.x, l1.y});
         }
       }
-      const char *ap = a_addr(buf, kb);
-      const halfx8 kh = *reinterpret_cast<const halfx8 *>(ap), kl = *reinterpret_cast<const halfx8 *>(ap + AT_PLANE);
+      const halfx8 kh = ah[kb % AT_LEAD], kl = al[kb % AT_LEAD];
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh0, sacc[kb], 0, 0, 0);
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql0, sacc[kb], 0, 0, 0);
       sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh0, sacc[kb], 0, 0, 0);
+      if (kb + AT_LEAD < 16) {
+        const char *ap = a_addr(buf, kb + AT_LEAD);
+        ah[kb % AT_LEAD] = *reinterpret_cast<const halfx8 *>(ap); al[kb % AT_LEAD] = *reinterpret_cast<const halfx8 *>(ap + AT_PLANE);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   };
@@ -241,15 +258,25 @@ attention256_kernel(const AttnParams p) {
   auto pv_step = [&](int m2, float4 (&cur)[4], float4 (&far)[4]) __attribute__((always_inline)) {
     const int step = NKC + m2, buf = step & 1;
     fetch(step + 2, far);
+    halfx8 ah[AT_LEAD], al[AT_LEAD];
+#pragma unroll
+    for (int i = 0; i < AT_LEAD; ++i) {
+      const char *ap = a_addr(buf, i);
+      ah[i] = *reinterpret_cast<const halfx8 *>(ap); al[i] = *reinterpret_cast<const halfx8 *>(ap + AT_PLANE);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       if (cb == (3 * NCB) / 4 && m2 + 1 < NVC) stash(step + 1, cur);
-      const char *ap = a_addr(buf, cb);
-      const halfx8 vh = *reinterpret_cast<const halfx8 *>(ap), vl = *reinterpret_cast<const halfx8 *>(ap + AT_PLANE);
+      const halfx8 vh = ah[cb % AT_LEAD], vl = al[cb % AT_LEAD];
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[m2], oacc[cb], 0, 0, 0);
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[m2], oacc[cb], 0, 0, 0);
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[m2], oacc[cb], 0, 0, 0);
+      if (cb + AT_LEAD < NCB) {
+        const char *ap = a_addr(buf, cb + AT_LEAD);
+        ah[cb % AT_LEAD] = *reinterpret_cast<const halfx8 *>(ap); al[cb % AT_LEAD] = *reinterpret_cast<const halfx8 *>(ap + AT_PLANE);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (m2 + 1 < NVC) __syncthreads();
   };
