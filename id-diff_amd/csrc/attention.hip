@@ -16,8 +16,8 @@
 //            the probabilities are cut into pairs IN PLACE and are already the B operand of phase 2 (a matrix instruction's k index may
 //            be any fixed permutation of the keys as long as A uses the same one: k slot (g, j) = key 16 (2 m + j / 4) + 4 g + j % 4)
 //   phase 2  O^T[c, q] = sum_key V^T[c, key] P[key, q]   A = V^T chunk (LDS, keys stored in that slot order), B = P (registers)
-// LDS: a ring of four chunk buffers of 32 KB (one barrier per two steps) (hi plane | lo plane, 64 B per row, 16-byte pieces XOR-swizzled by at_swz(row): conflict-free
-// ds_read_b128); 128 KB per workgroup.  The operands' conversion to pairs is vector-ALU work every workgroup of a sample repeats, so a
+// LDS: two chunk buffers of 32 KB (hi plane | lo plane, 64 B per row, 16-byte pieces XOR-swizzled by at_swz(row): conflict-free
+// ds_read_b128); 64 KB per workgroup.  The operands' conversion to pairs is vector-ALU work every workgroup of a sample repeats, so a
 // workgroup takes as many queries as the register file allows (8 waves x 224 registers).
 #include "common.h"
 
@@ -32,8 +32,7 @@ constexpr int AT_BQ = 128;                      // queries per workgroup (eight 
 constexpr int AT_THREADS = 512;
 constexpr int AT_PLANE = AT_T * 64;             // bytes: 256 rows x 32 halves
 constexpr int AT_CHUNK = 2 * AT_PLANE;          // hi | lo
-constexpr int AT_RING = 4;                       // chunk buffers: two being read, two being written; ONE barrier per two steps
-constexpr int AT_LDS = AT_RING * AT_CHUNK;      // 131,072 B
+constexpr int AT_LDS = 2 * AT_CHUNK;            // two buffers: 65,536 B
 constexpr float AT_PSCALE = 1024.0f;
 #ifndef IDIFF_AT_LEAD
 #define IDIFF_AT_LEAD 3
@@ -105,8 +104,8 @@ attention256_kernel(const AttnParams p) {
   const int piece = tid & 7, r0 = tid >> 3;
   const float *k_src = p.qk + ((int64_t)b * AT_T + r0) * p.ld_qk + C + 4 * piece;          // + 32 kc, rows step 64 ld
   const float *v_src = p.vt + ((int64_t)b * C + r0) * AT_T + 4 * piece;                     // + 32 m, rows step 64 * 256
-  // st: the chunk stored during this step (requested one step ago, read two steps from now), st2: the next one (requested at the start of
-  // this step): a request has about 1.75 steps to arrive.  With one step of lead the waves sat at s_waitcnt for two thirds of their life (SQ_WAIT_ANY 66 %).
+  // st: the chunk of the NEXT step (requested one step ago), st2: the one after it (requested at the start of this step): a request has
+  // about 1.75 steps to arrive.  With one step of lead the waves sat at s_waitcnt for two thirds of their life (SQ_WAIT_ANY 66 %).
   float4 st[4], st2[4];
   // Branch-free on purpose: behind a conditional request the compiler's wait-count bookkeeping falls back to "wait for everything", which
   // exposes the latency of the request made at the start of the step.  Requests past the last chunk (and V rows beyond C) re-read a valid
@@ -127,8 +126,7 @@ attention256_kernel(const AttnParams p) {
   // moves them (and with them the wait for the request) up to right behind the request, a whole step early
   auto pin = [](float4 &v) __attribute__((always_inline)) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
   auto stash = [&](int step, float4 (&st)[4]) __attribute__((always_inline)) {
-    if (step >= NKC + NVC) return;
-    char *dst = at_lds + (step & (AT_RING - 1)) * AT_CHUNK + r0 * 64 + (step < NKC ? k_off : v_off);
+    char *dst = at_lds + (step & 1) * AT_CHUNK + r0 * 64 + (step < NKC ? k_off : v_off);
     const float s = step < NKC ? s_qk : s_v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -166,21 +164,19 @@ attention256_kernel(const AttnParams p) {
     ql = __builtin_bit_cast(halfx8, uintx4{l0.x, l0.y, l1.x, l1.y});
   };
   fetch(0, st);
-  fetch(1, st2);
   q_fetch(0, qa, qb);
   stash(0, st);
   q_cut();
-  stash(1, st2);
-  fetch(2, st);
+  fetch(1, st);
   q_fetch(1, qa, qb);
   __syncthreads();
   // ---- phase 1.  The scheduling fences keep the compiler from sinking the requests down to their first use.  Two steps per trip: the
   // register sets swap ROLES (a copy st = st2 at the end of a step would wait for the request made at its start).
   auto qk_step = [&](int kc, float4 (&cur)[4], float4 (&far)[4], float4 &ca, float4 &cb, float4 &fa, float4 &fb) __attribute__((always_inline)) {
-    fetch(kc + 3, far);
+    fetch(kc + 2, far);
     q_fetch(kc + 2, fa, fb);
     __builtin_amdgcn_sched_barrier(0);
-    const int buf = kc & (AT_RING - 1);
+    const int buf = kc & 1;
     // the conversion of the next chunk goes in front of the last quarter of the matrix block: its vector instructions issue in the
     // shadow of the matrix instructions around them (a 16x16x32 instruction holds the SIMD's issue for 8 of its 16 cycles)
     const halfx8 qh0 = qh, ql0 = ql;
@@ -196,7 +192,7 @@ attention256_kernel(const AttnParams p) {
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
       if (kb == 12) {
-        stash(kc + 2, cur);
+        stash(kc + 1, cur);
         if (kc + 1 < NKC) {
           pin(ca); pin(cb);
           uintx2 h0, l0, h1, l1;
@@ -215,7 +211,7 @@ attention256_kernel(const AttnParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (kc & 1) __syncthreads();                 // the chunks written during steps 2 j, 2 j + 1 are read during 2 j + 2, 2 j + 3
+    __syncthreads();
   };
   static_assert(NKC % 2 == 0 && NVC % 2 == 0, "the register sets alternate: an even number of steps per phase");
 #pragma unroll 1
@@ -260,8 +256,8 @@ attention256_kernel(const AttnParams p) {
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) oacc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
   auto pv_step = [&](int m2, float4 (&cur)[4], float4 (&far)[4]) __attribute__((always_inline)) {
-    const int step = NKC + m2, buf = step & (AT_RING - 1);
-    fetch(step + 3, far);
+    const int step = NKC + m2, buf = step & 1;
+    fetch(step + 2, far);
     halfx8 ah[AT_LEAD], al[AT_LEAD];
 #pragma unroll
     for (int i = 0; i < AT_LEAD; ++i) {
@@ -271,7 +267,7 @@ attention256_kernel(const AttnParams p) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-      if (cb == (3 * NCB) / 4) stash(step + 2, cur);
+      if (cb == (3 * NCB) / 4 && m2 + 1 < NVC) stash(step + 1, cur);
       const halfx8 vh = ah[cb % AT_LEAD], vl = al[cb % AT_LEAD];
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[m2], oacc[cb], 0, 0, 0);
       oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[m2], oacc[cb], 0, 0, 0);
@@ -282,7 +278,7 @@ attention256_kernel(const AttnParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if ((m2 & 1) && m2 + 1 < NVC) __syncthreads();
+    if (m2 + 1 < NVC) __syncthreads();
   };
 #pragma unroll
   for (int m2 = 0; m2 < NVC; m2 += 2) {
