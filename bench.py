@@ -56,7 +56,8 @@ _CONV_ARITH = ("3x3 convs: Winograd F(4x4,3x3), fp32 transforms, fp32 MFMA contr
                else "3x3 convs: Winograd F(4x4,3x3), fp32 transforms, contraction on pairs of fp16 values -- 22 significand bits, 3 products, fp32 accumulate")
 _GEMM_ARITH = ("1x1/attention/dense contractions: fp32 MFMA" if os.environ.get("IDIFF_NO_SPLIT")
                else "1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate"
-               + ("" if os.environ.get("IDIFF_NO_PAIRS") else "; the q/k/v projections of a GroupNorm's output: pairs of fp16 values, 3 products"))
+               + ("" if os.environ.get("IDIFF_NO_PAIRS") else "; the q/k/v projections of a GroupNorm's output: pairs of fp16 values, 3 products")
+               + ("" if (os.environ.get("IDIFF_NO_PAIRS") or os.environ.get("IDIFF_NO_FUSED_ATTN")) else "; QK^T / softmax / PV of the 256-token attention blocks: one launch on fp16 pairs, softmax in fp32"))
 DTYPE = f"f32 ({_CONV_ARITH}; {_GEMM_ARITH})"
 WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=1e-5, B=128 -> S 4480x3072 + centred spectrum + ID"
 # PMC traffic tables (separate FETCH_SIZE / WRITE_SIZE passes, scripts/profile_round.sh), each stamped with the sha256 of the kernel
@@ -84,6 +85,7 @@ def source_sha256(rels):
 
 
 PAIRS_GEMM = "igemm_pipe_kernel on fp16 pairs (q / k / v projections of a GroupNorm's output)"
+FUSED_ATTN = "attention256_kernel (QK^T -> softmax -> PV of a 256-token block in one launch, logits on chip, both contractions on fp16 pairs)"
 
 
 class KernelProbe:
@@ -159,6 +161,10 @@ class KernelProbe:
             return (PAIRS_GEMM,
                     (2.0 * batch * M * N * K, 4.0 * (batch * (M * N + (N * K if weight_is_a else M * K)) + (M * K if weight_is_a else N * K))), f"{M}x{N}x{K}")
 
+        def attn(qk, vt, out, B, C, s_qk, s_v, scale, bias_v=None):
+            # two contractions of 2 * 256 * 256 * C flops per sample; compulsory bytes: q, k, v in and the mixed values out, each once
+            return FUSED_ATTN, (2.0 * 2.0 * B * 256 * 256 * C, 4.0 * 4.0 * B * 256 * C), f"{B}x256x{C}"
+
         def gemm_2src(a1, a2, bt, out, epilogue=None):
             M, K1 = a1.shape
             K, N = K1 + a2.shape[1], bt.shape[0]
@@ -173,7 +179,7 @@ class KernelProbe:
 
         for name, fn in (("conv2d_winograd", wino), ("conv2d_winograd43", wino43), ("groupnorm_apply", gn_apply), ("groupnorm_apply_colstats", gn_apply_cs),
                          ("gemm", gemm), ("gemm_2src", gemm_2src), ("gemm_pairs", gemm_pairs), ("gemm_pairs_2src", gemm_pairs_2src),
-                         ("upfirdn2d_raw", ufd), ("softmax_rows", softmax)):
+                         ("upfirdn2d_raw", ufd), ("softmax_rows", softmax), ("attention256", attn)):
             self._wrap(name, fn)
 
     def uninstall(self):
@@ -245,9 +251,17 @@ def roofline_report(probe):
                         "achieved": t22, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": t22 / FP32_MFMA_PEAK_TFLOPS,
                         "launches_sampled": dom22["launches"], "avg_launch_us": dom22["avg_us"]})
     for name in ("gn_apply_rows", "igemm_pipe_kernel K<=128 (1x1 / NIN)", "igemm_pipe_kernel K>=256 (1x1 / NIN / attention products)",
-                 "igemm_pipe_kernel two-source shortcut", PAIRS_GEMM, "upfirdn2d_nhwc", "softmax_rows"):
+                 "igemm_pipe_kernel two-source shortcut", PAIRS_GEMM, FUSED_ATTN, "upfirdn2d_nhwc", "softmax_rows"):
         g = probe.group(name)
         if not g:
+            continue
+        if name == FUSED_ATTN:
+            # 64 flop per compulsory byte: at 8 TB/s the memory roof (512 TFLOP/s fp32-equivalent) lies below the fp16 peak / 3 (833)
+            tf, gbs = g["flops_rate"] / 1e12, g["rate"] / 1e9
+            kernels.append({"kernel": name + " [3 fp16 products per fp32 multiply-add]", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "flop_per_byte": g["flops_rate"] / g["rate"], "tflops": tf, "gbs": gbs,
+                            "frac_of_f16_mfma_peak_over_3": tf / (F16_MFMA_PEAK_TFLOPS / 3.0),
+                            "launches_sampled": g["launches"], "avg_launch_us": g["avg_us"]})
             continue
         if name == PAIRS_GEMM:
             tf, gbs = g["flops_rate"] / 1e12, g["rate"] / 1e9
