@@ -161,16 +161,9 @@ __device__ __forceinline__ void f4_tail(const Wino43Params &p, float *lds, float
           }
           float *zp = zbase + (((3 * wa + ii) * F4_TILES + (reg & 3) + 8 * (reg >> 2)) * 2) * F4_COUT;
           if (PARK) { zp[0] = p0; zp[F4_COUT] = p1; }
-#ifdef IDIFF_W43_TAIL_RMW         // A/B builds: the read-modify-write this replaced
+          // (an LDS float add, ds_add_f32, instead of this read - add - write was measured TWICE as slow for the whole kernel: 146.3 against
+          //  78.6 ms per forward, profiles/r05_tail_ab.txt -- LDS float atomics do not run at the store rate)
           else { zp[0] += p0; zp[F4_COUT] += p1; }
-#else
-          // one LDS add instead of read + wait + add + write: the same single fp32 addition (parked value + this part), so the same bits
-          else {
-            typedef __attribute__((address_space(3))) float lds_float;
-            __builtin_amdgcn_ds_faddf((lds_float *)zp, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
-            __builtin_amdgcn_ds_faddf((lds_float *)(zp + F4_COUT), p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
-          }
-#endif
         }
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I8 = std::integral_constant<int, 8>;
