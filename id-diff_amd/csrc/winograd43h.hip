@@ -37,7 +37,14 @@ constexpr int H4_POS_BYTES = F4_TILES * H4_TILE_BYTES;                 // 2048
 constexpr int H4_STAGE_BYTES = F4_NPOS * H4_POS_BYTES;                 // 73,728
 constexpr int H4_SLOT_BYTES = 2 * 64 * H4_KC * 2;                      // 4096: one position of one (step, cout tile)
 constexpr int H4_PLANE_BYTES = 64 * H4_KC * 2;                         // 2048
-constexpr size_t H4_LDS_BYTES = 2 * H4_STAGE_BYTES > (int)sizeof(float) * F4_Z_FLOATS ? 2 * H4_STAGE_BYTES : sizeof(float) * F4_Z_FLOATS;
+constexpr int H4_TOUCH_BYTES = 1024;                                   // landing zone of the look-ahead touches (see touch() in the kernel)
+constexpr size_t H4_LDS_BYTES = (2 * H4_STAGE_BYTES > (int)sizeof(float) * F4_Z_FLOATS ? 2 * H4_STAGE_BYTES : sizeof(float) * F4_Z_FLOATS) + H4_TOUCH_BYTES;
+#ifndef IDIFF_W43H_TOUCH_AHEAD
+#define IDIFF_W43H_TOUCH_AHEAD 4
+#endif
+#ifndef IDIFF_W43H_TOUCH_AT
+#define IDIFF_W43H_TOUCH_AT 8
+#endif
 #ifndef IDIFF_W43H_BRING
 #define IDIFF_W43H_BRING 3
 #endif
@@ -154,6 +161,29 @@ winograd43h_kernel(const Wino43Params p) {
       else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)vo, choff + ro + (j - 1) * (int)cin4, 0));
       dp[i >> 1][j][i & 1] = v;
     }
+  };
+  // Look-ahead touches.  The K loop's pace is set by the patch requests: they miss to HBM, and a wave's vector-memory operations retire in
+  // order, so every U request (an L2 hit) issued behind one of them waits out an HBM round trip -- at six of a step's nine positions
+  // (profiles/r04_wino43h_loop_experiments.txt).  Here each lane touches ONE dword of up to three 64-byte pixel chunks of the patch
+  // TOUCH_AHEAD steps ahead -- between them the lanes of a wave cover the 4 x 36 chunks their tiles will request -- so that the L2 has the
+  // lines when the real requests come: those then retire in an L2 round trip, and the one HBM-latency wait per step sits behind the
+  // touches, at one position.  The touches are LDS-DMA loads into a landing zone nobody reads: no destination registers.
+  auto touch = [&](int step) __attribute__((always_inline)) {
+#ifndef IDIFF_W43H_NO_TOUCH
+    typedef __attribute__((address_space(3))) void lds_void;
+    lds_void *zone = (lds_void *)(ldsb + 2 * H4_STAGE_BYTES + (wave & 3) * 256);
+    const int choff = min(step, nsteps - 1) * (H4_KC * 4);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int pix = (tid & 15) + 16 * q;             // this lane's pixel of its tile's 6 x 6 patch: pix = 6 i + j
+      const int i = (pix * 43) >> 8, j = pix - 6 * i;
+      // rows / columns outside the image are not special-cased: the address is then a neighbouring pixel's (a line some tile requests
+      // anyway) or beyond the tensor (no request at all: the descriptor's range check)
+      const bool ok = pix < 36 && v_mid != F4_INVALID;
+      const uint32_t off = v_mid + (uint32_t)((i - 1) * row4 + (j - 1) * (int)cin4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, zone, 4, (int)(ok ? off : F4_INVALID), choff, 0, 0);
+    }
+#endif
   };
   // The dword (channels 2m, 2m + 1) this lane writes for every position: even lanes that of plane 0 (hi), odd lanes that of plane 1
   // (lo), which lies 32 bytes from it (bit 5 of the offset flipped)
@@ -276,6 +306,7 @@ winograd43h_kernel(const Wino43Params p) {
 #else
       if (pp + BRING < 9) load_b(pp + BRING, s); else if (!LAST) load_b(pp + BRING - 9, s + 1);
 #endif
+      if (!LAST && pp == IDIFF_W43H_TOUCH_AT) touch(s + IDIFF_W43H_TOUCH_AHEAD);
       if (!LAST) {
         __builtin_amdgcn_sched_barrier(0);
 #ifdef IDIFF_W43H_STAMP
