@@ -162,14 +162,16 @@ winograd43h_kernel(const Wino43Params p) {
       dp[i >> 1][j][i & 1] = v;
     }
   };
-  // Look-ahead touches.  The K loop's pace is set by the patch requests: they miss to HBM, and a wave's vector-memory operations retire in
+  // Look-ahead touches -- an experiment that did NOT pay (A/B builds only, -DIDIFF_W43H_TOUCH): one dword per 64-byte chunk is 64 separate
+  // line requests per instruction, 192 per wave and step beside the 144 of the real patch requests: the texture-address path, which the
+  // kernel already keeps busy, pays more than the earlier arrival of the lines gives back.  The idea: the K loop's pace is set by the patch requests: they miss to HBM, and a wave's vector-memory operations retire in
   // order, so every U request (an L2 hit) issued behind one of them waits out an HBM round trip -- at six of a step's nine positions
   // (profiles/r04_wino43h_loop_experiments.txt).  Here each lane touches ONE dword of up to three 64-byte pixel chunks of the patch
   // TOUCH_AHEAD steps ahead -- between them the lanes of a wave cover the 4 x 36 chunks their tiles will request -- so that the L2 has the
   // lines when the real requests come: those then retire in an L2 round trip, and the one HBM-latency wait per step sits behind the
   // touches, at one position.  The touches are LDS-DMA loads into a landing zone nobody reads: no destination registers.
   auto touch = [&](int step) __attribute__((always_inline)) {
-#ifndef IDIFF_W43H_NO_TOUCH
+#ifdef IDIFF_W43H_TOUCH           // OFF: measured 87.2 against 76.9 ms per forward (profiles/r05_touch_ab.txt)
     typedef __attribute__((address_space(3))) void lds_void;
     lds_void *zone = (lds_void *)(ldsb + 2 * H4_STAGE_BYTES + (wave & 3) * 256);
     const int choff = min(step, nsteps - 1) * (H4_KC * 4);
