@@ -211,6 +211,70 @@ upfirdn2d_planes_whole(const float *__restrict__ x, const float *__restrict__ k,
   }
 }
 
+// ---------------------------------------------------------------- minor == 1, FIR + decimation by 2 on small planes
+// up == 1, down == 2, kh, kw <= 4 (downsample_2d of the score networks, up_or_down_sampling.py:227-257): a thread produces a 2 x 2 block
+// of outputs from its 6 x 6 input window, read from LDS as one ds_read_b128 + one ds_read_b64 per row -- 3 LDS instructions per output
+// where the per-pixel form above issues 16 four-byte reads (which made that form LDS-bound: 2.1 MB of reads per CU at [128, 256, 16, 16]).
+// Planes sit in LDS inside a frame of zeros (pad_y0 rows on top, pad_x0 columns on the left, enough on the other two sides for the last
+// window), so no tap needs a validity test, and the frame puts column 4 X of the framed plane at the start of block X's window: 16-byte
+// aligned.  Stores are float2 (the two outputs of a block row), contiguous over the lanes.
+__global__ void __launch_bounds__(256)
+upfirdn2d_planes_down2(const float *__restrict__ x, const float *__restrict__ k, float *__restrict__ out, UfdParams p, int ppb,
+                       int rows, int pitch) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int plane0 = blockIdx.x * ppb;
+  const int nplanes = min(ppb, p.major - plane0);
+  const int psz = p.in_h * p.in_w, fsz = rows * pitch;            // fsz % 4 == 0 (pitch % 4 == 0)
+  // flipped taps, zero beyond kh x kw
+  float T[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) T[a][b] = (a < p.kh && b < p.kw) ? k[(p.kh - 1 - a) * p.kw + (p.kw - 1 - b)] : 0.f;
+  // frame of zeros, then the planes inside it
+  {
+    float4 *z4 = reinterpret_cast<float4 *>(lds);
+    for (int i = tid; i < (nplanes * fsz) >> 2; i += 256) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  {
+    const float4 *s4 = reinterpret_cast<const float4 *>(x + (int64_t)plane0 * psz);
+    const int w4 = p.in_w >> 2, per_plane = psz >> 2;
+    for (int i = tid; i < nplanes * per_plane; i += 256) {
+      const int q = i / per_plane, r = i - q * per_plane, iy = r / w4, c4 = r - iy * w4;
+      const float4 v = s4[i];
+      float *d = lds + q * fsz + (iy + p.pad_y0) * pitch + p.pad_x0 + 4 * c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+  __syncthreads();
+  const int bw = p.out_w >> 1, nb = (p.out_h >> 1) * bw, osz = p.out_h * p.out_w;
+  float *dst = out + (int64_t)plane0 * osz;
+  for (int i = tid; i < nplanes * nb; i += 256) {
+    const int q = i / nb, r = i - q * nb, Y = r / bw, X = r - Y * bw;
+    const float *w = lds + q * fsz + 4 * Y * pitch + 4 * X;
+    float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+      const float4 a = *reinterpret_cast<const float4 *>(w + rr * pitch);
+      const float2 b = *reinterpret_cast<const float2 *>(w + rr * pitch + 4);
+      const float c[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+      if (rr < 4) {                                                // output row 2 Y: window rows 0 .. 3
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { o00 = fmaf(c[t], T[rr][t], o00); o01 = fmaf(c[t + 2], T[rr][t], o01); }
+      }
+      if (rr >= 2) {                                               // output row 2 Y + 1: window rows 2 .. 5
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { o10 = fmaf(c[t], T[rr - 2][t], o10); o11 = fmaf(c[t + 2], T[rr - 2][t], o11); }
+      }
+    }
+    float *o = dst + (int64_t)q * osz + (2 * Y) * p.out_w + 2 * X;
+    *reinterpret_cast<float2 *>(o) = make_float2(o00, o01);
+    *reinterpret_cast<float2 *>(o + p.out_w) = make_float2(o10, o11);
+  }
+}
+
 // ---------------------------------------------------------------- minor == 1, plain FIR on small planes
 // up == down == 1, kh, kw <= 4 (the FIR in front of a stride-2 convolution, up_or_down_sampling.py:144-178): thread =
 // (plane, output row).  It walks its row with the three previous inputs of each of the four input rows in registers:
@@ -547,6 +611,19 @@ IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, in
     const size_t lds_bytes = (16 + (size_t)ppb * (lpsz + osz)) * sizeof(float);
     hipLaunchKernelGGL(upfirdn2d_planes_rowslide, dim3(ceil_div(major, ppb)), dim3(256), lds_bytes, st, x, k, out, p, ppb);
     return launch_status("upfirdn2d_planes_rowslide");
+  }
+  if (minor == 1 && up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2 && kh <= 4 && kw <= 4 && pad_x0 >= 0 && pad_y0 >= 0 &&
+      pad_x0 <= 4 && pad_y0 <= 4 && p.out_h % 2 == 0 && p.out_w % 2 == 0 && in_w % 4 == 0 && (int64_t)in_h * in_w <= 4096 &&
+      (((uintptr_t)x | (uintptr_t)out) & 15) == 0 && !option(OPT_UFD_ROWS)) {
+    // FIR + decimation by 2: 2 x 2 output blocks from framed planes in LDS.  Frame: rows -pad_y0 .. 2 out_h + 1 - pad_y0, columns
+    // -pad_x0 .. 2 out_w + 1 - pad_x0 (the last block's window), pitch a multiple of 4 floats
+    const int rows = max(in_h + pad_y0, 2 * p.out_h + 2), pitch = (max(in_w + pad_x0, 2 * p.out_w + 2) + 3) & ~3;
+    const int fsz = rows * pitch, nb = (p.out_h / 2) * (p.out_w / 2);
+    int ppb = max(1, min((40 * 1024 / 4) / fsz, max(1, major / 1024)));        // <= 40 KB of LDS, >= ~4 workgroups per CU
+    if (ppb * nb >= 256 && 256 % nb == 0) ppb -= ppb % (256 / nb);            // whole rounds of 256 blocks where the shape allows
+    const size_t lds_bytes = (size_t)ppb * fsz * sizeof(float);
+    hipLaunchKernelGGL(upfirdn2d_planes_down2, dim3(ceil_div(major, ppb)), dim3(256), lds_bytes, st, x, k, out, p, ppb, rows, pitch);
+    return launch_status("upfirdn2d_planes_down2");
   }
   if (minor == 1 && kh * kw <= kMaxTaps && (int64_t)in_h * in_w <= 8192 && (int64_t)p.out_h * p.out_w <= 16384) {
     // whole planes in LDS: <= 32 KB per plane; as many planes per workgroup as fit 32 KB / ~16 outputs per thread

@@ -52,6 +52,30 @@ def test_upfirdn2d_nchw_vs_oracle(shape, up, down, pad):
     assert rel_err(y.cpu(), ref) < 1e-6
 
 
+@pytest.mark.parametrize("shape,pad,ksz", [
+    ((128, 256, 16, 16), (1, 1), 4),   # the three down-by-2 shapes of SURVEY 8-a5
+    ((128, 256, 8, 8), (1, 1), 4),
+    ((5, 7, 32, 32), (1, 1), 4),       # fewer planes than a workgroup takes
+    ((3, 33, 16, 24), (1, 1), 4),      # non-square, a ragged last workgroup
+    ((2, 9, 16, 16), (2, 2), 4),       # wider frame on both sides
+    ((2, 9, 16, 16), (3, 1), 4),       # asymmetric pads (even output still)
+    ((2, 9, 12, 16), (0, 0), 2),       # 2 x 2 taps, no padding
+    ((2, 5, 16, 16), (1, 2), 3),       # 3 x 3 asymmetric taps
+])
+def test_upfirdn2d_down2_block_kernel_vs_oracle(shape, pad, ksz):
+    """upfirdn2d_planes_down2 (2 x 2 output blocks from zero-framed planes in LDS): every geometry that takes it, asymmetric random
+    taps (exposes the flip), against the oracle's restatement of upfirdn2d_native (op/upfirdn2d.py:159-200)."""
+    g = torch.Generator().manual_seed(sum(shape) + ksz)
+    x = torch.randn(*shape, generator=g)
+    k = torch.randn(ksz, ksz, generator=g)
+    ref = oops.upfirdn2d(x, k, up=1, down=2, pad=pad)
+    y = op.upfirdn2d(x.to(DEV), k.to(DEV), up=1, down=2, pad=pad)
+    assert y.shape == ref.shape and rel_err(y.cpu(), ref) < 1e-6
+    with _lib.thread_option("IDIFF_UFD_ROWS", 1):                  # the per-pixel form it replaced, same answer
+        y2 = op.upfirdn2d(x.to(DEV), k.to(DEV), up=1, down=2, pad=pad)
+    assert rel_err(y2.cpu(), ref) < 1e-6
+
+
 @pytest.mark.parametrize("C", [4, 8, 128, 3])
 @pytest.mark.parametrize("mode", [(1, 2, 1, 1), (2, 1, 2, 1), (1, 1, 2, 2)])
 def test_upfirdn2d_nhwc_minor(C, mode):
