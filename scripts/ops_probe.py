@@ -13,8 +13,33 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps
+def graph_time(fn, n=20, reps=5):
+    """Device time per launch with the host out of the loop: n launches captured into one hipGraph, replayed `reps` times (the C-ABI
+    launches on the stream it is handed, so stream capture records it).  None if capture is not possible."""
+    try:
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(n): fn()
+        torch.cuda.synchronize()
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): g.replay()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / (reps * n)
+    except Exception as exc:                      # noqa: BLE001 -- a probe: say so and go on
+        print(f"   (graph capture failed: {exc})", flush=True)
+        return None
 FLOOR = None   # seconds per call of the same entry point on a 4 KB tensor: host issue + launch + drain, no data
-def say(name, nbytes, dt):
+def say(name, nbytes, dt, dt_graph=None):
+    if dt_graph is not None:
+        print(f"{name:58s} {dt_graph*1e6:8.1f} us  {nbytes/dt_graph/1e9:7.0f} GB/s  ({nbytes/dt_graph/8e12*100:4.1f}% of 8 TB/s)  "
+              f"[device time per launch, 20 launches replayed from a hipGraph: no host in the loop]", flush=True)
     raw = nbytes / dt
     note = ""
     if FLOOR is not None:
@@ -30,15 +55,16 @@ _x0 = torch.randn(1, 1, 32, 32, device=dev); _o0 = torch.empty(1, 1, 33, 33, dev
 FLOOR = timeit(lambda: _lib.upfirdn2d_raw(_x0, k, _o0, 1, 32, 32, 1, 1, 1, 1, 1, 2, 2, 2, 2), reps=200)
 print(f"launch floor (upfirdn2d on one 32x32 plane, back-to-back calls): {FLOOR*1e6:.1f} us per call", flush=True)
 # op.upfirdn2d (NCHW, minor = 1) at the three ncsnpp families, B = 128
-for shape, up, down, pad in [((128, 128, 32, 32), 1, 2, (1, 1)), ((128, 256, 16, 16), 1, 2, (1, 1)), ((128, 256, 16, 16), 2, 1, (2, 1)),
-                             ((128, 256, 8, 8), 2, 1, (2, 1)), ((128, 3, 32, 32), 1, 1, (2, 2)), ((128, 128, 16, 16), 1, 1, (2, 2))]:
+for shape, up, down, pad in [((128, 128, 32, 32), 1, 2, (1, 1)), ((128, 256, 16, 16), 1, 2, (1, 1)), ((128, 256, 8, 8), 1, 2, (1, 1)),
+                             ((128, 256, 16, 16), 2, 1, (2, 1)), ((128, 256, 8, 8), 2, 1, (2, 1)), ((128, 256, 4, 4), 2, 1, (2, 1)),
+                             ((128, 3, 32, 32), 1, 1, (2, 2)), ((128, 128, 16, 16), 1, 1, (2, 2)), ((128, 256, 8, 8), 1, 1, (2, 2))]:
     x = torch.randn(*shape, device=dev)
     kk = k * (4 if up == 2 else 1)
     y = op.upfirdn2d(x, kk, up=up, down=down, pad=pad)
     out = torch.empty_like(y)
     n, c, h, w = shape
     def f(): _lib.upfirdn2d_raw(x, kk, out, n * c, h, w, 1, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
-    say(f"upfirdn2d NCHW {shape} up{up} down{down}", 4 * (x.numel() + y.numel()) + 64, timeit(f))
+    say(f"upfirdn2d NCHW {shape} up{up} down{down}", 4 * (x.numel() + y.numel()) + 64, timeit(f), graph_time(f))
 # NHWC (minor = C) as the networks call it, 512 rows
 for (B, H, C, up, down, pad) in [(512, 32, 128, 1, 2, (1, 1)), (512, 16, 256, 2, 1, (2, 1)), (512, 16, 256, 1, 2, (1, 1))]:
     x = torch.randn(B, H * H, C, device=dev)
