@@ -17,6 +17,7 @@
 //   generic      anything else, scalar.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -33,6 +34,29 @@ __device__ __forceinline__ int floor_div(int a, int b) {  // b > 0
 __device__ __forceinline__ int ceil_div_s(int a, int b) { return -floor_div(-a, b); }
 
 constexpr int kMaxTaps = 64;  // kh*kw kept in LDS for the fast kernels
+
+// How many planes a workgroup of the small-plane kernels takes per group, and how many workgroups to launch.  These launches last
+// 5 - 20 us: a grid of 1,093 workgroups on 1,024 resident slots runs as two rounds, the second 7 % full (measured: [128, 128, 16, 16]
+// plain FIR 15.4 us at 15 planes per group).  So: among the admissible group sizes pick the one with the least (rounds x planes per
+// group), launch ceil(groups / rounds) workgroups and let each walk its groups (grid-stride), so that every workgroup does the same
+// number of groups +- 1 and all of them are resident from the start.  256 CUs x min(8, LDS) workgroups of 256 threads are resident.
+struct GroupPlan { int ppb, grid, ngroups; };
+template <typename LdsBytes, typename Admissible>
+GroupPlan plan_plane_groups(int major, int ppb_max, LdsBytes lds_bytes_of, Admissible admissible) {
+  GroupPlan best = {1, major, major};
+  double best_cost = 1e300;
+  for (int ppb = 1; ppb <= ppb_max; ++ppb) {
+    if (!admissible(ppb)) continue;
+    const size_t lds = lds_bytes_of(ppb);
+    if (lds > 64 * 1024) continue;
+    const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+    const int slots = 256 * std::max(per_cu, 1), ngroups = idiff::ceil_div(major, ppb), rounds = idiff::ceil_div(ngroups, slots);
+    // per-group cost ~ planes + a fixed part (frame / taps / barriers), less latency hidden when few workgroups share a CU
+    const double cost = rounds * (ppb + 1.5) * (per_cu >= 4 ? 1.0 : 1.0 + 0.15 * (4 - per_cu));
+    if (cost < best_cost) { best_cost = cost; best = {ppb, idiff::ceil_div(ngroups, rounds), ngroups}; }
+  }
+  return best;
+}
 
 // ---------------------------------------------------------------- minor == 1
 // grid.x = plane groups, grid.y = tiles over (out_h, out_w).  Dynamic LDS: taps + [PPB][tih][tiw+1] window.
@@ -220,11 +244,9 @@ upfirdn2d_planes_whole(const float *__restrict__ x, const float *__restrict__ k,
 // aligned.  Stores are float2 (the two outputs of a block row), contiguous over the lanes.
 __global__ void __launch_bounds__(256)
 upfirdn2d_planes_down2(const float *__restrict__ x, const float *__restrict__ k, float *__restrict__ out, UfdParams p, int ppb,
-                       int rows, int pitch) {
+                       int rows, int pitch, int ngroups) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
-  const int plane0 = blockIdx.x * ppb;
-  const int nplanes = min(ppb, p.major - plane0);
   const int psz = p.in_h * p.in_w, fsz = rows * pitch;            // fsz % 4 == 0 (pitch % 4 == 0)
   // flipped taps, zero beyond kh x kw
   float T[4][4];
@@ -232,12 +254,15 @@ upfirdn2d_planes_down2(const float *__restrict__ x, const float *__restrict__ k,
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) T[a][b] = (a < p.kh && b < p.kw) ? k[(p.kh - 1 - a) * p.kw + (p.kw - 1 - b)] : 0.f;
-  // frame of zeros, then the planes inside it
+  // the frame of zeros is written once: every group overwrites the same interior cells
   {
     float4 *z4 = reinterpret_cast<float4 *>(lds);
-    for (int i = tid; i < (nplanes * fsz) >> 2; i += 256) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < (ppb * fsz) >> 2; i += 256) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  const int plane0 = grp * ppb;
+  const int nplanes = min(ppb, p.major - plane0);
   {
     const float4 *s4 = reinterpret_cast<const float4 *>(x + (int64_t)plane0 * psz);
     const int w4 = p.in_w >> 2, per_plane = psz >> 2;
@@ -273,6 +298,8 @@ upfirdn2d_planes_down2(const float *__restrict__ x, const float *__restrict__ k,
     *reinterpret_cast<float2 *>(o) = make_float2(o00, o01);
     *reinterpret_cast<float2 *>(o + p.out_w) = make_float2(o10, o11);
   }
+  __syncthreads();                                                 // the next group's planes overwrite the interior
+  }
 }
 
 // ---------------------------------------------------------------- minor == 1, plain FIR on small planes
@@ -282,7 +309,8 @@ upfirdn2d_planes_down2(const float *__restrict__ x, const float *__restrict__ k,
 // thread tile left 62 % of the lanes idle).  Planes sit in LDS with a pitch of in_w + 1 words (rows of one plane on
 // distinct banks); results go through LDS once more so that the stores are contiguous.
 __global__ void __launch_bounds__(256)
-upfirdn2d_planes_rowslide(const float *__restrict__ x, const float *__restrict__ k, float *__restrict__ out, UfdParams p, int ppb) {
+upfirdn2d_planes_rowslide(const float *__restrict__ x, const float *__restrict__ k, float *__restrict__ out, UfdParams p, int ppb,
+                          int ngroups) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *taps = lds;                        // [4][4] flipped, zero beyond kh x kw
   float *pl = lds + 16;                     // [ppb][in_h][in_w + 1]
@@ -293,7 +321,9 @@ upfirdn2d_planes_rowslide(const float *__restrict__ x, const float *__restrict__
     const int ky = tid >> 2, kx = tid & 3;
     taps[tid] = (ky < p.kh && kx < p.kw) ? k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)] : 0.f;
   }
-  const int plane0 = blockIdx.x * ppb;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  if (grp != (int)blockIdx.x) __syncthreads();                     // the previous group's output staging has been stored
+  const int plane0 = grp * ppb;
   const int nplanes = min(ppb, p.major - plane0);
   const float *src = x + (int64_t)plane0 * psz;
   if ((p.in_w & 3) == 0 && ((((uintptr_t)src) & 15) == 0)) {
@@ -353,6 +383,7 @@ upfirdn2d_planes_rowslide(const float *__restrict__ x, const float *__restrict__
   __syncthreads();
   float *dst = out + (int64_t)plane0 * osz;
   for (int i = tid; i < nplanes * osz; i += 256) dst[i] = ob[i];
+  }
 }
 
 // Workgroups are dealt to the 8 XCDs round-robin, and every XCD has an L2 of its own: consecutive block indices -- here
@@ -606,10 +637,9 @@ IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, in
       (int64_t)in_h * in_w <= 4096) {
     // plain FIR on small planes: one thread per (plane, output row)
     const int lpsz = in_h * (in_w + 1), osz = p.out_h * p.out_w;
-    int ppb = max(1, min(256 / p.out_h, (int)((60 * 1024 / 4 - 16) / (lpsz + osz))));
-    ppb = max(1, min(ppb, max(1, major / 512)));             // keep >= ~2 workgroups per CU when there are few planes
-    const size_t lds_bytes = (16 + (size_t)ppb * (lpsz + osz)) * sizeof(float);
-    hipLaunchKernelGGL(upfirdn2d_planes_rowslide, dim3(ceil_div(major, ppb)), dim3(256), lds_bytes, st, x, k, out, p, ppb);
+    auto lds_of = [&](int ppb) { return (16 + (size_t)ppb * (lpsz + osz)) * sizeof(float); };
+    const GroupPlan g = plan_plane_groups(major, max(1, 256 / p.out_h), lds_of, [](int) { return true; });
+    hipLaunchKernelGGL(upfirdn2d_planes_rowslide, dim3(g.grid), dim3(256), lds_of(g.ppb), st, x, k, out, p, g.ppb, g.ngroups);
     return launch_status("upfirdn2d_planes_rowslide");
   }
   if (minor == 1 && up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2 && kh <= 4 && kw <= 4 && pad_x0 >= 0 && pad_y0 >= 0 &&
@@ -619,10 +649,15 @@ IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, in
     // -pad_x0 .. 2 out_w + 1 - pad_x0 (the last block's window), pitch a multiple of 4 floats
     const int rows = max(in_h + pad_y0, 2 * p.out_h + 2), pitch = (max(in_w + pad_x0, 2 * p.out_w + 2) + 3) & ~3;
     const int fsz = rows * pitch, nb = (p.out_h / 2) * (p.out_w / 2);
-    int ppb = max(1, min((40 * 1024 / 4) / fsz, max(1, major / 1024)));        // <= 40 KB of LDS, >= ~4 workgroups per CU
-    if (ppb * nb >= 256 && 256 % nb == 0) ppb -= ppb % (256 / nb);            // whole rounds of 256 blocks where the shape allows
-    const size_t lds_bytes = (size_t)ppb * fsz * sizeof(float);
-    hipLaunchKernelGGL(upfirdn2d_planes_down2, dim3(ceil_div(major, ppb)), dim3(256), lds_bytes, st, x, k, out, p, ppb, rows, pitch);
+    auto lds_of = [&](int ppb) { return (size_t)ppb * fsz * sizeof(float); };
+    // whole rounds of 256 output blocks per group where the shape allows it (no idle lanes in the last round of a group)
+    auto full_rounds = [&](int ppb) {
+      if (nb >= 256 || 256 % nb != 0) return true;
+      const int unit = 256 / nb;                                     // planes per round of 256 blocks
+      return ppb % unit == 0 || (major < unit && ppb == major);
+    };
+    const GroupPlan g = plan_plane_groups(major, std::min(major, 64), lds_of, full_rounds);
+    hipLaunchKernelGGL(upfirdn2d_planes_down2, dim3(g.grid), dim3(256), lds_of(g.ppb), st, x, k, out, p, g.ppb, rows, pitch, g.ngroups);
     return launch_status("upfirdn2d_planes_down2");
   }
   if (minor == 1 && kh * kw <= kMaxTaps && (int64_t)in_h * in_w <= 8192 && (int64_t)p.out_h * p.out_w <= 16384) {
