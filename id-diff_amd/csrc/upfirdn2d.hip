@@ -302,6 +302,67 @@ upfirdn2d_planes_down2(const float *__restrict__ x, const float *__restrict__ k,
   }
 }
 
+// ---------------------------------------------------------------- minor == 1, plain FIR on small planes, strip form
+// up == down == 1, kh, kw <= 4 (the FIR in front of a stride-2 convolution, up_or_down_sampling.py:144-178; out = in + 1 with pads (2, 2)):
+// the framed-plane layout of upfirdn2d_planes_down2; a thread produces a strip of four outputs of one row from its 4 x 7 window, read as
+// two ds_read_b128 per row (2 LDS instructions per output).  The row-walking kernel below -- one thread per output ROW, a serial chain of
+// out_w steps -- sat at 2.2 TB/s on [128, 128, 16, 16].
+__global__ void __launch_bounds__(256)
+upfirdn2d_planes_fir4(const float *__restrict__ x, const float *__restrict__ k, float *__restrict__ out, UfdParams p, int ppb, int rows,
+                      int pitch, int ngroups) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int psz = p.in_h * p.in_w, fsz = rows * pitch;
+  float T[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) T[a][b] = (a < p.kh && b < p.kw) ? k[(p.kh - 1 - a) * p.kw + (p.kw - 1 - b)] : 0.f;
+  {
+    float4 *z4 = reinterpret_cast<float4 *>(lds);
+    for (int i = tid; i < (ppb * fsz) >> 2; i += 256) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  const int sx = (p.out_w + 3) >> 2, ns = p.out_h * sx, osz = p.out_h * p.out_w;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int plane0 = grp * ppb;
+    const int nplanes = min(ppb, p.major - plane0);
+    {
+      const float4 *s4 = reinterpret_cast<const float4 *>(x + (int64_t)plane0 * psz);
+      const int w4 = p.in_w >> 2, per_plane = psz >> 2;
+      for (int i = tid; i < nplanes * per_plane; i += 256) {
+        const int q = i / per_plane, r = i - q * per_plane, iy = r / w4, c4 = r - iy * w4;
+        const float4 v = s4[i];
+        float *d = lds + q * fsz + (iy + p.pad_y0) * pitch + p.pad_x0 + 4 * c4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+    __syncthreads();
+    float *dst = out + (int64_t)plane0 * osz;
+    for (int i = tid; i < nplanes * ns; i += 256) {
+      const int q = i / ns, r = i - q * ns, oy = r / sx, S = r - oy * sx;
+      const float *w = lds + q * fsz + oy * pitch + 4 * S;
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float4 a = *reinterpret_cast<const float4 *>(w + rr * pitch), b = *reinterpret_cast<const float4 *>(w + rr * pitch + 4);
+        const float c[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) o[e] = fmaf(c[e + t], T[rr][t], o[e]);
+      }
+      float *op = dst + (int64_t)q * osz + oy * p.out_w + 4 * S;
+      const int left = p.out_w - 4 * S;
+      op[0] = o[0];
+      if (left > 1) op[1] = o[1];
+      if (left > 2) op[2] = o[2];
+      if (left > 3) op[3] = o[3];
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- minor == 1, plain FIR on small planes
 // up == down == 1, kh, kw <= 4 (the FIR in front of a stride-2 convolution, up_or_down_sampling.py:144-178): thread =
 // (plane, output row).  It walks its row with the three previous inputs of each of the four input rows in registers:
@@ -633,6 +694,16 @@ IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, in
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)major * p.out_h * p.out_w * minor;
 
+  if (minor == 1 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh <= 4 && kw <= 4 && pad_x0 >= 0 && pad_y0 >= 0 &&
+      pad_x0 <= 4 && pad_y0 <= 4 && in_w % 4 == 0 && (int64_t)in_h * in_w <= 4096 && ((uintptr_t)x & 15) == 0 && !option(OPT_UFD_ROWS)) {
+    // plain FIR, strip form: frame rows -pad_y0 .. out_h + 2 - pad_y0, columns -pad_x0 .. 4 ceil(out_w / 4) + 3 - pad_x0
+    const int rows = max(in_h + pad_y0, p.out_h + 3), pitch = (max(in_w + pad_x0, 4 * ((p.out_w + 3) / 4) + 4) + 3) & ~3;
+    const int fsz = rows * pitch;
+    auto lds_of = [&](int ppb) { return (size_t)ppb * fsz * sizeof(float); };
+    const GroupPlan g = plan_plane_groups(major, std::min(major, 64), lds_of, [](int) { return true; });
+    hipLaunchKernelGGL(upfirdn2d_planes_fir4, dim3(g.grid), dim3(256), lds_of(g.ppb), st, x, k, out, p, g.ppb, rows, pitch, g.ngroups);
+    return launch_status("upfirdn2d_planes_fir4");
+  }
   if (minor == 1 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh <= 4 && kw <= 4 && p.out_h <= 128 &&
       (int64_t)in_h * in_w <= 4096) {
     // plain FIR on small planes: one thread per (plane, output row)

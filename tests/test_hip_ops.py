@@ -76,6 +76,30 @@ def test_upfirdn2d_down2_block_kernel_vs_oracle(shape, pad, ksz):
     assert rel_err(y2.cpu(), ref) < 1e-6
 
 
+@pytest.mark.parametrize("shape,pad,ksz", [
+    ((128, 128, 16, 16), (2, 2), 4),   # the plain-FIR shapes of SURVEY 8-a5 (out = in + 1)
+    ((128, 256, 8, 8), (2, 2), 4),
+    ((128, 3, 32, 32), (2, 2), 4),
+    ((3, 33, 16, 24), (2, 2), 4),      # non-square, ragged last group
+    ((2, 9, 16, 16), (1, 2), 4),       # out = in: strips end on the plane's edge
+    ((2, 9, 12, 16), (0, 0), 3),       # valid convolution with 3 x 3 taps
+    ((2, 5, 16, 16), (3, 0), 2),
+    ((1, 1, 4, 4), (2, 2), 4),
+])
+def test_upfirdn2d_fir_strip_kernel_vs_oracle(shape, pad, ksz):
+    """upfirdn2d_planes_fir4 (strips of four outputs from zero-framed planes in LDS) against the oracle's restatement of
+    upfirdn2d_native (op/upfirdn2d.py:159-200), asymmetric random taps; and the row-walking kernel it replaced."""
+    g = torch.Generator().manual_seed(sum(shape) + ksz + 1)
+    x = torch.randn(*shape, generator=g)
+    k = torch.randn(ksz, ksz, generator=g)
+    ref = oops.upfirdn2d(x, k, up=1, down=1, pad=pad)
+    y = op.upfirdn2d(x.to(DEV), k.to(DEV), up=1, down=1, pad=pad)
+    assert y.shape == ref.shape and rel_err(y.cpu(), ref) < 1e-6
+    with _lib.thread_option("IDIFF_UFD_ROWS", 1):
+        y2 = op.upfirdn2d(x.to(DEV), k.to(DEV), up=1, down=1, pad=pad)
+    assert rel_err(y2.cpu(), ref) < 1e-6
+
+
 @pytest.mark.parametrize("C", [4, 8, 128, 3])
 @pytest.mark.parametrize("mode", [(1, 2, 1, 1), (2, 1, 2, 1), (1, 1, 2, 2)])
 def test_upfirdn2d_nhwc_minor(C, mode):
