@@ -334,18 +334,11 @@ upfirdn2d_planes_fir4(const float *__restrict__ x, const float *__restrict__ k, 
         const int q = i / per_plane, r = i - q * per_plane, iy = r / w4, c4 = r - iy * w4;
         const float4 v = s4[i];
         float *d = lds + q * fsz + (iy + p.pad_y0) * pitch + p.pad_x0 + 4 * c4;
-        if ((p.pad_x0 & 1) == 0) {               // pitch % 4 == 0: an even left frame makes the cell 8-byte aligned
-          *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.y); *reinterpret_cast<float2 *>(d + 2) = make_float2(v.z, v.w);
-        } else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       }
     }
     __syncthreads();
-    // Outputs go through LDS: the group's planes are ONE contiguous run of the output tensor, stored from there in whole 16-byte pieces
-    // (rows of out_w = in_w + 1 floats are not 16-byte multiples: stored strip by strip they were 4-byte stores 16 bytes apart).
-    // The staging area starts at the run's own misalignment, so that 16-byte pieces of the run are 16-byte pieces of LDS.
-    const int64_t g0 = (int64_t)plane0 * osz;
-    const int mis = (int)(g0 & 3);
-    float *ob = lds + ppb * fsz + mis;
+    float *dst = out + (int64_t)plane0 * osz;
     for (int i = tid; i < nplanes * ns; i += 256) {
       const int q = i / ns, r = i - q * ns, oy = r / sx, S = r - oy * sx;
       const float *w = lds + q * fsz + oy * pitch + 4 * S;
@@ -359,22 +352,12 @@ upfirdn2d_planes_fir4(const float *__restrict__ x, const float *__restrict__ k, 
 #pragma unroll
           for (int t = 0; t < 4; ++t) o[e] = fmaf(c[e + t], T[rr][t], o[e]);
       }
-      float *op = ob + q * osz + oy * p.out_w + 4 * S;
+      float *op = dst + (int64_t)q * osz + oy * p.out_w + 4 * S;
       const int left = p.out_w - 4 * S;
       op[0] = o[0];
       if (left > 1) op[1] = o[1];
       if (left > 2) op[2] = o[2];
       if (left > 3) op[3] = o[3];
-    }
-    __syncthreads();
-    {
-      float *dst = out + g0;
-      const int total = nplanes * osz, head = min(total, (4 - mis) & 3), body4 = (total - head) >> 2, tail0 = head + 4 * body4;
-      if (tid < head) dst[tid] = ob[tid];
-      const float4 *o4 = reinterpret_cast<const float4 *>(ob + head);
-      float4 *d4 = reinterpret_cast<float4 *>(dst + head);
-      for (int i = tid; i < body4; i += 256) d4[i] = o4[i];
-      if (tid < total - tail0) dst[tail0 + tid] = ob[tail0 + tid];
     }
     __syncthreads();
   }
@@ -715,8 +698,8 @@ IDIFF_API int idiff_upfirdn2d_f32(const float *x, const float *k, float *out, in
       pad_x0 <= 4 && pad_y0 <= 4 && in_w % 4 == 0 && (int64_t)in_h * in_w <= 4096 && ((uintptr_t)x & 15) == 0 && !option(OPT_UFD_ROWS)) {
     // plain FIR, strip form: frame rows -pad_y0 .. out_h + 2 - pad_y0, columns -pad_x0 .. 4 ceil(out_w / 4) + 3 - pad_x0
     const int rows = max(in_h + pad_y0, p.out_h + 3), pitch = (max(in_w + pad_x0, 4 * ((p.out_w + 3) / 4) + 4) + 3) & ~3;
-    const int fsz = rows * pitch, osz = p.out_h * p.out_w;
-    auto lds_of = [&](int ppb) { return ((size_t)ppb * (fsz + osz) + 8) * sizeof(float); };     // framed planes + output staging
+    const int fsz = rows * pitch;
+    auto lds_of = [&](int ppb) { return (size_t)ppb * fsz * sizeof(float); };
     const GroupPlan g = plan_plane_groups(major, std::min(major, 64), lds_of, [](int) { return true; });
     hipLaunchKernelGGL(upfirdn2d_planes_fir4, dim3(g.grid), dim3(256), lds_of(g.ppb), st, x, k, out, p, g.ppb, rows, pitch, g.ngroups);
     return launch_status("upfirdn2d_planes_fir4");
