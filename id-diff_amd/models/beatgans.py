@@ -87,6 +87,7 @@ class BeatGANsUNetModel(HipScoreModel):
     _gn_act = NCSNpp._gn_act
     _conv = NCSNpp._conv
     _pointwise = NCSNpp._pointwise
+    _pointwise_pairs = NCSNpp._pointwise_pairs
     _box = NCSNpp._box
     _cat = NCSNpp._cat
     _pack_conv = staticmethod(NCSNpp._pack_conv)
@@ -231,6 +232,7 @@ class BeatGANsUNetModel(HipScoreModel):
                 pk["lin"][skey] = (_lib.pairs_scale_from_rows(wqk, bqk, gam), _lib.pairs_scale_from_rows(wv, bv, gam))
             s_qk, s_v = pk["lin"][skey]
             _lib.attention256(qk, vt, mixed, B, C, s_qk, s_v, float(C) ** (-0.5), bias_v=bv)
+            return self._pointwise_pairs(pk, _T(mixed, x.H, x.W, C), wo, bo, s_v, residual=x.buf, stats=True)
         else:
             logits = torch.empty(B, HW, HW, device=dev, dtype=torch.float32)
             _lib.gemm(qk, qk[:, C:], out=logits, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B,

@@ -461,6 +461,24 @@ class NCSNpp(HipScoreModel):
         _lib.gemm(x.buf.view(-1, cin), w, out=y.buf.view(-1, cout), epilogue=_lib.make_epilogue(bias=bias, **ep))
         return y
 
+    def _pointwise_pairs(self, pk, x, w, bias, act_scale, stats=False, **ep):
+        """_pointwise on fp16 pairs for an activation that is NOT a GroupNorm's output but whose scale is known: ``act_scale`` = device
+        {s, 1 / s} (the attention output is a convex combination of the rows of v: never beyond v's range, so v's scale serves)."""
+        B = x.buf.shape[0]
+        cout, cin = w.shape
+        M = B * x.H * x.W
+        if not _lib.gemm_pairs_ok(M, cout, cin):
+            return self._pointwise(x, w, bias, stats=stats, **ep)
+        y = self._new(B, x.H, x.W, cout, x.buf)
+        if stats:
+            ns = _lib.gemm_colstats_split(M, cout, cin, cin, w.stride(0), x.H * x.W)
+            if ns > 0:
+                y.stats = (torch.empty(B * ns * cout * 2, device=x.buf.device, dtype=torch.float64), ns)
+                ep["colstats"] = y.stats[0]
+        _lib.gemm_pairs(x.buf.view(-1, cin), w, _lib._pairs_scale_of(pk, w), y.buf.view(-1, cout),
+                        epilogue=_lib.make_epilogue(bias=bias, **ep), act_scale=act_scale)
+        return y
+
     def _fir(self, x, pk, mode):
         B = x.buf.shape[0]
         n = pk["fir_len"]
@@ -562,6 +580,7 @@ class NCSNpp(HipScoreModel):
         vt = torch.empty(B, C, HW, device=dev, dtype=torch.float32)
         _lib.gemm_weight_times_normed_t(pk, wv, n.buf, vt, B, HW, C, pairs=pairs)
         mixed = torch.empty(B, HW, C, device=dev, dtype=torch.float32)
+        rs = _INV_SQRT2 if self.skip_rescale else 1.0
         if pairs and _lib.attention256_ok(B, HW, C):
             # QK^T -> softmax -> PV in one launch, the logits never written (csrc/attention.hip); the operands' power-of-two scales from
             # the projections' row norms (their input n has unit variance times gamma's scale)
@@ -571,6 +590,7 @@ class NCSNpp(HipScoreModel):
                 pk["nin"][key] = (_lib.pairs_scale_from_rows(wqk, bqk, gam), _lib.pairs_scale_from_rows(wv, bv, gam))
             s_qk, s_v = pk["nin"][key]
             _lib.attention256(qk, vt, mixed, B, C, s_qk, s_v, float(int(C) ** (-0.5)), bias_v=bv)
+            return self._pointwise_pairs(pk, _T(mixed, x.H, x.W, C), w3, b3, s_v, residual=x.buf, out_scale=rs, stats=True)
         else:
             logits = torch.empty(B, HW, HW, device=dev, dtype=torch.float32)
             _lib.gemm(qk, qk[:, C:], out=logits, M=HW, N=HW, K=C, lda=2 * C, ldb=2 * C, ldc=HW, batch=B,
@@ -578,7 +598,6 @@ class NCSNpp(HipScoreModel):
             _lib.softmax_rows(logits, logits, B * HW, HW, float(int(C) ** (-0.5)))
             _lib.gemm(logits, vt, out=mixed, M=HW, N=C, K=HW, lda=HW, ldb=HW, ldc=C, batch=B,
                       stride_a=HW * HW, stride_b=C * HW, stride_c=HW * C, epilogue=_lib.make_epilogue(bias=bv))
-        rs = _INV_SQRT2 if self.skip_rescale else 1.0
         return self._pointwise(_T(mixed, x.H, x.W, C), w3, b3, residual=x.buf, out_scale=rs, stats=True)
 
     def _downsample(self, idx, x, pk, **ep):

@@ -113,10 +113,11 @@ def test_config5_pipeline_end_to_end_vs_oracle(tmp_path):
 # ------------------------------------------------------------------------------------------ BASELINE config 3, the headline
 class _RouteCounter:
     """Counts the launches of the contraction entry points by form, so that a test can assert WHICH kernels served a workload."""
-    NAMES = ("conv2d_winograd43", "conv2d_winograd", "conv2d_nhwc", "gemm_pairs", "gemm", "gemm_2src")
+    NAMES = ("conv2d_winograd43", "conv2d_winograd", "conv2d_nhwc", "gemm_pairs", "gemm", "gemm_2src", "attention256", "softmax_rows")
 
     def __init__(self):
-        self.n = {"wino43_pairs": 0, "wino43_fp32": 0, "wino22": 0, "igemm_conv": 0, "gemm_pairs": 0, "gemm": 0, "gemm_2src": 0}
+        self.n = {"wino43_pairs": 0, "wino43_fp32": 0, "wino22": 0, "igemm_conv": 0, "gemm_pairs": 0, "gemm": 0, "gemm_2src": 0,
+                  "attention256": 0, "softmax_rows": 0}
         self._orig = {}
 
     def __enter__(self):
@@ -134,6 +135,8 @@ class _RouteCounter:
         wrap("gemm_pairs", lambda *a, **k: "gemm_pairs")
         wrap("gemm", lambda *a, **k: "gemm")
         wrap("gemm_2src", lambda *a, **k: "gemm_2src")
+        wrap("attention256", lambda *a, **k: "attention256")
+        wrap("softmax_rows", lambda *a, **k: "softmax_rows")
         return self
 
     def __exit__(self, *exc):
@@ -182,11 +185,13 @@ def test_config3_full_size_production_routing_vs_oracle(golden):
         with _RouteCounter() as routes:
             S = builder.build(xd, 128, seed=POINT_SEED)
     _note(f"config 3: routing per point {routes.n}")
-    # two launch sets x (88 GroupNorm-fed 3x3 convs on fp16 pairs; the five 256-token attention blocks' {q|k, V^T} and the 16-token
-    # middle block's q|k on pair GEMMs -- its V^T has N = 16 tokens, below the pair form's N > 64, and stays on six products); no conv on
-    # the fp32 F(4x4) or the F(2x2) kernel; the stem, the three stride-2 convs and the 128 -> 3 head on the implicit-GEMM entry point
+    # two launch sets x (88 GroupNorm-fed 3x3 convs on fp16 pairs; the five 256-token attention blocks' {q|k, V^T, output projection} and
+    # the 16-token middle block's q|k on pair GEMMs -- its V^T has N = 16 tokens, below the pair form's N > 64, and stays on six
+    # products; the five 256-token blocks' QK^T -> softmax -> PV in ONE launch each, the middle block's in three); no conv on the fp32
+    # F(4x4) or the F(2x2) kernel; the stem, the three stride-2 convs and the 128 -> 3 head on the implicit-GEMM entry point
     assert routes.n["wino43_pairs"] == 2 * 88 and routes.n["wino43_fp32"] == 0 and routes.n["wino22"] == 0, routes.n
-    assert routes.n["gemm_pairs"] == 2 * (5 * 2 + 1), routes.n
+    assert routes.n["gemm_pairs"] == 2 * (5 * 3 + 1), routes.n
+    assert routes.n["attention256"] == 2 * 5 and routes.n["softmax_rows"] == 2 * 1, routes.n
     assert routes.n["igemm_conv"] == 2 * 5, routes.n
     assert S.shape == (4480, 3072) and bool(torch.isfinite(S).all())
 
