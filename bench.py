@@ -63,9 +63,9 @@ WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=
 # PMC traffic tables (separate FETCH_SIZE / WRITE_SIZE passes, scripts/profile_round.sh), each stamped with the sha256 of the kernel
 # source it was measured on: F(4x4,3x3) (the dominant kernel) and F(2x2,3x3)
 _CSRC = os.path.join("id-diff_amd", "csrc")
-TRAFFIC_TABLES = {"winograd43h_kernel": (os.path.join("profiles", "r04_wino43h_traffic.json"),
+TRAFFIC_TABLES = {"winograd43h_kernel": (os.path.join("profiles", "r05_wino43h_traffic.json"),
                                          (os.path.join(_CSRC, "winograd43h.hip"), os.path.join(_CSRC, "winograd43_shared.h"))),
-                  "winograd43_kernel": (os.path.join("profiles", "r04_wino43_traffic.json"),
+                  "winograd43_kernel": (os.path.join("profiles", "r05_wino43_traffic.json"),
                                         (os.path.join(_CSRC, "winograd43.hip"), os.path.join(_CSRC, "winograd43_shared.h"))),
                   "winograd_kernel": (os.path.join("profiles", "r03_wino_traffic.json"), (os.path.join(_CSRC, "winograd.hip"),))}
 
