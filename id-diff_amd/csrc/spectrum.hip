@@ -1214,13 +1214,18 @@ int bisect_launch(const double *diag, const double *offd, int P, int D, double *
   const size_t lds = use_lds ? (size_t)D * sizeof(double2) : 0;
   if (lds > 64 * 1024) {
     static idiff::AttrGuard guard;
-    const void *fns[2] = {reinterpret_cast<const void *>(bisect_kernel<true, 1>), reinterpret_cast<const void *>(bisect_kernel<true, 8>)};
-    if (int rc = idiff::set_dynamic_lds_once(guard, fns, 2, 8192 * (int)sizeof(double2), "bisect")) return rc;
+    const void *fns[3] = {reinterpret_cast<const void *>(bisect_kernel<true, 1>), reinterpret_cast<const void *>(bisect_kernel<true, 8>),
+                          reinterpret_cast<const void *>(bisect_kernel<true, 16>)};
+    if (int rc = idiff::set_dynamic_lds_once(guard, fns, 3, 8192 * (int)sizeof(double2), "bisect")) return rc;
   }
   // 64 eigenvalues per workgroup would spread the work over more CUs, but the chain length (D steps per
   // bisection) is the latency; 256 threads keep the broadcast LDS traffic low.
   const bool few = (int64_t)P * idiff::ceil_div(D, 256) <= 64;     // most SIMDs would idle: 8 lanes per eigenvalue
-  if (use_lds && few)
+  // 16 lanes per eigenvalue (four bits per sweep: ~12 dependent sweeps instead of ~16) while that still leaves one wave per SIMD
+  // (P D / 4 waves on 1024 SIMDs); beyond it the extra lanes would queue behind each other
+  if (use_lds && few && (int64_t)P * D * 16 / 64 <= 1024)
+    hipLaunchKernelGGL((bisect_kernel<true, 16>), dim3(idiff::ceil_div(D * 16, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv);
+  else if (use_lds && few)
     hipLaunchKernelGGL((bisect_kernel<true, 8>), dim3(idiff::ceil_div(D * 8, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv);
   else if (use_lds)
     hipLaunchKernelGGL((bisect_kernel<true, 1>), dim3(idiff::ceil_div(D, 256), P), dim3(256), lds, st, diag, offd, D, eig, sv);
