@@ -4,7 +4,7 @@ on the draws of the device path's Philox stream restated on the CPU (oracle/phil
 
 Run once in the build container (8 cores; ~10 min of oracle forwards + the SVDs):
 
-    python tests/golden/make_cfg3_point.py
+    python tests/golden/make_cfg3_point.py [point]      (default 1 -> cfg3_point.npz; 3 -> cfg3_point3.npz)
 
 What the fixture keeps (S itself is 55 MB and is not stored):
 * ``rows`` / ``S_rows``: 192 rows of the oracle's S, spread over both 2240-row launch sets of the HIP driver and
@@ -37,6 +37,15 @@ from oracle import dim as odim, models as omodels, philox, sde as osde  # noqa: 
 
 MODEL_SEED, IMAGE_SEED, N_IMAGES, IMAGE_INDEX, POINT = 0, 100, 9, 1, 1   # bench.py defaults: Workload on rank 0, 8 steps + 1 warm-up, first timed point
 POINT_SEED = 1234 + 1000003 * (POINT + 1)
+
+
+def point_seed(point):
+    """bench.py: Workload.point(i) on rank 0."""
+    return 1234 + 1000003 * (point + 1)
+
+
+def fixture_name(point):
+    return "cfg3_point.npz" if point == POINT else f"cfg3_point{point}.npz"
 ROWS = np.r_[0:32, 1100:1132, 2208:2272, 3400:3432, 4448:4480]      # 192 rows; 2208..2271 straddle the launch-set boundary at 2240
 T = 1e-5                                                             # sampling_eps of the VE SDE
 
@@ -52,17 +61,19 @@ def oracle_model(cfg):
     return omodels.create_model(cfg).eval()
 
 
-def data_point():
-    return smooth_decoder_images(N_IMAGES, [3, 32, 32], 64, seed=IMAGE_SEED)[IMAGE_INDEX]
+def data_point(point=POINT):
+    return smooth_decoder_images(N_IMAGES, [3, 32, 32], 64, seed=IMAGE_SEED)[point]
 
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "8")))
+    point = int(sys.argv[1]) if len(sys.argv) > 1 else POINT       # the bench's points 1 .. 8: different images, different IDs
+    POINT_SEED = point_seed(point)
     cfg = cfg3()
     model = oracle_model(cfg)
     sde = osde.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
     score_fn = osde.get_score_fn(sde, model)
-    x0 = data_point()
+    x0 = data_point(point)
     B = int(cfg.training.batch_size)
     nb, extra, rows = odim.batching(tuple(x0.shape), B)
     assert rows == 4480 and extra == 0
@@ -85,10 +96,10 @@ if __name__ == "__main__":
     print("top gaps (index i of s[i]-s[i+1], value):", [(int(i) + 1, float(gaps[i])) for i in order])
     print("ID fp32", odim.estimate_dim(sv32.tolist()), "ID fp64", odim.estimate_dim(sv64.tolist()), "sv[:4]", sv64[:4], "sv[-3:]", sv64[-3:])
     np.savez_compressed(
-        os.path.join(HERE, "cfg3_point.npz"), x0=x0.numpy(), rows=ROWS, S_rows=S[ROWS].numpy(), sv_f32=sv32, sv_f64=sv64,
+        os.path.join(HERE, fixture_name(point)), x0=x0.numpy(), rows=ROWS, S_rows=S[ROWS].numpy(), sv_f32=sv32, sv_f64=sv64,
         id_f32=np.array(odim.estimate_dim(sv32.tolist())), id_f64=np.array(odim.estimate_dim(sv64.tolist())),
         gap_index=(order + 1).astype(np.int64), gap_value=gaps[order], colmean=S.double().mean(dim=0).numpy(),
         fro2=np.array(float((centred.double() ** 2).sum())), weight_abs_sums=weight_abs_sums(model),
-        point_seed=np.array(POINT_SEED), torch_version=np.array(torch.__version__))
-    torch.save(S, os.path.join(ROOT, "gpurun_out", "cfg3_oracle_S.pt"))   # scratch copy (not tracked) for offline experiments
-    print("wrote cfg3_point.npz in", time.time() - t0, "s")
+        point_seed=np.array(POINT_SEED), point=np.array(point), torch_version=np.array(torch.__version__))
+    torch.save(S, os.path.join(ROOT, "gpurun_out", f"cfg3_oracle_S_{point}.pt"))   # scratch copy (not tracked) for offline experiments
+    print("wrote", fixture_name(point), "in", time.time() - t0, "s")
