@@ -322,3 +322,31 @@ def test_native_ops_in_float64_and_float16(golden):
             nat = oops.fused_bias_act_native(x, b, None, 3, 0, 0.2, 1.25)
             assert nat.dtype == ref.dtype
             np.testing.assert_allclose(nat.astype(np.float64), ref.astype(np.float64), rtol=tol, atol=tol * 1e-3)
+
+
+def test_philox_restatement_known_answers_and_cfg3_fixture_rows(golden):
+    """oracle/philox.py (the device's noise stream restated for the CPU): Random123's known answer for Philox4x32-10 on the zero counter /
+    zero key, N(0, 1) moments, independence of how rows are cut; and the full-size config-3 fixture is what the oracle network gives on
+    those draws (two of its 192 rows recomputed here)."""
+    import numpy as np
+    import torch
+    from oracle import philox, models as omodels, sde as osde
+    from golden.make_cfg3_point import T, cfg3, data_point, oracle_model, point_seed
+    w = philox.philox4x32_10(np.zeros(1, np.uint32), np.zeros(1, np.uint32), 0)
+    assert [int(v[0]) for v in w] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]      # Random123 kat_vectors: philox4x32 10, zeros
+    z = philox.normal_rows(99, 3072, 0, 64)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
+    np.testing.assert_array_equal(philox.normal_rows(99, 3072, 10, 5), z[10:15])          # a row's draws do not depend on the cut
+    fx = golden("cfg3_point.npz")
+    cfg = cfg3()
+    model = oracle_model(cfg)
+    sde = osde.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
+    x0 = data_point(1)
+    rows = fx["rows"][[0, 100]]
+    zz = torch.from_numpy(np.stack([philox.normal_rows(point_seed(1), 3072, int(r), 1)[0] for r in rows])).view(2, 3, 32, 32)
+    t = torch.ones(2) * T
+    mean, std = sde.marginal_prob(x0.unsqueeze(0).repeat(2, 1, 1, 1), t)
+    with torch.no_grad():
+        got = osde.get_score_fn(sde, model)(mean + std[:, None, None, None] * zz, t).reshape(2, -1)
+    ref = torch.from_numpy(fx["S_rows"][[0, 100]])
+    assert float((got.double() - ref.double()).norm() / ref.double().norm()) < 1e-5       # batch shape 2 vs 128: fp32 summation order only
