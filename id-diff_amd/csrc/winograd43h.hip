@@ -45,6 +45,9 @@ constexpr size_t H4_LDS_BYTES = (2 * H4_STAGE_BYTES > (int)sizeof(float) * F4_Z_
 #ifndef IDIFF_W43H_TOUCH_AT
 #define IDIFF_W43H_TOUCH_AT 8
 #endif
+#ifndef IDIFF_W43H_DMA_AT
+#define IDIFF_W43H_DMA_AT 0
+#endif
 #ifndef IDIFF_W43H_BRING
 #define IDIFF_W43H_BRING 3
 #endif
@@ -257,6 +260,23 @@ winograd43h_kernel(const Wino43Params p) {
     for (int j = 0; j < 6; ++j) stage_col(buf, j);
   };
 
+#ifdef IDIFF_W43H_DIAG_DMA
+  // Timing-only build (scripts/wino43h_ab.py, results wrong by construction): what the K loop would cost if the transformed, pair-cut
+  // patches V came READY from HBM (written by the producing GroupNorm pass) and went global -> LDS by LDS-DMA -- no patch registers, no
+  // transform, no LDS stores; each wave moves its ninth of the 73,728-byte stage with nine 1 KB requests.  The source is the input tensor
+  // itself, read as a stream of stage-sized blocks (one per workgroup row and step, shared by the workgroups of the other cout tiles).
+  auto dma_stage = [&](int buf, int step) __attribute__((always_inline)) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    const uint32_t blocks = (p.x_bytes - H4_STAGE_BYTES) / H4_STAGE_BYTES;
+    const uint32_t blk = ((uint32_t)tile_m * (uint32_t)nsteps + (uint32_t)min(step, nsteps - 1)) % (blocks ? blocks : 1u);
+    const int base = (int)(blk * (uint32_t)H4_STAGE_BYTES) + wave * (H4_STAGE_BYTES / 8);
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void *)(ldsb + buf * H4_STAGE_BYTES + wave * (H4_STAGE_BYTES / 8) + i * 1024), 16,
+                                               lane * 16, base + i * 1024, 0, 0);
+  };
+#endif
+
   // ---------------------------------------------------------------- contraction
   floatx16 acc[9];
 #pragma unroll
@@ -309,6 +329,9 @@ winograd43h_kernel(const Wino43Params p) {
       if (pp + BRING < 9) load_b(pp + BRING, s); else if (!LAST) load_b(pp + BRING - 9, s + 1);
 #endif
       if (!LAST && pp == IDIFF_W43H_TOUCH_AT) touch(s + IDIFF_W43H_TOUCH_AHEAD);
+#ifdef IDIFF_W43H_DIAG_DMA
+      if (!LAST && pp == IDIFF_W43H_DMA_AT) dma_stage(buf ^ 1, s + 1);
+#endif
       if (!LAST) {
         __builtin_amdgcn_sched_barrier(0);
 #ifdef IDIFF_W43H_STAMP
@@ -346,6 +369,9 @@ winograd43h_kernel(const Wino43Params p) {
   __builtin_amdgcn_sched_barrier(0);
 #endif
   stage(0);
+#ifdef IDIFF_W43H_DIAG_DMA
+  dma_stage(0, 0);
+#endif
 #ifdef IDIFF_W43H_STAMP
   __builtin_amdgcn_sched_barrier(0);
   const uint64_t st_pro2 = __builtin_amdgcn_s_memrealtime();     // first stage written by this wave
