@@ -20,7 +20,8 @@ fi
 if [ -n "$VARIANT" ]; then
   case "$VARIANT" in *[!A-Za-z0-9_]*) echo "build.sh: IDIFF_VARIANT must be alphanumeric" >&2; exit 4;; esac
   OUT="libidiff_hip.$VARIANT.so"
-  FLAGS="$FLAGS $VFLAGS -DIDIFF_VARIANT_FLAGS=\"$(printf '%s' "${VFLAGS:-(none)}" | tr -d '\\"')\""
+  # (the flags as ONE shell word inside the string literal: $FLAGS is expanded unquoted below)
+  FLAGS="$FLAGS $VFLAGS -DIDIFF_VARIANT_FLAGS=\"$(printf '%s' "${VFLAGS:-(none)}" | tr -d '\\"' | tr ' ' ',')\""
 fi
 OBJ=$(mktemp -d)
 trap 'rm -rf "$OBJ"' EXIT
