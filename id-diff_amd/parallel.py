@@ -43,6 +43,9 @@ def init_from_env(backend=None):
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", local_rank)    # eager communicator on THIS device
+        rdzv = os.environ.get("IDIFF_RDZV_FILE")     # set by launch_local_ranks only: no port to race for
+        if rdzv:
+            kwargs["init_method"] = "file://" + rdzv
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
 
@@ -94,13 +97,18 @@ def launch_local_ranks(script, argv, n, need_devices=True, timeout=None):
         raise SystemExit(f"error: --gpus {n}")
     if need_devices and visible_devices() < (1 if shares_card() else n):
         raise SystemExit(f"error: {n} devices needed, {visible_devices()} visible")
-    with socket.socket() as s:                       # a free rendezvous port on the loop-back interface
-        s.bind(("127.0.0.1", 0))
+    with socket.socket() as s:                       # a free port on the loop-back interface (kept in the environment for tools
+        s.bind(("127.0.0.1", 0))                      # that read MASTER_PORT; the ranks themselves meet through a file, below)
         port = s.getsockname()[1]
+    # The ranks of a self-launched job rendezvous through a FILE store in a directory of this launch (init_from_env): a port picked
+    # by bind-close-reuse can be taken by another job of the node between the close and rank 0's listen
+    import tempfile
+    rdzv_dir = tempfile.mkdtemp(prefix="idiff_rdzv_")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IDIFF_SELF_LAUNCHED="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IDIFF_SELF_LAUNCHED="1",
+                   IDIFF_RDZV_FILE=os.path.join(rdzv_dir, "store"))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
         procs.append(subprocess.Popen([sys.executable, script, *argv], env=env, stdout=subprocess.PIPE, text=True))
 
@@ -144,6 +152,8 @@ def launch_local_ranks(script, argv, n, need_devices=True, timeout=None):
             procs[r].wait()
     for t in threads:
         t.join(timeout=5)
+    import shutil
+    shutil.rmtree(rdzv_dir, ignore_errors=True)
     return rc
 
 
