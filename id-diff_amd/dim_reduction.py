@@ -58,8 +58,10 @@ class ScoreMatrixBuilder:
         self.inflight_rows = inflight_rows
         # OPT-IN (IDIFF_CONCURRENT_SETS=2 / concurrent_sets=2): consecutive launch sets of a point go to two worker streams,
         # so the tail of every launch and the small-map layers of one forward fill up with the other forward's work
-        # (two 2240-row NCSN++ forwards 476.6 -> 468 ms, scripts/two_stream_probe.py).  Same kernels, same bits.  Off by
-        # default: overlapped launches are not what bench.py's per-kernel events and the profiles are defined on.
+        # (two 2240-row NCSN++ forwards 476.6 -> 468 ms in round 3, scripts/two_stream_probe.py).  Same kernels, same bits.  Off by
+        # default -- and since the convolutions moved to the one-workgroup-per-CU pair kernel it LOSES: round 5 re-measured
+        # bench.py --concurrent-sets 2 at 10.4-14.2k evals/s (erratic: how the two streams' launches interleave) against 16.1k in
+        # sequence (profiles/HISTORY_r05.md).  Kept for the parity test of the stream logic only.
         if concurrent_sets is None:
             concurrent_sets = int(os.environ.get("IDIFF_CONCURRENT_SETS", "1"))
         self.concurrent_sets = max(1, int(concurrent_sets))
