@@ -215,7 +215,13 @@ gn_apply_rows_kernel(const float *__restrict__ x, int C, const float *__restrict
   for (; p + 3 * RP < p_hi; p += 4 * RP) {
     float4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = src[(int64_t)(p + u * RP) * src_stride];
+    for (int u = 0; u < 4; ++u) {
+#if defined(IDIFF_GN_NT_LOAD)      // A/B builds (scripts/gn_nt_ab.py)
+      v[u] = __builtin_nontemporal_load(&src[(int64_t)(p + u * RP) * src_stride]);
+#else
+      v[u] = src[(int64_t)(p + u * RP) * src_stride];
+#endif
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float4 o;
@@ -223,7 +229,11 @@ gn_apply_rows_kernel(const float *__restrict__ x, int C, const float *__restrict
       o.y = act_apply((v[u].y - mu[1]) * s[1] + t[1], act);
       o.z = act_apply((v[u].z - mu[2]) * s[2] + t[2], act);
       o.w = act_apply((v[u].w - mu[3]) * s[3] + t[3], act);
+#if defined(IDIFF_GN_NT_STORE)
+      __builtin_nontemporal_store(o, &dst[(int64_t)(p + u * RP) * CVt]);
+#else
       dst[(int64_t)(p + u * RP) * CVt] = o;
+#endif
     }
   }
   for (; p < p_hi; p += RP) {
