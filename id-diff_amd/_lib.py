@@ -68,6 +68,11 @@ _SIGNATURES = {
     "idiff_winograd43h_weight_floats": (c_i64, [c_i, c_i]),
     "idiff_winograd43h_pack_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "idiff_conv2d_winograd43h_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),
+    "idiff_conv2d_wino1d_ok": (c_i, [c_i] * 5),
+    "idiff_conv2d_wino1d_colstats_split": (c_i, [c_i] * 5),
+    "idiff_wino1d_weight_floats": (c_i64, [c_i, c_i]),
+    "idiff_wino1d_pack_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    "idiff_conv2d_wino1d_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_p]),
     "idiff_conv2d_winograd_split_ok": (c_i, [c_i] * 5),
     "idiff_winograd_split_weight_floats": (c_i64, [c_i, c_i]),
     "idiff_winograd_pack_split_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
@@ -500,6 +505,33 @@ def conv2d_winograd43(x, u, out, B, H, W, Cin, Cout, epilogue=None, pairs=False)
         raise RuntimeError(f"conv2d_winograd43: a filter bank of {u.numel()} floats ({36 * Cin * Cout} expected): pack it with winograd43_pack")
     _check(lib().idiff_conv2d_winograd43_f32(x.data_ptr(), u.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, ep, _stream()),
            "idiff_conv2d_winograd43_f32")
+    return out
+
+
+def conv2d_wino1d_ok(B, H, W, Cin, Cout):
+    """True when the row-wise F(4, 3) kernel on fp16 pairs (csrc/wino1d.hip) serves this geometry (W in {8, 16, 32}; off under
+    IDIFF_NO_WINOGRAD / IDIFF_NO_WINO43H / IDIFF_NO_WINO1D)."""
+    return bool(lib().idiff_conv2d_wino1d_ok(B, H, W, Cin, Cout))
+
+
+def conv2d_wino1d_colstats_split(B, H, W, Cin, Cout):
+    return lib().idiff_conv2d_wino1d_colstats_split(B, H, W, Cin, Cout)
+
+
+def wino1d_pack(wt, Cin, Cout):
+    """wt [Cout, 3, 3, Cin] -> the filter bank of idiff_conv2d_wino1d_f32 (scaled fp16 pairs of (G g[ky])[i], 18 * Cin * Cout + 4 floats)."""
+    if wt.dtype != torch.float32 or not wt.is_contiguous() or tuple(wt.shape) != (Cout, 3, 3, Cin):
+        raise RuntimeError(f"wino1d_pack: expected contiguous float32 {Cout}x3x3x{Cin} weights, got {wt.dtype} {tuple(wt.shape)}")
+    u = torch.empty(lib().idiff_wino1d_weight_floats(Cin, Cout), device=wt.device, dtype=torch.float32)
+    _check(lib().idiff_wino1d_pack_f32(wt.data_ptr(), u.data_ptr(), Cin, Cout, _stream()), "idiff_wino1d_pack_f32")
+    return u
+
+
+def conv2d_wino1d(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+    ep = ctypes.byref(epilogue) if epilogue is not None else None
+    if u.numel() != 18 * Cin * Cout + 4:
+        raise RuntimeError(f"conv2d_wino1d: a bank of {u.numel()} floats ({18 * Cin * Cout + 4} expected): pack it with wino1d_pack")
+    _check(lib().idiff_conv2d_wino1d_f32(x.data_ptr(), u.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, ep, _stream()), "idiff_conv2d_wino1d_f32")
     return out
 
 

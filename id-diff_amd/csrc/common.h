@@ -37,7 +37,7 @@ inline int launch_status(const char *what) {
 // is loaded (no getenv on any launch path); idiff_set_option() flips them afterwards.
 enum Option { OPT_NO_WINOGRAD, OPT_NO_COLSTATS, OPT_NO_PIPE, OPT_SCALAR_EPILOGUE, OPT_DBUF_ONLY, OPT_TRIDIAG_ONESTAGE,
               OPT_UFD_ROWS, OPT_CHASE_WAVEFRONT, OPT_WINO_NGROUP, OPT_GRAM_SMALL_TILES, OPT_CHASE_SPIN_LIMIT, OPT_FAKE_CU_COUNT,
-              OPT_SBR_SYNC, OPT_SBR_FULL, OPT_NO_SPLIT, OPT_WINO_SPLIT, OPT_SBR_LOOKAHEAD, OPT_NO_WINO43, OPT_NO_WINO43H, OPT_NO_PAIRS, OPT_PAIRS_MIN_TILES, OPT_NO_FUSED_ATTN, OPT_COUNT };
+              OPT_SBR_SYNC, OPT_SBR_FULL, OPT_NO_SPLIT, OPT_WINO_SPLIT, OPT_SBR_LOOKAHEAD, OPT_NO_WINO43, OPT_NO_WINO43H, OPT_NO_PAIRS, OPT_PAIRS_MIN_TILES, OPT_NO_FUSED_ATTN, OPT_NO_WINO1D, OPT_COUNT };
 bool option(Option o);
 int option_value(Option o);   // the integer behind a switch (IDIFF_WINO_NGROUP: output-channel tiles per scheduling group)
 

@@ -18,7 +18,7 @@ const char *const kOptionNames[OPT_COUNT] = {"IDIFF_NO_WINOGRAD", "IDIFF_NO_COLS
                                              "IDIFF_DBUF_ONLY", "IDIFF_TRIDIAG_ONESTAGE", "IDIFF_UFD_ROWS", "IDIFF_CHASE_WAVEFRONT",
                                              "IDIFF_WINO_NGROUP", "IDIFF_GRAM_SMALL_TILES", "IDIFF_CHASE_SPIN_LIMIT",
                                              "IDIFF_FAKE_CU_COUNT", "IDIFF_SBR_SYNC", "IDIFF_SBR_FULL", "IDIFF_NO_SPLIT", "IDIFF_WINO_SPLIT", "IDIFF_SBR_LOOKAHEAD",
-                                             "IDIFF_NO_WINO43", "IDIFF_NO_WINO43H", "IDIFF_NO_PAIRS", "IDIFF_PAIRS_MIN_TILES", "IDIFF_NO_FUSED_ATTN"};
+                                             "IDIFF_NO_WINO43", "IDIFF_NO_WINO43H", "IDIFF_NO_PAIRS", "IDIFF_PAIRS_MIN_TILES", "IDIFF_NO_FUSED_ATTN", "IDIFF_NO_WINO1D"};
 struct OptionTable {
   int v[OPT_COUNT];
   OptionTable() {

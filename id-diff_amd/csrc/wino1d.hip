@@ -1,0 +1,564 @@
+// 3x3 / stride 1 / pad 1 convolutions by Winograd's F(4, 3) ALONG THE IMAGE ROWS ONLY -- the three filter rows stay a direct sum -- with
+// the 18 contractions per 1 x 4 output tile on the fp16 matrix cores of gfx950 (fp16 pairs, as winograd43h.hip).
+//
+// Why a second pair kernel.  winograd43h_kernel (F(4x4, 3x3): 2.25 multiplications per output) is not bound by its matrix instructions
+// (22 % of the SIMD cycles) but by what its workgroup has to bring in per K step: 36 positions x 64 channels of U (147 KB) for 512 output
+// pixels, because 36 accumulators per tile and channel leave room for no more pixels in the register file, plus 6 x 6 patches that repeat
+// their neighbours' pixels -- 2,040 - 2,230 128-byte lines from L2 per workgroup and step, at the 16 TB/s the L2 -> L1 path delivers chip-wide
+// (profiles/r05_wino43h_l1_requests.txt: the time follows the line count).  Transforming along x only costs twice the matrix work
+// (4.5 multiplications per output) and HALF the lines: six positions x three filter rows of U are 74 KB per step, shared by all 512 pixels
+// of the workgroup, and the input is read as whole image rows -- every pixel once per step, no horizontal halo at all, one halo row above or
+// below the block.  The matrix cores have the room: 108 instructions per wave and step are 3,456 cycles of a step that took 9,300.
+//
+//   out[r][4t + a] = sum_i A^T[a][i] sum_ky ( V[r + ky - 1][t][i] . U[i][ky] ),   V[r][t][.] = B^T x[r][4t - 1 .. 4t + 4],   U[.][ky] = G g[ky][.]
+//   (same points 0, +-2/3, +-3/2, inf and the same B^T, G, A^T as winograd43_shared.h, used in one dimension: the transform's gain is
+//   5.4 where the 2-D form has 29.3, so |x| may reach 12,000 before a pair overflows, and the rounding of the transform enters once)
+//
+// Workgroup: 256 threads = 4 waves, ONE PER SIMD (up to 512 registers each), 512 output pixels x 64 output channels:
+//   RB = 512 / W whole image rows (W = 32: half an image, 16: two images, 8: eight), 128 row-tiles of 1 x 4 pixels, six positions each.
+//   Wave (h, ph): output channels 32 h .. 32 h + 31, positions 3 ph .. 3 ph + 2, all four groups of 32 row-tiles: 12 accumulator tiles of
+//   32 x 32 = 192 registers.  Every U fragment (position, filter row, channel half: 2 KB of pairs) is loaded by exactly one wave, straight from
+//   L2 into registers, three (position, filter row) combinations ahead.
+// K step: 16 input channels.  Per wave and step nine combinations (position, filter row) x four groups x three matrix instructions
+//   (hi hi, hi lo, lo hi); the V operand of (group, filter row ky) is the stage's rows 4 g + ky - 1 .. 4 g + ky + 2: the same LDS image read at a
+//   row's distance, no copy per filter row.  Rows that lie outside the image of an output row (a block of small maps holds several images) are
+//   read from an all-zero entry instead.
+// Loader: thread (channel c = tid % 16, k = tid / 16) holds the 32 pixels of the image rows k NR .. k NR + NR - 1 of the block (NR = RB / 16)
+//   for its channel -- 16 consecutive lanes read the 64 contiguous bytes of a pixel --, threads k < 2 W / 4 additionally one row-tile (six
+//   pixels) of the halo row above or below the block: 38 registers that hold the NEXT step's pixels while this step is contracted.  Per
+//   combination one row-tile is transformed (12 fmas), cut into pairs, exchanged with the neighbouring channel's lane and stored
+//   (as winograd43h_kernel's stage), and the pixels no later tile needs are requested again for the step after next.
+// Stage (LDS): [6 positions][(RB + 2) W / 4 + 1 entries][64 B], entry = (row slot, tile), the last one all zero; the four 16-byte pieces
+//   (plane, channel half) of entry e are stored at piece ^ ((e >> 2) & 3): a ds_read_b128 of 32 consecutive entries is conflict-free from any
+//   even first entry (checked by enumeration over the instruction's lane groups).  Two stages <= 111,360 B.
+// U (global): [Cin/16][Cout/64][18 slots = position * 3 + filter row][2 planes][64 cout][16 cin] fp16 + 4 floats of header (the factor that
+//   undoes the power-of-two scaling first).
+// Tail: each wave forms its half of A^T m (positions 0-2 or 3-5) for its 64 x 2 row-tiles, the two halves meet in LDS ([128 row-tiles][4 pixels]
+//   [64 channels] fp32: each wave parks two groups, then adds its other two onto what the partner parked), and thread (4 channels, 32
+//   consecutive pixels) applies the epilogue of idiff_conv2d_nhwc_f32 and stores 16 bytes per pixel.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+constexpr double R1_A = 2.0 / 3.0, R1_B = 1.5;                     // the interpolation points of winograd43_shared.h
+constexpr float R1_a = (float)R1_A, R1_b = (float)R1_B, R1_a2 = (float)(R1_A * R1_A), R1_b2 = (float)(R1_B * R1_B),
+                R1_a3 = (float)(R1_A * R1_A * R1_A), R1_b3 = (float)(R1_B * R1_B * R1_B), R1_ab2 = (float)(R1_A * R1_A + R1_B * R1_B);
+constexpr int R1_THREADS = 256;
+constexpr int R1_COUT = 64;
+constexpr int R1_KC = 16;
+constexpr int R1_PIXELS = 512;                                     // output pixels of a workgroup
+constexpr int R1_RT = R1_PIXELS / 4;                               // its row-tiles
+constexpr int R1_NSLOT = 18;                                       // (position, filter row)
+constexpr int R1_SLOT_BYTES = 2 * 64 * R1_KC * 2;                  // 4096
+constexpr int R1_PLANE_BYTES = 64 * R1_KC * 2;                     // 2048
+constexpr int R1_Z_BYTES = R1_RT * 4 * R1_COUT * 4;                // the tail's exchange: 131,072
+constexpr size_t R1_LDS_BYTES = R1_Z_BYTES;
+constexpr uint32_t R1_INVALID = 0xFFFF8000u;                       // beyond any valid extent (the scalar offset is not range-checked)
+constexpr int64_t R1_X_LIMIT = 0xFFFF0000ll;
+#ifndef IDIFF_W1D_BRING
+#define IDIFF_W1D_BRING 3
+#endif
+constexpr int R1_BRING = IDIFF_W1D_BRING;                          // combinations of U requested ahead (register sets of 8)
+static_assert(9 % R1_BRING == 0, "the ring of U registers must divide the nine combinations of a step");
+
+template <int W> struct R1Geo {
+  static constexpr int TPR = W / 4;                                // row-tiles per image row
+  static constexpr int RB = R1_PIXELS / W;                         // image rows per workgroup
+  static constexpr int NR = RB / 16;                               // rows per loader thread
+  static constexpr int E = (RB + 2) * TPR + 1;                     // stage entries: slot 0 = the row above the block, RB + 1 = the row below, then the zero entry
+  static constexpr int EZ = E - 1;
+  static constexpr int POS_BYTES = E * 64;
+  static constexpr int STAGE_BYTES = 6 * POS_BYTES;
+  static_assert(NR * TPR == 8, "a loader thread owns eight row-tiles");
+  static_assert(2 * STAGE_BYTES <= R1_Z_BYTES, "two stages inside the tail's exchange");
+  static_assert(5 * POS_BYTES < 65536, "positions are reached by the LDS instructions' immediate offset");
+};
+
+struct Wino1dParams {
+  const float *x;
+  const float *u;
+  float *out;
+  int B, H, W, Cin, Cout;
+  int rows_total, blocks_m, tiles_n, ngroup;
+  uint32_t x_bytes, u_bytes, out_bytes, res_bytes;
+  idiff_epilogue ep;
+  int has_ep;
+  float c_nb2, c_na2, c_nab2, c_a, c_b;            // the transform's constants as kernel arguments (SGPR operands of plain fmas)
+};
+
+template <int W>
+__global__ void __launch_bounds__(R1_THREADS)
+wino1d_kernel(const Wino1dParams p) {
+  using G = R1Geo<W>;
+  constexpr int TPR = G::TPR, RB = G::RB, NR = G::NR, POS = G::POS_BYTES, STAGE = G::STAGE_BYTES, BRING = R1_BRING;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char *const ldsb = reinterpret_cast<char *>(lds);
+  const int nwg = p.blocks_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {   // consecutive workgroups of the launch order land on different XCDs: give every XCD a contiguous range of the (row block, cout tile) order
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int per_group = p.blocks_m * p.ngroup;
+  const int grp = bid / per_group, in_grp = bid - grp * per_group;
+  const int tile_n = grp * p.ngroup + in_grp % p.ngroup, tile_m = in_grp / p.ngroup;
+  const int row0 = tile_m * RB, n0 = tile_n * R1_COUT;            // first global image row (sample * H + y) of the block
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wh = wave & 1, ph = wave >> 1;
+
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
+  const uint32_t cin4 = (uint32_t)p.Cin * 4u;
+  // the halo tile's pixel 4 t - 1 goes through a descriptor whose base is one pixel to the left (the range check covers the vector offset only)
+  const __amdgpu_buffer_rsrc_t rX0 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x - p.Cin), 0, (int)(p.x_bytes + cin4), 0x00020000);
+  const int roww = W * (int)cin4;                                  // bytes per image row
+  const int nsteps = p.Cin / R1_KC;
+
+  // ---------------------------------------------------------------- loader: thread = (channel, rows)
+  const int lch = tid & 15, lk = tid >> 4;
+  uint32_t v_main, v_halo;
+  bool h_c0, h_c5;
+  int e_halo;
+  {
+    const int rho = row0 + lk * NR;                                // my first row: all NR of them inside the tensor or none (H % 4 == 0)
+    v_main = rho < p.rows_total ? (uint32_t)rho * (uint32_t)roww + (uint32_t)lch * 4u : R1_INVALID;
+    const bool part = lk < 2 * TPR, top = lk < TPR;
+    const int tx = top ? lk : lk - TPR;
+    const int hr = top ? row0 - 1 : row0 + RB;                     // the halo row: inside the same image as the block's first / last row?
+    const bool valid = part && (top ? (row0 % p.H != 0) : ((row0 + RB) % p.H != 0 && row0 + RB < p.rows_total));
+    v_halo = valid ? (uint32_t)hr * (uint32_t)roww + (uint32_t)(4 * tx) * cin4 + (uint32_t)lch * 4u : R1_INVALID;   // at pixel 4 t
+    h_c0 = tx > 0; h_c5 = tx + 1 < TPR;
+    e_halo = part ? (top ? tx : (RB + 1) * TPR + tx) : G::EZ;      // threads without a halo tile transform zeros into the zero entry
+  }
+  const int e_main0 = TPR + 8 * lk;                                // my eight row-tiles' entries: consecutive
+  // Pixels in PAIRS of registers: rp[row][m] = (x[2 m - 1], x[2 m]), pixel -1 and pixel W are the zero padding: tile t reads rp[2 t .. 2 t + 2]
+  f2 rp[NR][2 * TPR + 1];
+  f2 hp[3];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int m = 0; m < 2 * TPR + 1; ++m) rp[r][m] = f2{0.f, 0.f};
+  auto fetch_tile = [&](int q, int step) __attribute__((always_inline)) {      // the pixels whose LAST reader is tile q, for K step `step`
+    const int choff = min(step, nsteps - 1) * (R1_KC * 4);                     // (clamped: the last stages request their own step again, nobody reads it)
+    const int rl = q / TPR, tx = q % TPR;
+    const int x0 = tx == 0 ? 0 : 4 * tx - 1, x1 = tx == TPR - 1 ? W - 1 : 4 * tx + 2;
+#pragma unroll
+    for (int x = x0; x <= x1; ++x)
+      rp[rl][(x + 1) >> 1][(x + 1) & 1] =
+          __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)v_main, choff + rl * roww + x * (int)cin4, 0));
+  };
+  auto fetch_halo = [&](int step) __attribute__((always_inline)) {
+    const int choff = min(step, nsteps - 1) * (R1_KC * 4);
+    uint32_t invalid = R1_INVALID;
+    asm volatile("" : "+s"(invalid));
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float v;
+      if (j == 0) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX0, (int)(h_c0 ? v_halo : invalid), choff, 0));
+      else if (j == 5) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)(h_c5 ? v_halo : invalid), choff + 4 * (int)cin4, 0));
+      else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)v_halo, choff + (j - 1) * (int)cin4, 0));
+      hp[j >> 1][j & 1] = v;
+    }
+  };
+  // The dword (channels 2m, 2m + 1) this lane writes for every position: even lanes that of plane 0 (hi), odd lanes that of plane 1 (lo)
+  const bool odd = (tid & 1) != 0;
+  const int w_piece = 2 * (tid & 1) + (lch >> 3), w_in = ((lch & 7) >> 1) * 4;
+  const uint32_t sel0 = odd ? 0x01000504u : 0x05040100u, sel1 = sel0 + 0x02020202u;
+  const float k_nb2 = p.c_nb2, k_na2 = p.c_na2, k_nab2 = p.c_nab2, k_a = p.c_a, k_b = p.c_b;
+  // One row-tile: t = B^T d (12 fmas, the arithmetic of winograd43_shared.h's f4_bt), each value cut into its fp16 pair, halves traded with the
+  // neighbouring lane (channels 2m and 2m + 1) by DPP so that every lane stores whole dwords, one per position.
+  auto put_tile = [&](int buf, const f2 P0, const f2 P1, const f2 P2, int e) __attribute__((always_inline)) {
+    char *Vd = ldsb + buf * STAGE + e * 64 + ((w_piece ^ ((e >> 2) & 3)) << 4) + w_in;
+    const float d0 = P0.x, d1 = P0.y, d2 = P1.x, d3 = P1.y, d4 = P2.x, d5 = P2.y;
+    const float pe = fmaf(k_nb2, d2, d4), po = fmaf(k_nb2, d1, d3);
+    const float re = fmaf(k_na2, d2, d4), ro = fmaf(k_na2, d1, d3);
+    f2 v[3];
+    v[0].x = fmaf(k_nab2, d2, d0 + d4); v[0].y = fmaf(k_nab2, d3, d1 + d5);        // positions 0, 5
+    v[1].x = fmaf(k_a, po, pe); v[1].y = fmaf(-k_a, po, pe);                        // 1, 2
+    v[2].x = fmaf(k_b, ro, re); v[2].y = fmaf(-k_b, ro, re);                        // 3, 4
+    constexpr int pos_lo[3] = {0, 1, 3}, pos_hi[3] = {5, 2, 4};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const uint32_t xh = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[q], h2));
+      f2 rest;                                                      // v - hi in one mixed-precision instruction per component (exact)
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rest.x) : "v"(xh), "v"(v[q].x));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest.y) : "v"(xh), "v"(v[q].y));
+      const uint32_t xl = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, h2));
+      const uint32_t give = odd ? xh : xl, keep = odd ? xl : xh;
+      const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp((int)give, (int)give, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
+      *reinterpret_cast<uint32_t *>(Vd + pos_lo[q] * POS) = __builtin_amdgcn_perm(got, keep, sel0);
+      *reinterpret_cast<uint32_t *>(Vd + pos_hi[q] * POS) = __builtin_amdgcn_perm(got, keep, sel1);
+    }
+  };
+  // part c of a stage: row-tile c of my rows (c < 8) or my halo tile (c == 8) goes to the stage, its pixels are requested for `next`
+  auto stage_part = [&](int buf, int c, int next) __attribute__((always_inline)) {
+    if (c < 8) {
+      const int rl = c / TPR, tx = c % TPR;
+      put_tile(buf, rp[rl][2 * tx], rp[rl][2 * tx + 1], rp[rl][2 * tx + 2], e_main0 + c);
+      fetch_tile(c, next);
+    } else {
+      put_tile(buf, hp[0], hp[1], hp[2], e_halo);
+      fetch_halo(next);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---------------------------------------------------------------- contraction
+  floatx16 acc[4][3];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][i][r] = 0.f;
+  const int fr = lane & 31, fh = lane >> 5;
+  // V fragment of (group g, filter row ky): the entry of row-tile 32 g + fr one row up / at / one row down, or the zero entry where that row
+  // is outside the output row's image; piece fh of plane 0, plane 1 lies at the address with bit 5 flipped
+  uint32_t a_hi[4][3];
+  {
+    const int y0 = row0 % p.H;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = 32 * g + fr, r = m / TPR, tx = m % TPR;
+      const int y = (y0 + r) % p.H;
+      const bool inside = row0 + r < p.rows_total;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const bool ok = inside && (ky == 1 || (ky == 0 ? y > 0 : y + 1 < p.H));
+        const int e = ok ? (r + ky) * TPR + tx : G::EZ;
+        a_hi[g][ky] = (uint32_t)(e * 64 + ((fh ^ ((e >> 2) & 3)) << 4));
+      }
+    }
+  }
+  const uint32_t u_lane = (uint32_t)((wh * 32 + fr) * (R1_KC * 2) + fh * 16);
+  halfx8 bh[BRING], bl[BRING];
+  auto load_b = [&](int c, int step) __attribute__((always_inline)) {
+    const int soff = ((step * p.tiles_n + tile_n) * R1_NSLOT + 9 * ph + c) * R1_SLOT_BYTES;     // slot = (3 ph + c / 3) * 3 + c % 3
+    bh[c % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane, soff, 0));
+    bl[c % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane + R1_PLANE_BYTES, soff, 0));
+  };
+  // A step: nine combinations c = (position 3 ph + c / 3, filter row c % 3), each twelve matrix instructions on four V fragments read one
+  // combination ahead and a U fragment requested three ahead; behind each combination's instructions one part of the next step's staging.
+  auto step = [&](int s, auto last) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last)::value;
+    const int buf = s & 1;
+    const uint32_t sbase = (uint32_t)(buf * STAGE + ph * 3 * POS);
+    halfx8 ah[2][4], al[2][4];
+    auto read_a = [&](int c) __attribute__((always_inline)) {
+      const int pi = c / 3, ky = c % 3;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint32_t at = a_hi[g][ky] + sbase;
+        ah[c & 1][g] = *reinterpret_cast<const halfx8 *>(ldsb + at + pi * POS);
+        al[c & 1][g] = *reinterpret_cast<const halfx8 *>(ldsb + (at ^ 32u) + pi * POS);
+      }
+    };
+    read_a(0);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < 9) read_a(c + 1);
+      const int pi = c / 3;
+      const halfx8 yh = bh[c % BRING], yl = bl[c % BRING];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c & 1][g], yh, acc[g][pi], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c & 1][g], yl, acc[g][pi], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c & 1][g], yh, acc[g][pi], 0, 0, 0);
+      if (c + BRING < 9) load_b(c + BRING, s); else if (!LAST) load_b(c + BRING - 9, s + 1);
+      if (!LAST) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_part(buf ^ 1, c, s + 2);
+      }
+    }
+    __syncthreads();
+  };
+
+  // the zero entry of both stages
+  if (tid < 192) {
+    const int b = tid / 96, rem = tid - 96 * b;
+    *reinterpret_cast<uint32_t *>(ldsb + b * STAGE + (rem >> 4) * POS + G::EZ * 64 + (rem & 15) * 4) = 0u;
+  }
+#pragma unroll
+  for (int c = 0; c < BRING; ++c) load_b(c, 0);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) fetch_tile(c, 0);
+  fetch_halo(0);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) stage_part(0, c, 1);
+  __syncthreads();
+  {
+    int s = 0;                                        // at least two steps (Cin >= 32, checked by the launcher)
+    do step(s, std::false_type()); while (++s + 1 < nsteps);
+  }
+  step(nsteps - 1, std::true_type());
+
+  // ---------------------------------------------------------------- tail
+  const float descale = p.u[(int64_t)R1_NSLOT * p.Cin * p.Cout];
+  const idiff_epilogue &ep = p.ep;
+  const bool has_ep = p.has_ep != 0;
+  // z[row-tile][a][cout]: accumulator register `reg` of lane l is row-tile (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) of its group, cout wh * 32 + (l & 31)
+  float *zbase = lds + (size_t)(4 * (lane >> 5)) * 4 * R1_COUT + wh * 32 + (lane & 31);
+  auto mix = [&](auto grp, auto park) __attribute__((always_inline)) {
+    constexpr int GI = decltype(grp)::value;
+    constexpr bool PARK = decltype(park)::value;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const float ma = acc[GI][0][reg], mb = acc[GI][1][reg], mc = acc[GI][2][reg];
+      float y0, y1, y2, y3;
+      if (ph == 0) {                                   // positions 0, 1, 2
+        const float s = mb + mc, d = mb - mc;
+        y0 = ma + s; y1 = R1_a * d; y2 = R1_a2 * s; y3 = R1_a3 * d;
+      } else {                                         // positions 3, 4, 5
+        const float s = ma + mb, d = ma - mb;
+        y0 = s; y1 = R1_b * d; y2 = R1_b2 * s; y3 = fmaf(R1_b3, d, mc);
+      }
+      float *zp = zbase + (size_t)(32 * GI + (reg & 3) + 8 * (reg >> 2)) * 4 * R1_COUT;
+      if (PARK) { zp[0] = y0; zp[R1_COUT] = y1; zp[2 * R1_COUT] = y2; zp[3 * R1_COUT] = y3; }
+      else { zp[0] += y0; zp[R1_COUT] += y1; zp[2 * R1_COUT] += y2; zp[3 * R1_COUT] += y3; }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  // the finishing thread: channels n .. n + 3 of the 32 consecutive pixels of rows tl NR .. (row-tiles 8 tl .. 8 tl + 7): one sample
+  const int cq = tid & 15, tl = tid >> 4;
+  const int n = n0 + 4 * cq;
+  const bool has_res = has_ep && ep.residual != nullptr;
+  const bool scaled = has_ep && (ep.out_scale != 1.f || ep.rowscale != nullptr);
+  const int act = has_ep ? ep.act : (int)IDIFF_ACT_NONE;
+  const bool want_stats = has_ep && ep.colstats != nullptr;
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)ep.residual, 0, (int)p.res_bytes, 0x00020000);
+  const int ld_res = (int)ep.ld_residual;
+  const int orow = row0 + tl * NR;
+  const bool ook = orow < p.rows_total;
+  const uint32_t px0 = (uint32_t)orow * (uint32_t)W;
+  const uint32_t ooff = ook ? (px0 * (uint32_t)p.Cout + (uint32_t)n) * 4u : R1_INVALID;
+  const uint32_t roff = ook ? (px0 * (uint32_t)ld_res + (uint32_t)n) * 4u : R1_INVALID;
+  float4 badd = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sc = has_ep ? ep.out_scale : 1.f;
+  if (has_ep && ep.bias) badd = *reinterpret_cast<const float4 *>(ep.bias + n);
+  if (has_ep && ook) {
+    const int img = orow / p.H;
+    if (ep.rowbias) {
+      const float4 rb = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)img * ep.ld_rowbias + n);
+      badd.x += rb.x; badd.y += rb.y; badd.z += rb.z; badd.w += rb.w;
+    }
+    if (ep.rowscale) sc *= ep.rowscale[img];
+  }
+  float4 res[2][8];
+  auto load_res = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      res[chunk & 1][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)roff, (8 * chunk + i) * ld_res * 4, 0));
+  };
+  if (has_res) load_res(0);
+  // the last step ended with a barrier: nobody reads the stages any more
+  if (ph == 0) { mix(I2(), std::true_type()); mix(I3(), std::true_type()); } else { mix(I0(), std::true_type()); mix(I1(), std::true_type()); }
+  __syncthreads();
+  if (ph == 0) { mix(I0(), std::false_type()); mix(I1(), std::false_type()); } else { mix(I2(), std::false_type()); mix(I3(), std::false_type()); }
+  __syncthreads();
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int chunk = 0; chunk < 4; ++chunk) {
+    if (has_res && chunk + 1 < 4) load_res(chunk + 1);
+    float4 z[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = *reinterpret_cast<const float4 *>(lds + (size_t)(32 * tl + 8 * chunk + i) * R1_COUT + 4 * cq);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float y[4] = {z[i].x * descale + badd.x, z[i].y * descale + badd.y, z[i].z * descale + badd.z, z[i].w * descale + badd.w};
+      if (act != IDIFF_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = idiff::act_apply(y[e], act);
+      }
+      if (has_res) { const float4 r = res[chunk & 1][i]; y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w; }
+      if (scaled) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] *= sc;
+      }
+      if (want_stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += (double)y[e]; s2[e] += (double)y[e] * (double)y[e]; }
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, make_float4(y[0], y[1], y[2], y[3])), rO, (int)ooff,
+                                             (8 * chunk + i) * p.Cout * 4, 0);
+    }
+  }
+  if (want_stats) {
+    // per-sample (or per-block, where a sample spans several blocks) column sums for the GroupNorm that reads this output: thread sums ->
+    // [16 thread rows][64 channels] in LDS -> one thread per (slot, channel)
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(lds);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[((tl * R1_COUT) + 4 * cq + e) * 2] = s1[e];
+      red[((tl * R1_COUT) + 4 * cq + e) * 2 + 1] = s2[e];
+    }
+    __syncthreads();
+    const int slots = RB > p.H ? RB / p.H : 1;                     // samples per block
+    const int per = 16 / slots;                                    // thread rows per sample
+    for (int o = tid; o < slots * R1_COUT; o += R1_THREADS) {
+      const int smp = o / R1_COUT, ch = o - smp * R1_COUT;
+      const int64_t slot = (int64_t)tile_m * slots + smp;           // sample, or (sample, split) = block
+      if (slots > 1 && slot >= p.B) continue;
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < per; ++k) { a += red[((smp * per + k) * R1_COUT + ch) * 2]; b += red[((smp * per + k) * R1_COUT + ch) * 2 + 1]; }
+      double *dst = ep.colstats + (slot * p.Cout + n0 + ch) * 2;
+      dst[0] = a; dst[1] = b;
+    }
+  }
+}
+
+// U[i][ky] = sum_kx G[i][kx] g[ky][kx] in fp64 for one (cin, cout) pair
+__device__ __forceinline__ void r1_u_of_pair(const float *wt, int Cin, int cin, int cout, double (&U)[18]) {
+  const double a = R1_A, b = R1_B, na = 1.0 / (2.0 * a * a * (a * a - b * b)), nb = 1.0 / (2.0 * b * b * (b * b - a * a)), n0 = 1.0 / (a * a * b * b);
+  const double Gm[6][3] = {{n0, 0.0, 0.0}, {na, a * na, a * a * na}, {na, -a * na, a * a * na}, {nb, b * nb, b * b * nb}, {nb, -b * nb, b * b * nb},
+                           {0.0, 0.0, 1.0}};
+  for (int ky = 0; ky < 3; ++ky) {
+    double g[3];
+    for (int kx = 0; kx < 3; ++kx) g[kx] = (double)wt[((int64_t)cout * 9 + ky * 3 + kx) * Cin + cin];
+    for (int i = 0; i < 6; ++i) U[3 * i + ky] = Gm[i][0] * g[0] + Gm[i][1] * g[1] + Gm[i][2] * g[2];
+  }
+}
+
+// pass 1: max |U| over the layer (bits of a non-negative float order like unsigned integers; the word was zeroed by the launcher)
+__global__ void wino1d_absmax_kernel(const float *wt, unsigned int *absmax_bits, int Cin, int Cout) {
+  const int64_t total = (int64_t)Cin * Cout;
+  float m = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    double U[18];
+    r1_u_of_pair(wt, Cin, (int)(idx % Cin), (int)(idx / Cin), U);
+    for (int k = 0; k < 18; ++k) m = fmaxf(m, fabsf((float)U[k]));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(absmax_bits, __float_as_uint(m));
+}
+
+// pass 2: the pairs.  The scale 2^k brings max |U| into [2^11, 2^12); header[0] receives 2^-k.
+__global__ void wino1d_pack_kernel(const float *wt, _Float16 *u, float *header, int Cin, int Cout) {
+  const float amax = __uint_as_float(*reinterpret_cast<const unsigned int *>(header + 1));
+  int e = 0;
+  if (amax > 0.f && isfinite(amax)) { (void)frexpf(amax, &e); }          // amax = f 2^e, f in [0.5, 1)
+  const int k = (amax > 0.f && isfinite(amax)) ? 12 - e : 0;
+  const double scale = ldexp(1.0, k);
+  const int64_t total = (int64_t)Cin * Cout;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cin = (int)(idx % Cin), cout = (int)(idx / Cin);
+    double U[18];
+    r1_u_of_pair(wt, Cin, cin, cout, U);
+    const int s = cin / R1_KC, c16 = cin % R1_KC, nt = cout / R1_COUT, co = cout % R1_COUT;
+    _Float16 *dst = u + ((int64_t)(s * (Cout / R1_COUT) + nt) * R1_NSLOT) * (R1_SLOT_BYTES / 2) + co * R1_KC + c16;
+    for (int q = 0; q < 18; ++q) {
+      const float v = (float)(U[q] * scale);                                   // rounded once to fp32, then cut
+      const _Float16 hi = (_Float16)v;
+      const _Float16 lo = (_Float16)(v - (float)hi);
+      dst[(int64_t)q * (R1_SLOT_BYTES / 2)] = hi;
+      dst[(int64_t)q * (R1_SLOT_BYTES / 2) + R1_PLANE_BYTES / 2] = lo;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) header[0] = (float)ldexp(1.0, -k);
+}
+
+bool r1_geometry_ok(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || Cin <= 0 || Cout <= 0) return false;
+  if (W != 8 && W != 16 && W != 32) return false;
+  const int RB = R1_PIXELS / W;
+  if (H % 4 || (RB % H != 0 && H % RB != 0)) return false;                     // a block is whole images or a whole part of one
+  if (Cin % R1_KC || Cin < 2 * R1_KC || Cin > 1024 || Cout % R1_COUT) return false;
+  if ((int64_t)R1_NSLOT * Cin * Cout * 4 >= R1_X_LIMIT) return false;
+  if ((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) * 4 >= R1_X_LIMIT - 0x4000) return false;   // one buffer descriptor per tensor
+  return true;
+}
+
+template <int W>
+int r1_launch(const Wino1dParams &p, hipStream_t stream) {
+  static idiff::AttrGuard guard;
+  const void *fn = reinterpret_cast<const void *>(wino1d_kernel<W>);
+  if (int rc = idiff::set_dynamic_lds_once(guard, &fn, 1, (int)R1_LDS_BYTES, "conv2d_wino1d")) return rc;
+  hipLaunchKernelGGL(wino1d_kernel<W>, dim3(p.blocks_m * p.tiles_n), dim3(R1_THREADS), R1_LDS_BYTES, stream, p);
+  return idiff::launch_status("conv2d_wino1d");
+}
+}  // namespace
+
+IDIFF_API int idiff_conv2d_wino1d_ok(int B, int H, int W, int Cin, int Cout) {
+  using namespace idiff;
+  if (option(OPT_NO_WINOGRAD) || option(OPT_NO_WINO43H) || option(OPT_NO_WINO1D)) return 0;
+  return r1_geometry_ok(B, H, W, Cin, Cout) ? 1 : 0;
+}
+
+// nsplit of epilogue.colstats ([samples, nsplit, Cout, 2]) or 0 when the statistics cannot be produced
+IDIFF_API int idiff_conv2d_wino1d_colstats_split(int B, int H, int W, int Cin, int Cout) {
+  if (!idiff_conv2d_wino1d_ok(B, H, W, Cin, Cout) || idiff::option(idiff::OPT_NO_COLSTATS)) return 0;
+  const int RB = R1_PIXELS / W;
+  return H > RB ? H / RB : 1;
+}
+
+IDIFF_API int64_t idiff_wino1d_weight_floats(int Cin, int Cout) { return (int64_t)R1_NSLOT * Cin * Cout + 4; }
+
+IDIFF_API int idiff_wino1d_pack_f32(const float *wt, float *u, int Cin, int Cout, void *stream) {
+  using namespace idiff;
+  if (Cin <= 0 || Cout <= 0 || Cin % R1_KC || Cout % R1_COUT)
+    return fail("wino1d_pack: Cin must be a multiple of %d and Cout of %d (got %d, %d)", R1_KC, R1_COUT, Cin, Cout);
+  if (!wt || !u) return fail("wino1d_pack: null pointer");
+  if ((uintptr_t)u & 15) return fail("wino1d_pack: u must be 16-byte aligned");
+  const int64_t total = (int64_t)Cin * Cout;
+  float *header = u + (int64_t)R1_NSLOT * Cin * Cout;
+  hipError_t e = hipMemsetAsync(header, 0, 16, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("wino1d_pack: hipMemsetAsync: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(wino1d_absmax_kernel, dim3(streaming_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, wt,
+                     reinterpret_cast<unsigned int *>(header + 1), Cin, Cout);
+  hipLaunchKernelGGL(wino1d_pack_kernel, dim3(streaming_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, wt,
+                     reinterpret_cast<_Float16 *>(u), header, Cin, Cout);
+  return launch_status("wino1d_pack");
+}
+
+IDIFF_API int idiff_conv2d_wino1d_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
+                                      const idiff_epilogue *ep, void *stream) {
+  using namespace idiff;
+  if (B == 0) return 0;
+  if (!r1_geometry_ok(B, H, W, Cin, Cout))
+    return fail("conv2d_wino1d: geometry B=%d H=%d W=%d Cin=%d Cout=%d not supported (ask idiff_conv2d_wino1d_ok)", B, H, W, Cin, Cout);
+  if (!x || !u || !out) return fail("conv2d_wino1d: null pointer");
+  if (((uintptr_t)x & 15) || ((uintptr_t)u & 15) || ((uintptr_t)out & 15)) return fail("conv2d_wino1d: x, u and out must be 16-byte aligned");
+  if (ep && ep->colstats && idiff_conv2d_wino1d_colstats_split(B, H, W, Cin, Cout) <= 0)
+    return fail("conv2d_wino1d: colstats are switched off (IDIFF_NO_COLSTATS): ask idiff_conv2d_wino1d_colstats_split");
+  if (ep && (ep->rowbias || ep->rowscale) && ep->rows_per_group != H * W)
+    return fail("conv2d_wino1d: per-row-group bias / scale only per image (rows_per_group = H * W = %d, got %d)", H * W, ep->rows_per_group);
+  if (ep && ep->residual && (((uintptr_t)ep->residual & 15) || ep->ld_residual % 4 || ep->ld_residual < Cout || ep->ld_residual > 0x7fffffff / 4))
+    return fail("conv2d_wino1d: residual must be 16-byte aligned with a row pitch >= Cout that is a multiple of 4");
+  const int64_t res_bytes = (ep && ep->residual) ? (int64_t)B * H * W * ep->ld_residual * 4 : 0;
+  if (res_bytes >= R1_X_LIMIT) return fail("conv2d_wino1d: residual beyond one buffer descriptor");
+  Wino1dParams p = {};
+  p.x = x; p.u = u; p.out = out; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.rows_total = B * H;
+  p.blocks_m = ceil_div(p.rows_total, R1_PIXELS / W); p.tiles_n = Cout / R1_COUT;
+  {
+    const int want = option_value(OPT_WINO_NGROUP);
+    p.ngroup = (want > 0 && p.tiles_n % want == 0) ? want : ((p.tiles_n > 2 && p.tiles_n % 2 == 0) ? 2 : p.tiles_n);
+  }
+  p.x_bytes = (uint32_t)((int64_t)B * H * W * Cin * 4); p.u_bytes = (uint32_t)((int64_t)R1_NSLOT * Cin * Cout * 4);
+  p.out_bytes = (uint32_t)((int64_t)B * H * W * Cout * 4); p.res_bytes = (uint32_t)res_bytes;
+  if (ep) {
+    p.ep = *ep; p.has_ep = 1;
+    if (p.ep.rows_per_group <= 0) p.ep.rows_per_group = 1;
+  } else {
+    p.has_ep = 0; p.ep.rows_per_group = 1; p.ep.out_scale = 1.f;
+  }
+  p.c_nb2 = -R1_b2; p.c_na2 = -R1_a2; p.c_nab2 = -R1_ab2; p.c_a = R1_a; p.c_b = R1_b;
+  switch (W) {
+    case 8: return r1_launch<8>(p, (hipStream_t)stream);
+    case 16: return r1_launch<16>(p, (hipStream_t)stream);
+    default: return r1_launch<32>(p, (hipStream_t)stream);
+  }
+}

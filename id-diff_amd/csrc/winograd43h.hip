@@ -56,6 +56,21 @@ constexpr int H4_BRING = IDIFF_W43H_BRING;     // positions of U requested ahead
 #ifndef IDIFF_W43H_STAGE_AT
 #define IDIFF_W43H_STAGE_AT 0
 #endif
+#ifndef IDIFF_W43H_U_AUX
+#define IDIFF_W43H_U_AUX 0          // cache policy bits of the U loads (1 = sc0, 2 = nt, 16 = sc1)
+#endif
+#ifndef IDIFF_W43H_X_AUX
+#define IDIFF_W43H_X_AUX 0          // ... of the patch loads
+#endif
+#ifndef IDIFF_W43H_COLORDER
+#define IDIFF_W43H_COLORDER 0
+#endif
+// the order in which a step's six patch columns are transformed, written and re-requested
+#if IDIFF_W43H_COLORDER == 1
+__device__ constexpr int H4_COL[6] = {0, 4, 1, 5, 2, 3};     // columns that neighbouring tiles share (4 = the right neighbour's 0, 5 = its 1) back to back
+#else
+__device__ constexpr int H4_COL[6] = {0, 1, 2, 3, 4, 5};
+#endif
 #ifndef IDIFF_W43H_COLS_PER_PART
 #define IDIFF_W43H_COLS_PER_PART 1
 #endif
@@ -157,11 +172,17 @@ winograd43h_kernel(const Wino43Params p) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       float v;
+#ifdef IDIFF_W43H_DIAG_NO_COL45   // timing-only builds: what the loop costs without the requests that repeat a neighbouring tile's (columns 4, 5 = the right
+      if (j >= 4) { dp[i >> 1][j][i & 1] = dp[i >> 1][j - 4][i & 1]; continue; }   // neighbour's 0, 1; rows 4, 5 = the lower neighbour's 0, 1)
+#endif
+#ifdef IDIFF_W43H_DIAG_NO_ROW45
+      if (i >= 4) { dp[i >> 1][j][i & 1] = dp[(i - 4) >> 1][j][i & 1]; continue; }
+#endif
       const uint32_t vo = i == 0 ? v_top : (i == 5 ? v_bot : v_mid);
       const int ro = i == 0 ? 0 : (i - 1) * row4;
-      if (j == 0) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX0, (int)(c0ok ? vo : invalid), choff + ro, 0));
-      else if (j == 5) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX5, (int)(c5ok ? vo : invalid), choff + ro, 0));
-      else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)vo, choff + ro + (j - 1) * (int)cin4, 0));
+      if (j == 0) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX0, (int)(c0ok ? vo : invalid), choff + ro, IDIFF_W43H_X_AUX));
+      else if (j == 5) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX5, (int)(c5ok ? vo : invalid), choff + ro, IDIFF_W43H_X_AUX));
+      else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)vo, choff + ro + (j - 1) * (int)cin4, IDIFF_W43H_X_AUX));
       dp[i >> 1][j][i & 1] = v;
     }
   };
@@ -217,9 +238,9 @@ winograd43h_kernel(const Wino43Params p) {
       __builtin_amdgcn_sched_barrier(0);              // one row pair / column at a time: interleaved they need registers that do not exist
     }
   };
-  auto stage_col = [&](int buf, int j) __attribute__((always_inline)) {
+  auto stage_col = [&](int buf, int j, bool last_col) __attribute__((always_inline)) {
 #ifdef IDIFF_W43H_DIAG_NO_STAGE
-    if (j == 5) ++f_step;
+    if (last_col) ++f_step;
     (void)buf; return;
 #endif
     char *Vd = ldsb + buf * H4_STAGE_BYTES + w_off;
@@ -251,13 +272,13 @@ winograd43h_kernel(const Wino43Params p) {
     if (f_step == 0)
 #endif
     fetch_col(j, f_step + 1);                         // the column's registers are free: the next step's column moves in
-    if (j == 5) ++f_step;
+    if (last_col) ++f_step;
     __builtin_amdgcn_sched_barrier(0);
   };
   auto stage = [&](int buf) __attribute__((always_inline)) {       // all of it at once: the first step's, before the loop
     stage_rows();
 #pragma unroll
-    for (int j = 0; j < 6; ++j) stage_col(buf, j);
+    for (int q = 0; q < 6; ++q) stage_col(buf, H4_COL[q], q == 5);
   };
 
 #ifdef IDIFF_W43H_DIAG_DMA
@@ -292,8 +313,8 @@ winograd43h_kernel(const Wino43Params p) {
   auto load_b = [&](int pp, int step) __attribute__((always_inline)) {
     const int slot = pos0 + (pp / 3) * 6 + (pp % 3);
     const int soff = ((step * p.tiles_n + tile_n) * F4_NPOS + slot) * H4_SLOT_BYTES;
-    bh[pp % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane, soff, 0));
-    bl[pp % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane + H4_PLANE_BYTES, soff, 0));
+    bh[pp % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane, soff, IDIFF_W43H_U_AUX));
+    bl[pp % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane + H4_PLANE_BYTES, soff, IDIFF_W43H_U_AUX));
   };
   // A step: nine positions, each three matrix instructions whose U operands were requested three positions earlier -- about one L2 round
   // trip (~1600 clocks) per three positions, so the contraction alone is bound by that latency (stamps: 5200 clocks of a 9000-clock step
@@ -339,8 +360,8 @@ winograd43h_kernel(const Wino43Params p) {
 #endif
         if (pp == H4_STAGE_AT) stage_rows();
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-          if (pp == H4_STAGE_AT + 1 + j / H4_COLS_PER_PART) stage_col(buf ^ 1, j);
+        for (int q = 0; q < 6; ++q)
+          if (pp == H4_STAGE_AT + 1 + q / H4_COLS_PER_PART) stage_col(buf ^ 1, H4_COL[q], q == 5);
 #ifdef IDIFF_W43H_STAMP
         ph_stage += (uint32_t)(IDIFF_PH_T() - a_);
 #endif
@@ -361,7 +382,7 @@ winograd43h_kernel(const Wino43Params p) {
 #pragma unroll
   for (int pp = 0; pp < BRING; ++pp) load_b(pp, 0);
 #pragma unroll
-  for (int j = 0; j < 6; ++j) fetch_col(j, 0);
+  for (int q = 0; q < 6; ++q) fetch_col(H4_COL[q], 0);
 #ifdef IDIFF_W43H_STAMP
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -50,7 +50,7 @@ const char *idiff_variant_flags(void);
  * stream beside the next panel's factorisation; 5 % at D = 12288 when the helper gets a hardware queue of its own, 50 %
  * SLOWER when the runtime maps it onto the caller's queue, which happens once a process has made a few streams),
  * IDIFF_NO_WINO43 (3x3 convolutions on the F(2x2,3x3) kernel instead of F(4x4,3x3)), IDIFF_NO_WINO43H (F(4x4,3x3) with its
- * contractions on the fp32 matrix cores instead of fp16 pairs), IDIFF_NO_FUSED_ATTN (idiff_attention256_ok answers 0), IDIFF_NO_PAIRS (idiff_gemm_pairs_ok answers 0: the 1x1
+ * contractions on the fp32 matrix cores instead of fp16 pairs), IDIFF_NO_FUSED_ATTN (idiff_attention256_ok answers 0), IDIFF_NO_WINO1D (idiff_conv2d_wino1d_ok answers 0), IDIFF_NO_PAIRS (idiff_gemm_pairs_ok answers 0: the 1x1
  * projections behind a GroupNorm stay on idiff_gemm_f32's six-product form), IDIFF_PAIRS_MIN_TILES (tests: the number of 128 x 128
  * tiles from which idiff_gemm_pairs_ok answers 1; default 256).
  * Returns the previous value, -1 for an unknown name.  No reference counterpart. */
@@ -258,6 +258,27 @@ int64_t idiff_winograd43h_weight_floats(int Cin, int Cout);
 int idiff_winograd43h_pack_f32(const float *wt, float *u, int Cin, int Cout, void *stream);
 int idiff_conv2d_winograd43h_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
                                  const idiff_epilogue *ep, void *stream);
+
+/* The same 3x3 / stride 1 / pad 1 convolution (replaces F.conv2d behind ddpm_conv3x3, models/layers.py:100-132, as the entries above)
+ * by Winograd's F(4, 3) along the image rows only -- the three filter rows stay a direct sum: 4.5 multiplications per output instead of
+ * 2.25, on fp16 pairs as idiff_conv2d_winograd43h_f32 (same cut, same three partial products, fp32 accumulation; one 6-point transform
+ * instead of two: gain 5.4 instead of 29.3, the input may reach |x| ~ 12,000 before a pair overflows to NaN).  Twice the matrix work for
+ * half the operand traffic per output: a workgroup of 512 output pixels x 64 channels reads 18 instead of 36 transformed filter slots
+ * per K step and every input pixel once instead of 2.25 times, which is what bounds the 2-D form on gfx950 (csrc/wino1d.hip).
+ *   idiff_conv2d_wino1d_ok             1 when served: W in {8, 16, 32}, H % 4 == 0 with 512 / W a multiple or a divisor of H (a workgroup takes
+ *                                      whole images or a whole part of one), Cin % 16 == 0, 32 <= Cin <= 1024, Cout % 64 == 0, every tensor
+ *                                      within one buffer descriptor; 0 under IDIFF_NO_WINOGRAD / IDIFF_NO_WINO43H / IDIFF_NO_WINO1D.
+ *   idiff_conv2d_wino1d_colstats_split nsplit of epilogue.colstats ([samples, nsplit, Cout, 2]): H * W / 512 for maps above 512 pixels, else 1
+ *                                      (0 under IDIFF_NO_COLSTATS or when the geometry is not served).
+ *   idiff_wino1d_weight_floats         size of the bank in floats (18 * Cin * Cout for the fp16 pairs + 4 of header).
+ *   idiff_wino1d_pack_f32              wt [Cout, 3, 3, Cin] -> the scaled pairs of U[i][ky] = (G g[ky])[i] (fp64, rounded once to fp32, then cut).
+ *   idiff_conv2d_wino1d_f32            x [B, H, W, Cin] -> out [B, H, W, Cout] with the epilogue of idiff_conv2d_nhwc_f32. */
+int idiff_conv2d_wino1d_ok(int B, int H, int W, int Cin, int Cout);
+int idiff_conv2d_wino1d_colstats_split(int B, int H, int W, int Cin, int Cout);
+int64_t idiff_wino1d_weight_floats(int Cin, int Cout);
+int idiff_wino1d_pack_f32(const float *wt, float *u, int Cin, int Cout, void *stream);
+int idiff_conv2d_wino1d_f32(const float *x, const float *u, float *out, int B, int H, int W, int Cin, int Cout,
+                            const idiff_epilogue *ep, void *stream);
 
 /* Split-precision form of the same convolution: the 16 position-wise contractions run on the bf16 matrix cores with every
  * fp32 operand cut exactly into three bf16 pieces and six of the nine partial products kept (fp32 accumulation; what is

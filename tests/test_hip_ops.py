@@ -1053,6 +1053,87 @@ def test_conv2d_winograd43_pairs_limits():
     torch.testing.assert_close(out, bias.expand(2, 8, 8, 64), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 32, 32, 128, 128), (3, 8, 8, 256, 64), (5, 16, 16, 80, 64), (2, 16, 16, 512, 256), (1, 64, 32, 32, 64),
+                                            (2, 8, 8, 32, 64), (33, 8, 8, 256, 256), (7, 16, 16, 384, 256), (3, 32, 16, 48, 128), (9, 4, 8, 64, 64),
+                                            (2, 128, 8, 32, 64)])
+def test_conv2d_wino1d_vs_cpu(B, H, W, Cin, Cout):
+    """The 3x3 convolution by F(4, 3) along the rows, three filter rows summed directly, on fp16 pairs (wino1d_kernel) against the fp64 CPU
+    convolution with every epilogue term, the direct kernel and the column sums: blocks of half an image (W = 32), of several images
+    (W = 16, 8: the rows of a neighbouring image must not leak into a sample's first / last row), partial last blocks, non-square maps with
+    one or two halo rows per block, 2 to 32 K steps, several output-channel tiles.  Bar 3e-6, that of the 2-D pair form (measured below it:
+    one transform instead of two).  Inputs span five decades with exact zeros among them, as in the 2-D form's test."""
+    g = torch.Generator().manual_seed(B * H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x = x * (torch.rand(B, Cin, H, W, generator=g) < 0.9) * torch.exp(torch.randn(B, Cin, H, W, generator=g).clamp(-6, 2))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    temb = torch.randn(B, Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    rsc = torch.rand(B, generator=g) + 0.5
+    assert _lib.conv2d_wino1d_ok(B, H, W, Cin, Cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wt = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    u = _lib.wino1d_pack(wt, Cin, Cout)
+    assert u.numel() == 18 * Cin * Cout + 4
+    descale = float(u[-4])
+    assert descale > 0 and np.log2(descale) == round(np.log2(descale))       # a power of two: undone exactly
+    out = torch.full((B, H, W, Cout), float("nan"), device=DEV)          # every output must be written
+    _lib.conv2d_wino1d(xd, u, out, B, H, W, Cin, Cout, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 3e-6
+    # elementwise too: a misplaced store or a leaked neighbouring row moves single entries by O(1) while the norm moves by 1e-2
+    assert float((out.permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    direct = torch.empty_like(out)
+    _lib.conv2d_nhwc(xd, wt, direct, B, H, W, Cin, Cout, 3, 3, 1, 1, epilogue=_lib.make_epilogue(bias=b.to(DEV)))
+    assert rel_err(out.cpu(), direct.double().cpu()) < 3e-6
+    resd = res.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ns = _lib.conv2d_wino1d_colstats_split(B, H, W, Cin, Cout)
+    assert ns == max(1, H * W // 512)
+    cs = torch.full((B * ns * Cout * 2,), float("nan"), device=DEV, dtype=torch.float64)
+    _lib.conv2d_wino1d(xd, u, out, B, H, W, Cin, Cout,
+                       epilogue=_lib.make_epilogue(bias=b.to(DEV), rowbias=temb.to(DEV), rows_per_group=H * W, act="silu",
+                                                   residual=resd, out_scale=0.7071, rowscale=rsc.to(DEV), colstats=cs))
+    ref2 = (F.silu(ref + temb.double()[:, :, None, None]) + res.double()) * 0.7071 * rsc.double()[:, None, None, None]
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref2) < 3e-6
+    assert float((out.permute(0, 3, 1, 2).cpu().double() - ref2).abs().max()) < 1e-4 * float(ref2.abs().max())
+    tot = cs.view(B, ns, Cout, 2).sum(1)                                  # the column sums are those of the stored outputs
+    o64 = out.double().reshape(B, H * W, Cout)
+    torch.testing.assert_close(tot[..., 0], o64.sum(1), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(tot[..., 1], (o64 * o64).sum(1), rtol=1e-6, atol=1e-6)
+
+
+def test_conv2d_wino1d_limits():
+    """What the row-wise pair form refuses, its switches, and its documented failure: an input beyond the fp16 range of the transformed
+    values gives NaN outputs, never finite wrong ones."""
+    assert not _lib.conv2d_wino1d_ok(2, 8, 12, 32, 64)           # W not 8 / 16 / 32
+    assert not _lib.conv2d_wino1d_ok(2, 8, 8, 24, 64)            # Cin % 16
+    assert not _lib.conv2d_wino1d_ok(2, 8, 8, 16, 64)            # fewer than two K steps
+    assert not _lib.conv2d_wino1d_ok(2, 24, 32, 32, 64)          # a block of 16 rows would straddle two images
+    assert not _lib.conv2d_wino1d_ok(2, 8, 8, 32, 48)            # Cout % 64
+    for name in ("IDIFF_NO_WINO1D", "IDIFF_NO_WINO43H", "IDIFF_NO_WINOGRAD"):
+        with _lib.thread_option(name, 1):
+            assert not _lib.conv2d_wino1d_ok(2, 8, 8, 32, 64)
+    assert _lib.conv2d_wino1d_ok(2, 8, 8, 32, 64)
+    g = torch.Generator().manual_seed(0)
+    wt = (torch.randn(64, 3, 3, 32, generator=g) / 17).to(DEV)
+    u = _lib.wino1d_pack(wt, 32, 64)
+    with pytest.raises(RuntimeError, match="wino1d_pack"):        # another kernel's bank
+        _lib.conv2d_wino1d(torch.zeros(2, 8, 8, 32, device=DEV), _lib.winograd43_pack(wt, 32, 64, pairs=True), torch.zeros(2, 8, 8, 64, device=DEV),
+                           2, 8, 8, 32, 64)
+    x = torch.randn(2, 8, 8, 32, generator=g).to(DEV)
+    out = torch.empty(2, 8, 8, 64, device=DEV)
+    ref = torch.empty_like(out)
+    _lib.conv2d_wino1d(x * 3000.0, u, out, 2, 8, 8, 32, 64)       # |V| up to ~6e4 / 5.4: inside, where the 2-D form is already beyond its range
+    _lib.conv2d_nhwc(x * 3000.0, wt, ref, 2, 8, 8, 32, 64, 3, 3, 1, 1)
+    assert rel_err(out.cpu(), ref.double().cpu()) < 3e-6
+    _lib.conv2d_wino1d(x * 1e5, u, out, 2, 8, 8, 32, 64)          # beyond: loud
+    assert bool(torch.isnan(out).any()) and not bool(torch.isfinite(out).all())
+    uz = _lib.wino1d_pack(torch.zeros_like(wt), 32, 64)           # an all-zero filter packs (no scale to find) and convolves to the bias
+    bias = torch.randn(64, generator=g).to(DEV)
+    _lib.conv2d_wino1d(x, uz, out, 2, 8, 8, 32, 64, epilogue=_lib.make_epilogue(bias=bias))
+    torch.testing.assert_close(out, bias.expand(2, 8, 8, 64), rtol=0, atol=0)
+
+
 def test_conv2d_winograd43_rejects_what_it_cannot_take():
     assert not _lib.conv2d_winograd43_ok(2, 6, 8, 32, 64)       # height not a multiple of 4
     assert not _lib.conv2d_winograd43_ok(2, 8, 8, 4, 64)        # Cin % 8
