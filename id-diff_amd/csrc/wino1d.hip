@@ -66,6 +66,9 @@ constexpr int64_t R1_X_LIMIT = 0xFFFF0000ll;
 #ifndef IDIFF_W1D_BRING
 #define IDIFF_W1D_BRING 3
 #endif
+#ifndef IDIFF_W1D_STORE_AUX
+#define IDIFF_W1D_STORE_AUX 0      // cache policy bits of the output stores (1 = sc0, 2 = nt, 16 = sc1)
+#endif
 constexpr int R1_BRING = IDIFF_W1D_BRING;                          // combinations of U requested ahead (register sets of 8)
 static_assert(9 % R1_BRING == 0, "the ring of U registers must divide the nine combinations of a step");
 
@@ -88,10 +91,14 @@ struct Wino1dParams {
   float *out;
   int B, H, W, Cin, Cout;
   int rows_total, blocks_m, tiles_n, ngroup;
+  int stagger;                                     // first-round workgroups wait ((blockIdx / 8) % 4) * stagger x 8128 cycles before they start (0: off)
   uint32_t x_bytes, u_bytes, out_bytes, res_bytes;
   idiff_epilogue ep;
   int has_ep;
   float c_nb2, c_na2, c_nab2, c_a, c_b;            // the transform's constants as kernel arguments (SGPR operands of plain fmas)
+#ifdef IDIFF_W1D_STAMP
+  uint64_t *stamps;                                // diagnostic build (scripts/wino1d_stamps.py): 8 ticks of 100 MHz per workgroup
+#endif
 };
 
 template <int W>
@@ -100,6 +107,20 @@ wino1d_kernel(const Wino1dParams p) {
   using G = R1Geo<W>;
   constexpr int TPR = G::TPR, RB = G::RB, NR = G::NR, POS = G::POS_BYTES, STAGE = G::STAGE_BYTES, BRING = R1_BRING;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef IDIFF_W1D_STAMP
+  uint64_t st[8];
+#define IDIFF_W1D_T(k) { __builtin_amdgcn_sched_barrier(0); st[k] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define IDIFF_W1D_T(k)
+#endif
+  // Every CU runs its workgroups back to back and all workgroups take the same time: without this the whole chip requests its first operands,
+  // runs its K loops and stores its outputs in step -- 32 MB of stores at once, then none for 50 us.  The FIRST workgroup of each CU starts a
+  // quarter, a half or three quarters of a workgroup's life late (by CU), and the offset stays for the whole launch.
+  if (p.stagger > 0 && blockIdx.x < 256) {
+    const int turns = (int)((blockIdx.x >> 3) & 3) * p.stagger;
+    for (int i = 0; i < turns; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  IDIFF_W1D_T(0)
   char *const ldsb = reinterpret_cast<char *>(lds);
   const int nwg = p.blocks_m * p.tiles_n;
   int bid = blockIdx.x;
@@ -169,11 +190,38 @@ wino1d_kernel(const Wino1dParams p) {
       hp[j >> 1][j & 1] = v;
     }
   };
+  // the same requests in three portions (the K loop deals them over a combination's gaps): pixels [x0, x1] of tile q -> 2 + 2 + the rest
+  auto fetch_tile_part = [&](int q, int step, int part) __attribute__((always_inline)) {
+    const int choff = min(step, nsteps - 1) * (R1_KC * 4);
+    const int rl = q / TPR, tx = q % TPR;
+    const int x0 = tx == 0 ? 0 : 4 * tx - 1, x1 = tx == TPR - 1 ? W - 1 : 4 * tx + 2;
+#pragma unroll
+    for (int x = x0; x <= x1; ++x)
+      if ((x - x0) / 2 == part || (part == 2 && (x - x0) / 2 > 2))
+        rp[rl][(x + 1) >> 1][(x + 1) & 1] =
+            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)v_main, choff + rl * roww + x * (int)cin4, 0));
+  };
+  auto fetch_halo_part = [&](int step, int part) __attribute__((always_inline)) {
+    const int choff = min(step, nsteps - 1) * (R1_KC * 4);
+    uint32_t invalid = R1_INVALID;
+    asm volatile("" : "+s"(invalid));
+#pragma unroll
+    for (int j = 2 * part; j < 2 * part + 2; ++j) {
+      float v;
+      if (j == 0) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX0, (int)(h_c0 ? v_halo : invalid), choff, 0));
+      else if (j == 5) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)(h_c5 ? v_halo : invalid), choff + 4 * (int)cin4, 0));
+      else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)v_halo, choff + (j - 1) * (int)cin4, 0));
+      hp[j >> 1][j & 1] = v;
+    }
+  };
   // The dword (channels 2m, 2m + 1) this lane writes for every position: even lanes that of plane 0 (hi), odd lanes that of plane 1 (lo)
   const bool odd = (tid & 1) != 0;
   const int w_piece = 2 * (tid & 1) + (lch >> 3), w_in = ((lch & 7) >> 1) * 4;
   const uint32_t sel0 = odd ? 0x01000504u : 0x05040100u, sel1 = sel0 + 0x02020202u;
   const float k_nb2 = p.c_nb2, k_na2 = p.c_na2, k_nab2 = p.c_nab2, k_a = p.c_a, k_b = p.c_b;
+#ifdef IDIFF_W1D_DIAG_NO_VWRITE
+  uint32_t diag_sink = 0;
+#endif
   // One row-tile: t = B^T d (12 fmas, the arithmetic of winograd43_shared.h's f4_bt), each value cut into its fp16 pair, halves traded with the
   // neighbouring lane (channels 2m and 2m + 1) by DPP so that every lane stores whole dwords, one per position.
   auto put_tile = [&](int buf, const f2 P0, const f2 P1, const f2 P2, int e) __attribute__((always_inline)) {
@@ -195,8 +243,12 @@ wino1d_kernel(const Wino1dParams p) {
       const uint32_t xl = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, h2));
       const uint32_t give = odd ? xh : xl, keep = odd ? xl : xh;
       const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp((int)give, (int)give, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
+#ifdef IDIFF_W1D_DIAG_NO_VWRITE    // timing-only build: the pairs are summed into one register instead of written
+      diag_sink += __builtin_amdgcn_perm(got, keep, sel0) + __builtin_amdgcn_perm(got, keep, sel1); (void)Vd;
+#else
       *reinterpret_cast<uint32_t *>(Vd + pos_lo[q] * POS) = __builtin_amdgcn_perm(got, keep, sel0);
       *reinterpret_cast<uint32_t *>(Vd + pos_hi[q] * POS) = __builtin_amdgcn_perm(got, keep, sel1);
+#endif
     }
   };
   // part c of a stage: row-tile c of my rows (c < 8) or my halo tile (c == 8) goes to the stage, its pixels are requested for `next`
@@ -204,12 +256,20 @@ wino1d_kernel(const Wino1dParams p) {
     if (c < 8) {
       const int rl = c / TPR, tx = c % TPR;
       put_tile(buf, rp[rl][2 * tx], rp[rl][2 * tx + 1], rp[rl][2 * tx + 2], e_main0 + c);
+#ifdef IDIFF_W1D_DIAG_NO_XLOAD     // timing-only build: the input is loaded for the first two steps only
+      if (next <= 1)
+#endif
       fetch_tile(c, next);
     } else {
       put_tile(buf, hp[0], hp[1], hp[2], e_halo);
+#ifdef IDIFF_W1D_DIAG_NO_XLOAD
+      if (next <= 1)
+#endif
       fetch_halo(next);
     }
+#ifndef IDIFF_W1D_INTERLEAVE
     __builtin_amdgcn_sched_barrier(0);
+#endif
   };
 
   // ---------------------------------------------------------------- contraction
@@ -247,40 +307,125 @@ wino1d_kernel(const Wino1dParams p) {
     bl[c % BRING] = __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(rU, (int)u_lane + R1_PLANE_BYTES, soff, 0));
   };
   // A step: nine combinations c = (position 3 ph + c / 3, filter row c % 3), each twelve matrix instructions on four V fragments read one
-  // combination ahead and a U fragment requested three ahead; behind each combination's instructions one part of the next step's staging.
+  // combination ahead and a U fragment requested BRING ahead.  One wave per SIMD issues in order: vector work placed behind the matrix
+  // instructions would start when the last of them has been issued.  So the step is written as 108 GAPS -- one matrix instruction, then a
+  // slice of at most five other instructions that fit in the 32 cycles it runs, then a scheduling fence -- and the staging of one row-tile
+  // (41 vector instructions, 6 LDS writes, its 3 - 6 loads), the eight LDS reads of the next combination's V fragments and the two U loads
+  // are dealt over the twelve gaps of a combination by hand (slice()).
+  uint32_t wtab[9];                                   // where my dword of row-tile c goes, relative to its stage
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const int e = c < 8 ? e_main0 + c : e_halo;
+    wtab[c] = (uint32_t)(e * 64 + ((w_piece ^ ((e >> 2) & 3)) << 4) + w_in);
+  }
   auto step = [&](int s, auto last) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last)::value;
     const int buf = s & 1;
-    const uint32_t sbase = (uint32_t)(buf * STAGE + ph * 3 * POS);
+    const uint32_t sbase = (uint32_t)(buf * STAGE + ph * 3 * POS), wbase = (uint32_t)((buf ^ 1) * STAGE);
+    uint32_t ra[4][3];                                // this step's fragment addresses (plane 0; plane 1: bit 5 flipped)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) ra[g][ky] = a_hi[g][ky] + sbase;
     halfx8 ah[2][4], al[2][4];
-    auto read_a = [&](int c) __attribute__((always_inline)) {
-      const int pi = c / 3, ky = c % 3;
+    auto rd_hi = [&](int c, int g) __attribute__((always_inline)) { ah[c & 1][g] = *reinterpret_cast<const halfx8 *>(ldsb + ra[g][c % 3] + (c / 3) * POS); };
+    auto rd_lo = [&](int c, int g) __attribute__((always_inline)) { al[c & 1][g] = *reinterpret_cast<const halfx8 *>(ldsb + (ra[g][c % 3] ^ 32u) + (c / 3) * POS); };
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const uint32_t at = a_hi[g][ky] + sbase;
-        ah[c & 1][g] = *reinterpret_cast<const halfx8 *>(ldsb + at + pi * POS);
-        al[c & 1][g] = *reinterpret_cast<const halfx8 *>(ldsb + (at ^ 32u) + pi * POS);
+    for (int g = 0; g < 4; ++g) { rd_hi(0, g); rd_lo(0, g); }
+    // the staging state of the row-tile in flight
+    float pe, po, re, ro;
+    f2 v[3];
+    uint32_t xh, xl, give, keep, got;
+    char *Vd = ldsb;
+    constexpr int pos_lo[3] = {0, 1, 3}, pos_hi[3] = {5, 2, 4};
+    auto slice = [&](auto cc, auto kk) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value, k = decltype(kk)::value;
+      // V fragments of the next combination: plane 0 first (its products come first)
+      if (c + 1 < 9) {
+        if (k == 1) { rd_hi(c + 1, 0); rd_hi(c + 1, 1); }
+        if (k == 2) { rd_hi(c + 1, 2); rd_hi(c + 1, 3); }
+        if (k == 6) { rd_lo(c + 1, 0); rd_lo(c + 1, 1); }
+        if (k == 9) { rd_lo(c + 1, 2); rd_lo(c + 1, 3); }
       }
-    };
-    read_a(0);
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (c + 1 < 9) read_a(c + 1);
-      const int pi = c / 3;
-      const halfx8 yh = bh[c % BRING], yl = bl[c % BRING];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c & 1][g], yh, acc[g][pi], 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c & 1][g], yl, acc[g][pi], 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c & 1][g], yh, acc[g][pi], 0, 0, 0);
-      if (c + BRING < 9) load_b(c + BRING, s); else if (!LAST) load_b(c + BRING - 9, s + 1);
+      if (k == 4) {
+#ifdef IDIFF_W1D_DIAG_NO_BLOAD     // timing-only build: U is loaded for the first step only
+        if (s == 0) { if (c + BRING < 9) load_b(c + BRING, s); }
+#else
+        if (c + BRING < 9) load_b(c + BRING, s); else if (!LAST) load_b(c + BRING - 9, s + 1);
+#endif
+      }
+#ifndef IDIFF_W1D_DIAG_NO_STAGE    // timing-only build: no transform, no stage writes, no input loads after the prologue
       if (!LAST) {
-        __builtin_amdgcn_sched_barrier(0);
-        stage_part(buf ^ 1, c, s + 2);
+        constexpr int rl = c < 8 ? c / TPR : 0, tx = c < 8 ? c % TPR : 0;
+        const f2 P0 = c < 8 ? rp[rl][2 * tx] : hp[0], P1 = c < 8 ? rp[rl][2 * tx + 1] : hp[1], P2 = c < 8 ? rp[rl][2 * tx + 2] : hp[2];
+        if (k == 0) {
+          Vd = ldsb + wtab[c] + wbase;
+          pe = fmaf(k_nb2, P1.x, P2.x); po = fmaf(k_nb2, P0.y, P1.y);
+          re = fmaf(k_na2, P1.x, P2.x); ro = fmaf(k_na2, P0.y, P1.y);
+        }
+        if (k == 1) { v[0].x = fmaf(k_nab2, P1.x, P0.x + P2.x); v[0].y = fmaf(k_nab2, P1.y, P0.y + P2.y); }      // positions 0, 5
+        if (k == 2) { v[1].x = fmaf(k_a, po, pe); v[1].y = fmaf(-k_a, po, pe); v[2].x = fmaf(k_b, ro, re); v[2].y = fmaf(-k_b, ro, re); }   // 1, 2 | 3, 4
+        constexpr int q = k >= 3 ? (k - 3) / 3 : 0, ph3 = k >= 3 ? (k - 3) % 3 : -1;          // pair q of the tile: cut (4), trade (3), store (2 + 2)
+        if (ph3 == 0) {
+          xh = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[q], h2));
+          f2 rest;                                                  // v - hi in one mixed-precision instruction per component (exact)
+          asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rest.x) : "v"(xh), "v"(v[q].x));
+          asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest.y) : "v"(xh), "v"(v[q].y));
+          xl = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, h2));
+        }
+        if (ph3 == 1) {
+          give = odd ? xh : xl; keep = odd ? xl : xh;
+          got = (uint32_t)__builtin_amdgcn_update_dpp((int)give, (int)give, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
+        }
+        if (ph3 == 2) {
+#ifdef IDIFF_W1D_DIAG_NO_VWRITE    // timing-only build: the pairs are summed into one register instead of written
+          diag_sink += __builtin_amdgcn_perm(got, keep, sel0) + __builtin_amdgcn_perm(got, keep, sel1);
+#else
+          *reinterpret_cast<uint32_t *>(Vd + pos_lo[q] * POS) = __builtin_amdgcn_perm(got, keep, sel0);
+          *reinterpret_cast<uint32_t *>(Vd + pos_hi[q] * POS) = __builtin_amdgcn_perm(got, keep, sel1);
+#endif
+        }
+        // the pixels nobody reads any more receive the step after next (the transform read them in gaps 0 - 2)
+#ifdef IDIFF_W1D_DIAG_NO_XLOAD     // timing-only build: the input is loaded for the first two steps only
+        if (s + 2 <= 1)
+#endif
+        {
+          if (c < 8) {
+            if (k == 7) fetch_tile_part(c, s + 2, 0);
+            if (k == 10) fetch_tile_part(c, s + 2, 1);
+            if (k == 11) fetch_tile_part(c, s + 2, 2);
+          } else {
+            if (k == 7) fetch_halo_part(s + 2, 0);
+            if (k == 10) fetch_halo_part(s + 2, 1);
+            if (k == 11) fetch_halo_part(s + 2, 2);
+          }
+        }
       }
-    }
+#endif
+    };
+    auto combo = [&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      constexpr int pi = c / 3;
+      const halfx8 yh = bh[c % BRING], yl = bl[c % BRING];
+      auto gap = [&](auto kk) __attribute__((always_inline)) {
+        constexpr int k = decltype(kk)::value, g = k & 3, pr = k >> 2;       // products: plane 0 x plane 0, plane 0 x plane 1, plane 1 x plane 0
+#ifdef IDIFF_W1D_DIAG_NO_MFMA      // timing-only build: the operands are consumed by one vector instruction instead
+        acc[g][pi][0] += (float)(pr == 2 ? al[c & 1][g] : ah[c & 1][g])[0] + (float)(pr == 1 ? yl : yh)[0];
+#else
+        acc[g][pi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? al[c & 1][g] : ah[c & 1][g], pr == 1 ? yl : yh, acc[g][pi], 0, 0, 0);
+#endif
+        slice(cc, kk);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      gap(std::integral_constant<int, 0>()); gap(std::integral_constant<int, 1>()); gap(std::integral_constant<int, 2>());
+      gap(std::integral_constant<int, 3>()); gap(std::integral_constant<int, 4>()); gap(std::integral_constant<int, 5>());
+      gap(std::integral_constant<int, 6>()); gap(std::integral_constant<int, 7>()); gap(std::integral_constant<int, 8>());
+      gap(std::integral_constant<int, 9>()); gap(std::integral_constant<int, 10>()); gap(std::integral_constant<int, 11>());
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    combo(std::integral_constant<int, 0>()); combo(std::integral_constant<int, 1>()); combo(std::integral_constant<int, 2>());
+    combo(std::integral_constant<int, 3>()); combo(std::integral_constant<int, 4>()); combo(std::integral_constant<int, 5>());
+    combo(std::integral_constant<int, 6>()); combo(std::integral_constant<int, 7>()); combo(std::integral_constant<int, 8>());
     __syncthreads();
   };
 
@@ -294,14 +439,23 @@ wino1d_kernel(const Wino1dParams p) {
 #pragma unroll
   for (int c = 0; c < 8; ++c) fetch_tile(c, 0);
   fetch_halo(0);
+#ifdef IDIFF_W1D_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  IDIFF_W1D_T(1)                                     // first operands arrived
 #pragma unroll
   for (int c = 0; c < 9; ++c) stage_part(0, c, 1);
   __syncthreads();
+  IDIFF_W1D_T(2)
   {
     int s = 0;                                        // at least two steps (Cin >= 32, checked by the launcher)
     do step(s, std::false_type()); while (++s + 1 < nsteps);
   }
   step(nsteps - 1, std::true_type());
+  IDIFF_W1D_T(3)
+#ifdef IDIFF_W1D_DIAG_NO_VWRITE
+  if (diag_sink == 12345u) ldsb[tid] = 1;
+#endif
 
   // ---------------------------------------------------------------- tail
   const float descale = p.u[(int64_t)R1_NSLOT * p.Cin * p.Cout];
@@ -333,10 +487,15 @@ wino1d_kernel(const Wino1dParams p) {
   // the finishing thread: channels n .. n + 3 of the 32 consecutive pixels of rows tl NR .. (row-tiles 8 tl .. 8 tl + 7): one sample
   const int cq = tid & 15, tl = tid >> 4;
   const int n = n0 + 4 * cq;
+#ifdef IDIFF_W1D_DIAG_PLAIN_EP      // timing-only build: the epilogue's switches as compile-time constants (bias only)
+  const bool has_res = false, scaled = false, want_stats = false;
+  const int act = (int)IDIFF_ACT_NONE;
+#else
   const bool has_res = has_ep && ep.residual != nullptr;
   const bool scaled = has_ep && (ep.out_scale != 1.f || ep.rowscale != nullptr);
   const int act = has_ep ? ep.act : (int)IDIFF_ACT_NONE;
   const bool want_stats = has_ep && ep.colstats != nullptr;
+#endif
   const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)p.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)ep.residual, 0, (int)p.res_bytes, 0x00020000);
   const int ld_res = (int)ep.ld_residual;
@@ -368,33 +527,53 @@ wino1d_kernel(const Wino1dParams p) {
   __syncthreads();
   if (ph == 0) { mix(I0(), std::false_type()); mix(I1(), std::false_type()); } else { mix(I2(), std::false_type()); mix(I3(), std::false_type()); }
   __syncthreads();
+  IDIFF_W1D_T(4)
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  // The 32 pixels of this thread with the epilogue's switches as COMPILE-TIME constants: with `act`, `has_res`, ... tested at run time inside
+  // the loop every pixel became a chain of scalar branches between its LDS read and its store and nothing of one pixel overlapped the next --
+  // 9.6 us per workgroup where this form takes 1.7 (profiles/r05_wino1d_stamps.txt).  ACT < 0: the activation by its run-time code.
+  auto finish = [&](auto act_c, auto res_c, auto scaled_c, auto stats_c) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_c)::value;
+    constexpr bool RES = decltype(res_c)::value, SCALED = decltype(scaled_c)::value, STATS = decltype(stats_c)::value;
 #pragma unroll
-  for (int chunk = 0; chunk < 4; ++chunk) {
-    if (has_res && chunk + 1 < 4) load_res(chunk + 1);
-    float4 z[8];
+    for (int chunk = 0; chunk < 4; ++chunk) {
+      if (RES && chunk + 1 < 4) load_res(chunk + 1);
+      float4 z[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) z[i] = *reinterpret_cast<const float4 *>(lds + (size_t)(32 * tl + 8 * chunk + i) * R1_COUT + 4 * cq);
+      for (int i = 0; i < 8; ++i) z[i] = *reinterpret_cast<const float4 *>(lds + (size_t)(32 * tl + 8 * chunk + i) * R1_COUT + 4 * cq);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float y[4] = {z[i].x * descale + badd.x, z[i].y * descale + badd.y, z[i].z * descale + badd.z, z[i].w * descale + badd.w};
-      if (act != IDIFF_ACT_NONE) {
+      for (int i = 0; i < 8; ++i) {
+        float y[4] = {z[i].x * descale + badd.x, z[i].y * descale + badd.y, z[i].z * descale + badd.z, z[i].w * descale + badd.w};
+        if (ACT != (int)IDIFF_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = idiff::act_apply(y[e], act);
+          for (int e = 0; e < 4; ++e) y[e] = idiff::act_apply(y[e], ACT < 0 ? act : ACT);
+        }
+        if (RES) { const float4 r = res[chunk & 1][i]; y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w; }
+        if (SCALED) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] *= sc;
+        }
+        if (STATS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1[e] += (double)y[e]; s2[e] += (double)y[e] * (double)y[e]; }
+        }
+#ifdef IDIFF_W1D_DIAG_NO_STORE     // timing-only build: one store per thread instead of 32
+        if (8 * chunk + i == 31)
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, make_float4(y[0], y[1], y[2], y[3])), rO, (int)ooff,
+                                               (8 * chunk + i) * p.Cout * 4, IDIFF_W1D_STORE_AUX);
       }
-      if (has_res) { const float4 r = res[chunk & 1][i]; y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w; }
-      if (scaled) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] *= sc;
-      }
-      if (want_stats) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s1[e] += (double)y[e]; s2[e] += (double)y[e] * (double)y[e]; }
-      }
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, make_float4(y[0], y[1], y[2], y[3])), rO, (int)ooff,
-                                             (8 * chunk + i) * p.Cout * 4, 0);
     }
+  };
+  {
+    using T = std::true_type; using F = std::false_type;
+    using ANone = std::integral_constant<int, (int)IDIFF_ACT_NONE>; using AAny = std::integral_constant<int, -1>;
+    auto by_stats = [&](auto a, auto r, auto sc_) __attribute__((always_inline)) { if (want_stats) finish(a, r, sc_, T()); else finish(a, r, sc_, F()); };
+    auto by_scale = [&](auto a, auto r) __attribute__((always_inline)) { if (scaled) by_stats(a, r, T()); else by_stats(a, r, F()); };
+    auto by_res = [&](auto a) __attribute__((always_inline)) { if (has_res) by_scale(a, T()); else by_scale(a, F()); };
+    if (act == (int)IDIFF_ACT_NONE) by_res(ANone()); else by_res(AAny());
   }
+  IDIFF_W1D_T(5)
   if (want_stats) {
     // per-sample (or per-block, where a sample spans several blocks) column sums for the GroupNorm that reads this output: thread sums ->
     // [16 thread rows][64 channels] in LDS -> one thread per (slot, channel)
@@ -418,6 +597,15 @@ wino1d_kernel(const Wino1dParams p) {
       dst[0] = a; dst[1] = b;
     }
   }
+#ifdef IDIFF_W1D_STAMP
+  IDIFF_W1D_T(6)
+  if (tid == 0 && p.stamps) {
+    uint64_t *q = p.stamps + 8 * (int64_t)blockIdx.x;
+    for (int k = 0; k < 7; ++k) q[k] = st[k];
+    q[7] = __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (0 << 6) | 4) ;   // HW_ID low byte: wave / SIMD / pipe ... (bits 8..11: CU)
+  }
+#endif
+#undef IDIFF_W1D_T
 }
 
 // U[i][ky] = sum_kx G[i][kx] g[ky][kx] in fp64 for one (cin, cout) pair
@@ -556,6 +744,10 @@ IDIFF_API int idiff_conv2d_wino1d_f32(const float *x, const float *u, float *out
     p.has_ep = 0; p.ep.rows_per_group = 1; p.ep.out_scale = 1.f;
   }
   p.c_nb2 = -R1_b2; p.c_na2 = -R1_a2; p.c_nab2 = -R1_ab2; p.c_a = R1_a; p.c_b = R1_b;
+  { const char *e = getenv("IDIFF_W1D_STAGGER"); p.stagger = e ? atoi(e) : 0; }     // EXPERIMENT (scripts/wino1d_probe.py): read per launch
+#ifdef IDIFF_W1D_STAMP
+  { const char *e = getenv("IDIFF_W1D_STAMP_PTR"); p.stamps = e ? reinterpret_cast<uint64_t *>(strtoull(e, nullptr, 0)) : nullptr; }
+#endif
   switch (W) {
     case 8: return r1_launch<8>(p, (hipStream_t)stream);
     case 16: return r1_launch<16>(p, (hipStream_t)stream);
