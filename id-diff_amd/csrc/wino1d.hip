@@ -47,6 +47,16 @@ typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// LDS by its 32-bit address: the K loop keeps complete addresses in registers (stage, entry, piece; positions are immediate offsets), so no
+// instruction re-adds the allocation's base per access
+typedef __attribute__((address_space(3))) char r1_lds_char;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"           // (the host pass sees 64-bit pointers; LDS pointers of the device pass are 32 bits wide)
+typedef __attribute__((address_space(3))) halfx8 r1_lds_halfx8;
+typedef __attribute__((address_space(3))) uint32_t r1_lds_u32;
+__device__ __forceinline__ halfx8 r1_lds_read16(uint32_t at) { return *(const r1_lds_halfx8 *)at; }
+__device__ __forceinline__ void r1_lds_write4(uint32_t at, uint32_t v) { *(r1_lds_u32 *)at = v; }
+#pragma clang diagnostic pop
 
 constexpr double R1_A = 2.0 / 3.0, R1_B = 1.5;                     // the interpolation points of winograd43_shared.h
 constexpr float R1_a = (float)R1_A, R1_b = (float)R1_B, R1_a2 = (float)(R1_A * R1_A), R1_b2 = (float)(R1_B * R1_B),
@@ -61,6 +71,7 @@ constexpr int R1_SLOT_BYTES = 2 * 64 * R1_KC * 2;                  // 4096
 constexpr int R1_PLANE_BYTES = 64 * R1_KC * 2;                     // 2048
 constexpr int R1_Z_BYTES = R1_RT * 4 * R1_COUT * 4;                // the tail's exchange: 131,072
 constexpr size_t R1_LDS_BYTES = R1_Z_BYTES;
+constexpr uint32_t R1_STAGE_STRIDE = 0x10000;                      // the two stages 64 KB apart: the other stage is one XOR away
 constexpr uint32_t R1_INVALID = 0xFFFF8000u;                       // beyond any valid extent (the scalar offset is not range-checked)
 constexpr int64_t R1_X_LIMIT = 0xFFFF0000ll;
 #ifndef IDIFF_W1D_BRING
@@ -72,16 +83,23 @@ constexpr int64_t R1_X_LIMIT = 0xFFFF0000ll;
 constexpr int R1_BRING = IDIFF_W1D_BRING;                          // combinations of U requested ahead (register sets of 8)
 static_assert(9 % R1_BRING == 0, "the ring of U registers must divide the nine combinations of a step");
 
+// Where entry e of a stage lives: the entries of every second group of four trade places in pairs.  The 32 lanes of one pass of a ds_write_b32
+// are four loader threads' dwords of the entries e, e + 4, e + 8, e + 12 (32 bytes each); at e * 64 they would fall on two of the four
+// 32-byte quarters of the 128 bytes the banks span (a two-way conflict on every stage write, SQ_LDS_BANK_CONFLICT = 24 % of the LDS cycles);
+// the trade alternates the entries' parity and the four land on four quarters.  A fragment read covers both members of every pair, so its
+// conflict-free pattern is unchanged.
+__device__ __forceinline__ int r1_slot(int e) { return e ^ ((e >> 2) & 1); }
+
 template <int W> struct R1Geo {
   static constexpr int TPR = W / 4;                                // row-tiles per image row
   static constexpr int RB = R1_PIXELS / W;                         // image rows per workgroup
   static constexpr int NR = RB / 16;                               // rows per loader thread
-  static constexpr int E = (RB + 2) * TPR + 1;                     // stage entries: slot 0 = the row above the block, RB + 1 = the row below, then the zero entry
-  static constexpr int EZ = E - 1;
+  static constexpr int EZ = (RB + 2) * TPR;                        // stage entries: row slot 0 = the row above the block, RB + 1 = the row below, then the zero entry
+  static constexpr int E = (EZ + 1 + 7) & ~7;                      // (whole groups of eight: r1_slot() stays inside)
   static constexpr int POS_BYTES = E * 64;
   static constexpr int STAGE_BYTES = 6 * POS_BYTES;
   static_assert(NR * TPR == 8, "a loader thread owns eight row-tiles");
-  static_assert(2 * STAGE_BYTES <= R1_Z_BYTES, "two stages inside the tail's exchange");
+  static_assert(STAGE_BYTES <= R1_STAGE_STRIDE, "a stage inside its half of the LDS allocation");
   static_assert(5 * POS_BYTES < 65536, "positions are reached by the LDS instructions' immediate offset");
 };
 
@@ -105,7 +123,7 @@ template <int W>
 __global__ void __launch_bounds__(R1_THREADS)
 wino1d_kernel(const Wino1dParams p) {
   using G = R1Geo<W>;
-  constexpr int TPR = G::TPR, RB = G::RB, NR = G::NR, POS = G::POS_BYTES, STAGE = G::STAGE_BYTES, BRING = R1_BRING;
+  constexpr int TPR = G::TPR, RB = G::RB, NR = G::NR, POS = G::POS_BYTES, BRING = R1_BRING;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef IDIFF_W1D_STAMP
   uint64_t st[8];
@@ -122,6 +140,7 @@ wino1d_kernel(const Wino1dParams p) {
   }
   IDIFF_W1D_T(0)
   char *const ldsb = reinterpret_cast<char *>(lds);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(r1_lds_char *)ldsb;   // the allocation's LDS address
   const int nwg = p.blocks_m * p.tiles_n;
   int bid = blockIdx.x;
   {   // consecutive workgroups of the launch order land on different XCDs: give every XCD a contiguous range of the (row block, cout tile) order
@@ -136,140 +155,140 @@ wino1d_kernel(const Wino1dParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wh = wave & 1, ph = wave >> 1;
 
-  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)p.u, 0, (int)p.u_bytes, 0x00020000);
   const uint32_t cin4 = (uint32_t)p.Cin * 4u;
-  // the halo tile's pixel 4 t - 1 goes through a descriptor whose base is one pixel to the left (the range check covers the vector offset only)
-  const __amdgpu_buffer_rsrc_t rX0 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x - p.Cin), 0, (int)(p.x_bytes + cin4), 0x00020000);
   const int roww = W * (int)cin4;                                  // bytes per image row
   const int nsteps = p.Cin / R1_KC;
 
-  // ---------------------------------------------------------------- loader: thread = (channel, rows)
-  const int lch = tid & 15, lk = tid >> 4;
+  // ---------------------------------------------------------------- loader: thread = (channel pair, row segment)
+  // Lane lm holds channels 2 lm and 2 lm + 1 (8-byte loads: eight consecutive lanes read the 64 contiguous bytes of a pixel), so the two halves of
+  // every stage dword are in ONE lane and a value pair costs 2 conversions + 2 mixed fmas -- no exchange with a neighbouring lane, no selects.
+  // Segment set lk: W = 32: half a row (pixels 16 hf - 1 .. 16 hf + 16 of row lk / 2), W = 16: row lk, W = 8: rows 2 lk and 2 lk + 1 -- four
+  // row-tiles and 16 pixels (+ the neighbours left and right) per thread and step; lk < 2 W / 4 additionally one row-tile of a halo row.
+  constexpr int NSEG = W == 8 ? 2 : 1;                             // row segments of a thread
+  constexpr int TS = 4 / NSEG;                                     // row-tiles per segment
+  constexpr int NPX = 4 * TS + 2;                                  // its pixels, the one to the left and the one to the right included
+  const int lm = tid & 7, lk = tid >> 3;
+  // base one pixel to the LEFT: offset v + j * cin4 is the segment's pixel j - 1 ... (the range check covers the vector offset only)
+  const __amdgpu_buffer_rsrc_t rXm = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x - p.Cin), 0, (int)(p.x_bytes + cin4), 0x00020000);
   uint32_t v_main, v_halo;
-  bool h_c0, h_c5;
+  bool m_l, m_r, h_c0, h_c5;
   int e_halo;
   {
-    const int rho = row0 + lk * NR;                                // my first row: all NR of them inside the tensor or none (H % 4 == 0)
-    v_main = rho < p.rows_total ? (uint32_t)rho * (uint32_t)roww + (uint32_t)lch * 4u : R1_INVALID;
+#ifdef IDIFF_W1D_DIAG_SAME_X       // timing-only build: every workgroup reads the first block's pixels (L2 hits instead of HBM misses)
+    const int rho = (W == 32 ? lk >> 1 : (W == 16 ? lk : 2 * lk));
+#else
+    const int rho = row0 + (W == 32 ? lk >> 1 : (W == 16 ? lk : 2 * lk));
+#endif
+    const int xf = W == 32 ? 16 * (lk & 1) : 0;                   // first pixel of my first tile
+    v_main = rho < p.rows_total ? (uint32_t)rho * (uint32_t)roww + (uint32_t)xf * cin4 + (uint32_t)lm * 8u : R1_INVALID;
+    m_l = xf > 0; m_r = xf + 4 * TS < W;                           // the neighbours are pixels of the row (else the zero padding)
     const bool part = lk < 2 * TPR, top = lk < TPR;
     const int tx = top ? lk : lk - TPR;
     const int hr = top ? row0 - 1 : row0 + RB;                     // the halo row: inside the same image as the block's first / last row?
     const bool valid = part && (top ? (row0 % p.H != 0) : ((row0 + RB) % p.H != 0 && row0 + RB < p.rows_total));
-    v_halo = valid ? (uint32_t)hr * (uint32_t)roww + (uint32_t)(4 * tx) * cin4 + (uint32_t)lch * 4u : R1_INVALID;   // at pixel 4 t
+    v_halo = valid ? (uint32_t)hr * (uint32_t)roww + (uint32_t)(4 * tx) * cin4 + (uint32_t)lm * 8u : R1_INVALID;
     h_c0 = tx > 0; h_c5 = tx + 1 < TPR;
     e_halo = part ? (top ? tx : (RB + 1) * TPR + tx) : G::EZ;      // threads without a halo tile transform zeros into the zero entry
   }
-  const int e_main0 = TPR + 8 * lk;                                // my eight row-tiles' entries: consecutive
-  // Pixels in PAIRS of registers: rp[row][m] = (x[2 m - 1], x[2 m]), pixel -1 and pixel W are the zero padding: tile t reads rp[2 t .. 2 t + 2]
-  f2 rp[NR][2 * TPR + 1];
-  f2 hp[3];
+  const int e_main0 = TPR + 4 * lk;                                // my four row-tiles' entries: consecutive
+  f2 px[NSEG][NPX];                                                // (channel 2 lm, channel 2 lm + 1) per pixel
+  f2 hp[6];
 #pragma unroll
-  for (int r = 0; r < NR; ++r)
+  for (int g = 0; g < NSEG; ++g)
 #pragma unroll
-    for (int m = 0; m < 2 * TPR + 1; ++m) rp[r][m] = f2{0.f, 0.f};
-  auto fetch_tile = [&](int q, int step) __attribute__((always_inline)) {      // the pixels whose LAST reader is tile q, for K step `step`
-    const int choff = min(step, nsteps - 1) * (R1_KC * 4);                     // (clamped: the last stages request their own step again, nobody reads it)
-    const int rl = q / TPR, tx = q % TPR;
-    const int x0 = tx == 0 ? 0 : 4 * tx - 1, x1 = tx == TPR - 1 ? W - 1 : 4 * tx + 2;
-#pragma unroll
-    for (int x = x0; x <= x1; ++x)
-      rp[rl][(x + 1) >> 1][(x + 1) & 1] =
-          __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)v_main, choff + rl * roww + x * (int)cin4, 0));
-  };
-  auto fetch_halo = [&](int step) __attribute__((always_inline)) {
+    for (int j = 0; j < NPX; ++j) px[g][j] = f2{0.f, 0.f};
+  uint32_t invalid_s = R1_INVALID;
+  // pixels [j0, j1] of segment g for K step `step` (clamped: the last stages request their own step again, nobody reads it)
+  auto fetch_px = [&](int g, int j0, int j1, int step) __attribute__((always_inline)) {
     const int choff = min(step, nsteps - 1) * (R1_KC * 4);
-    uint32_t invalid = R1_INVALID;
-    asm volatile("" : "+s"(invalid));
+    asm volatile("" : "+s"(invalid_s));
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      float v;
-      if (j == 0) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX0, (int)(h_c0 ? v_halo : invalid), choff, 0));
-      else if (j == 5) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)(h_c5 ? v_halo : invalid), choff + 4 * (int)cin4, 0));
-      else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)v_halo, choff + (j - 1) * (int)cin4, 0));
-      hp[j >> 1][j & 1] = v;
+    for (int j = j0; j <= j1; ++j) {
+      if (W != 32 && (j == 0 || j == NPX - 1)) continue;           // always the padding
+      const uint32_t vo = j == 0 ? (m_l ? v_main : invalid_s) : (j == NPX - 1 ? (m_r ? v_main : invalid_s) : v_main);
+      px[g][j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rXm, (int)vo, choff + g * roww + j * (int)cin4, 0));
     }
   };
-  // the same requests in three portions (the K loop deals them over a combination's gaps): pixels [x0, x1] of tile q -> 2 + 2 + the rest
-  auto fetch_tile_part = [&](int q, int step, int part) __attribute__((always_inline)) {
+  auto fetch_hp = [&](int j0, int j1, int step) __attribute__((always_inline)) {
     const int choff = min(step, nsteps - 1) * (R1_KC * 4);
-    const int rl = q / TPR, tx = q % TPR;
-    const int x0 = tx == 0 ? 0 : 4 * tx - 1, x1 = tx == TPR - 1 ? W - 1 : 4 * tx + 2;
+    asm volatile("" : "+s"(invalid_s));
 #pragma unroll
-    for (int x = x0; x <= x1; ++x)
-      if ((x - x0) / 2 == part || (part == 2 && (x - x0) / 2 > 2))
-        rp[rl][(x + 1) >> 1][(x + 1) & 1] =
-            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)v_main, choff + rl * roww + x * (int)cin4, 0));
-  };
-  auto fetch_halo_part = [&](int step, int part) __attribute__((always_inline)) {
-    const int choff = min(step, nsteps - 1) * (R1_KC * 4);
-    uint32_t invalid = R1_INVALID;
-    asm volatile("" : "+s"(invalid));
-#pragma unroll
-    for (int j = 2 * part; j < 2 * part + 2; ++j) {
-      float v;
-      if (j == 0) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX0, (int)(h_c0 ? v_halo : invalid), choff, 0));
-      else if (j == 5) v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)(h_c5 ? v_halo : invalid), choff + 4 * (int)cin4, 0));
-      else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, (int)v_halo, choff + (j - 1) * (int)cin4, 0));
-      hp[j >> 1][j & 1] = v;
+    for (int j = j0; j <= j1; ++j) {
+      const uint32_t vo = j == 0 ? (h_c0 ? v_halo : invalid_s) : (j == 5 ? (h_c5 ? v_halo : invalid_s) : v_halo);
+      hp[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rXm, (int)vo, choff + j * (int)cin4, 0));
     }
   };
-  // The dword (channels 2m, 2m + 1) this lane writes for every position: even lanes that of plane 0 (hi), odd lanes that of plane 1 (lo)
-  const bool odd = (tid & 1) != 0;
-  const int w_piece = 2 * (tid & 1) + (lch >> 3), w_in = ((lch & 7) >> 1) * 4;
-  const uint32_t sel0 = odd ? 0x01000504u : 0x05040100u, sel1 = sel0 + 0x02020202u;
+  // where my hi dword of row-tile i (4: the halo tile) goes in stage 0, position 0 (LDS address); the lo dword: bit 5 flipped; stage 1: bit 16
+  uint32_t wtab[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int e = r1_slot(i < 4 ? e_main0 + i : e_halo);
+    wtab[i] = lds0 + (uint32_t)(e * 64 + (((lm >> 2) ^ ((e >> 2) & 3)) << 4) + (lm & 3) * 4);
+  }
   const float k_nb2 = p.c_nb2, k_na2 = p.c_na2, k_nab2 = p.c_nab2, k_a = p.c_a, k_b = p.c_b;
 #ifdef IDIFF_W1D_DIAG_NO_VWRITE
   uint32_t diag_sink = 0;
 #endif
-  // One row-tile: t = B^T d (12 fmas, the arithmetic of winograd43_shared.h's f4_bt), each value cut into its fp16 pair, halves traded with the
-  // neighbouring lane (channels 2m and 2m + 1) by DPP so that every lane stores whole dwords, one per position.
-  auto put_tile = [&](int buf, const f2 P0, const f2 P1, const f2 P2, int e) __attribute__((always_inline)) {
-    char *Vd = ldsb + buf * STAGE + e * 64 + ((w_piece ^ ((e >> 2) & 3)) << 4) + w_in;
-    const float d0 = P0.x, d1 = P0.y, d2 = P1.x, d3 = P1.y, d4 = P2.x, d5 = P2.y;
-    const float pe = fmaf(k_nb2, d2, d4), po = fmaf(k_nb2, d1, d3);
-    const float re = fmaf(k_na2, d2, d4), ro = fmaf(k_na2, d1, d3);
-    f2 v[3];
-    v[0].x = fmaf(k_nab2, d2, d0 + d4); v[0].y = fmaf(k_nab2, d3, d1 + d5);        // positions 0, 5
-    v[1].x = fmaf(k_a, po, pe); v[1].y = fmaf(-k_a, po, pe);                        // 1, 2
-    v[2].x = fmaf(k_b, ro, re); v[2].y = fmaf(-k_b, ro, re);                        // 3, 4
-    constexpr int pos_lo[3] = {0, 1, 3}, pos_hi[3] = {5, 2, 4};
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const uint32_t xh = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[q], h2));
-      f2 rest;                                                      // v - hi in one mixed-precision instruction per component (exact)
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rest.x) : "v"(xh), "v"(v[q].x));
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest.y) : "v"(xh), "v"(v[q].y));
+  // The staging of ONE row-tile (two channels) in 13 groups of at most five vector instructions, the units the K loop deals over its gaps:
+  //   0 - 4   t = B^T d for both channels (12 operations each, the arithmetic of winograd43_shared.h's f4_bt)
+  //   5 - 10  position grp - 5: the two channels' values -> one dword of hi parts, one of lo parts (v - hi in one mixed-precision fma each), stored
+  //   11, 12  the pixels no later tile reads are requested for K step `next`
+  float t_pe[2], t_po[2], t_re[2], t_ro[2], t_s04[2], t_s15[2], tv[2][6];
+  uint32_t w_hi = 0, w_lo = 0;
+  auto tile_group = [&](auto ii, auto gg, uint32_t wbase, int next) __attribute__((always_inline)) {
+    constexpr int i = decltype(ii)::value, grp = decltype(gg)::value;
+    constexpr int sg = i < 4 ? i / TS : 0, t = i < 4 ? i % TS : 0;
+    auto d = [&](int c, int j) __attribute__((always_inline)) { return i < 4 ? px[sg][4 * t + j][c] : hp[j][c]; };
+    auto head = [&](int c, int part) __attribute__((always_inline)) {          // the twelve operations of channel c in five parts
+      if (part == 0) { t_pe[c] = fmaf(k_nb2, d(c, 2), d(c, 4)); t_po[c] = fmaf(k_nb2, d(c, 1), d(c, 3)); t_re[c] = fmaf(k_na2, d(c, 2), d(c, 4)); }
+      if (part == 1) { t_ro[c] = fmaf(k_na2, d(c, 1), d(c, 3)); t_s04[c] = d(c, 0) + d(c, 4); t_s15[c] = d(c, 1) + d(c, 5); }
+      if (part == 2) { tv[c][0] = fmaf(k_nab2, d(c, 2), t_s04[c]); tv[c][5] = fmaf(k_nab2, d(c, 3), t_s15[c]); }
+      if (part == 3) { tv[c][1] = fmaf(k_a, t_po[c], t_pe[c]); tv[c][2] = fmaf(-k_a, t_po[c], t_pe[c]); }
+      if (part == 4) { tv[c][3] = fmaf(k_b, t_ro[c], t_re[c]); tv[c][4] = fmaf(-k_b, t_ro[c], t_re[c]); }
+    };
+    if (grp == 0) { w_hi = wtab[i] ^ wbase; w_lo = w_hi ^ 32u; head(0, 0); head(0, 1); }     // (wbase: 0 or the stage stride)
+    if (grp == 1) { head(0, 2); head(0, 3); }
+    if (grp == 2) { head(0, 4); head(1, 0); }
+    if (grp == 3) { head(1, 1); head(1, 2); }
+    if (grp == 4) { head(1, 3); head(1, 4); }
+    if (grp >= 5 && grp <= 10) {
+      constexpr int pos = grp >= 5 && grp <= 10 ? grp - 5 : 0;
+      const f2 vv = {tv[0][pos], tv[1][pos]};
+      const uint32_t xh = __builtin_bit_cast(uint32_t, __builtin_convertvector(vv, h2));
+      f2 rest;                                                      // v - hi in one mixed-precision instruction per channel (exact)
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rest.x) : "v"(xh), "v"(vv.x));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest.y) : "v"(xh), "v"(vv.y));
       const uint32_t xl = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, h2));
-      const uint32_t give = odd ? xh : xl, keep = odd ? xl : xh;
-      const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp((int)give, (int)give, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
 #ifdef IDIFF_W1D_DIAG_NO_VWRITE    // timing-only build: the pairs are summed into one register instead of written
-      diag_sink += __builtin_amdgcn_perm(got, keep, sel0) + __builtin_amdgcn_perm(got, keep, sel1); (void)Vd;
+      diag_sink += xh + xl;
 #else
-      *reinterpret_cast<uint32_t *>(Vd + pos_lo[q] * POS) = __builtin_amdgcn_perm(got, keep, sel0);
-      *reinterpret_cast<uint32_t *>(Vd + pos_hi[q] * POS) = __builtin_amdgcn_perm(got, keep, sel1);
+      r1_lds_write4(w_hi + pos * POS, xh);
+      r1_lds_write4(w_lo + pos * POS, xl);
 #endif
+    }
+#ifdef IDIFF_W1D_DIAG_NO_XLOAD     // timing-only build: the input is loaded for the first two steps only
+    if (next <= 1)
+#endif
+    if (grp >= 11) {
+      if (i < 4) {
+        constexpr int j0 = 4 * t, j1 = t == TS - 1 ? 4 * t + 5 : 4 * t + 3, mid = (j0 + j1) / 2;
+        if (grp == 11) fetch_px(sg, j0, mid, next); else fetch_px(sg, mid + 1, j1, next);
+      } else {
+        if (grp == 11) fetch_hp(0, 2, next); else fetch_hp(3, 5, next);
+      }
     }
   };
-  // part c of a stage: row-tile c of my rows (c < 8) or my halo tile (c == 8) goes to the stage, its pixels are requested for `next`
-  auto stage_part = [&](int buf, int c, int next) __attribute__((always_inline)) {
-    if (c < 8) {
-      const int rl = c / TPR, tx = c % TPR;
-      put_tile(buf, rp[rl][2 * tx], rp[rl][2 * tx + 1], rp[rl][2 * tx + 2], e_main0 + c);
-#ifdef IDIFF_W1D_DIAG_NO_XLOAD     // timing-only build: the input is loaded for the first two steps only
-      if (next <= 1)
-#endif
-      fetch_tile(c, next);
-    } else {
-      put_tile(buf, hp[0], hp[1], hp[2], e_halo);
-#ifdef IDIFF_W1D_DIAG_NO_XLOAD
-      if (next <= 1)
-#endif
-      fetch_halo(next);
-    }
-#ifndef IDIFF_W1D_INTERLEAVE
+  // all of one tile at once (the first step's stage, before the loop)
+  auto tile_all = [&](auto ii, uint32_t wbase, int next) __attribute__((always_inline)) {
+    tile_group(ii, std::integral_constant<int, 0>(), wbase, next); tile_group(ii, std::integral_constant<int, 1>(), wbase, next);
+    tile_group(ii, std::integral_constant<int, 2>(), wbase, next); tile_group(ii, std::integral_constant<int, 3>(), wbase, next);
+    tile_group(ii, std::integral_constant<int, 4>(), wbase, next); tile_group(ii, std::integral_constant<int, 5>(), wbase, next);
+    tile_group(ii, std::integral_constant<int, 6>(), wbase, next); tile_group(ii, std::integral_constant<int, 7>(), wbase, next);
+    tile_group(ii, std::integral_constant<int, 8>(), wbase, next); tile_group(ii, std::integral_constant<int, 9>(), wbase, next);
+    tile_group(ii, std::integral_constant<int, 10>(), wbase, next); tile_group(ii, std::integral_constant<int, 11>(), wbase, next);
+    tile_group(ii, std::integral_constant<int, 12>(), wbase, next);
     __builtin_amdgcn_sched_barrier(0);
-#endif
   };
 
   // ---------------------------------------------------------------- contraction
@@ -283,7 +302,7 @@ wino1d_kernel(const Wino1dParams p) {
   const int fr = lane & 31, fh = lane >> 5;
   // V fragment of (group g, filter row ky): the entry of row-tile 32 g + fr one row up / at / one row down, or the zero entry where that row
   // is outside the output row's image; piece fh of plane 0, plane 1 lies at the address with bit 5 flipped
-  uint32_t a_hi[4][3];
+  uint32_t ra[4][3];                                  // LDS addresses (plane 0; plane 1: bit 5 flipped) in the stage being read: toggled to the other stage after every step
   {
     const int y0 = row0 % p.H;
 #pragma unroll
@@ -294,8 +313,8 @@ wino1d_kernel(const Wino1dParams p) {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const bool ok = inside && (ky == 1 || (ky == 0 ? y > 0 : y + 1 < p.H));
-        const int e = ok ? (r + ky) * TPR + tx : G::EZ;
-        a_hi[g][ky] = (uint32_t)(e * 64 + ((fh ^ ((e >> 2) & 3)) << 4));
+        const int e = r1_slot(ok ? (r + ky) * TPR + tx : G::EZ);
+        ra[g][ky] = lds0 + (uint32_t)(ph * 3 * POS + e * 64 + ((fh ^ ((e >> 2) & 3)) << 4));
       }
     }
   }
@@ -308,39 +327,21 @@ wino1d_kernel(const Wino1dParams p) {
   };
   // A step: nine combinations c = (position 3 ph + c / 3, filter row c % 3), each twelve matrix instructions on four V fragments read one
   // combination ahead and a U fragment requested BRING ahead.  One wave per SIMD issues in order: vector work placed behind the matrix
-  // instructions would start when the last of them has been issued.  So the step is written as 108 GAPS -- one matrix instruction, then a
-  // slice of at most five other instructions that fit in the 32 cycles it runs, then a scheduling fence -- and the staging of one row-tile
-  // (41 vector instructions, 6 LDS writes, its 3 - 6 loads), the eight LDS reads of the next combination's V fragments and the two U loads
-  // are dealt over the twelve gaps of a combination by hand (slice()).
-  uint32_t wtab[9];                                   // where my dword of row-tile c goes, relative to its stage
-#pragma unroll
-  for (int c = 0; c < 9; ++c) {
-    const int e = c < 8 ? e_main0 + c : e_halo;
-    wtab[c] = (uint32_t)(e * 64 + ((w_piece ^ ((e >> 2) & 3)) << 4) + w_in);
-  }
+  // instructions would start when the last of them has been issued.  So the step is written as 108 GAPS -- one matrix instruction, then at
+  // most ~five other instructions that fit in the 32 cycles it runs, then a scheduling fence -- and everything else is dealt over them by hand:
+  //   gaps 1, 2, 6, 9 of a combination: two LDS reads each of the NEXT combination's V fragments (plane 0 first: its products come first)
+  //   gap 4: the two U loads
+  //   gaps 0, 3, 5, 7, 8, 10, 11 (and 1, 2, 6, 9 of the last combination): the next staging group -- 4 x 13 for my row-tiles, then 13 for the halo tile.
   auto step = [&](int s, auto last) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last)::value;
-    const int buf = s & 1;
-    const uint32_t sbase = (uint32_t)(buf * STAGE + ph * 3 * POS), wbase = (uint32_t)((buf ^ 1) * STAGE);
-    uint32_t ra[4][3];                                // this step's fragment addresses (plane 0; plane 1: bit 5 flipped)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) ra[g][ky] = a_hi[g][ky] + sbase;
+    const uint32_t wbase = (s & 1) ? 0u : R1_STAGE_STRIDE;         // the stage being written: the one not read
     halfx8 ah[2][4], al[2][4];
-    auto rd_hi = [&](int c, int g) __attribute__((always_inline)) { ah[c & 1][g] = *reinterpret_cast<const halfx8 *>(ldsb + ra[g][c % 3] + (c / 3) * POS); };
-    auto rd_lo = [&](int c, int g) __attribute__((always_inline)) { al[c & 1][g] = *reinterpret_cast<const halfx8 *>(ldsb + (ra[g][c % 3] ^ 32u) + (c / 3) * POS); };
+    auto rd_hi = [&](int c, int g) __attribute__((always_inline)) { ah[c & 1][g] = r1_lds_read16(ra[g][c % 3] + (c / 3) * POS); };
+    auto rd_lo = [&](int c, int g) __attribute__((always_inline)) { al[c & 1][g] = r1_lds_read16((ra[g][c % 3] ^ 32u) + (c / 3) * POS); };
 #pragma unroll
     for (int g = 0; g < 4; ++g) { rd_hi(0, g); rd_lo(0, g); }
-    // the staging state of the row-tile in flight
-    float pe, po, re, ro;
-    f2 v[3];
-    uint32_t xh, xl, give, keep, got;
-    char *Vd = ldsb;
-    constexpr int pos_lo[3] = {0, 1, 3}, pos_hi[3] = {5, 2, 4};
     auto slice = [&](auto cc, auto kk) __attribute__((always_inline)) {
       constexpr int c = decltype(cc)::value, k = decltype(kk)::value;
-      // V fragments of the next combination: plane 0 first (its products come first)
       if (c + 1 < 9) {
         if (k == 1) { rd_hi(c + 1, 0); rd_hi(c + 1, 1); }
         if (k == 2) { rd_hi(c + 1, 2); rd_hi(c + 1, 3); }
@@ -356,50 +357,12 @@ wino1d_kernel(const Wino1dParams p) {
       }
 #ifndef IDIFF_W1D_DIAG_NO_STAGE    // timing-only build: no transform, no stage writes, no input loads after the prologue
       if (!LAST) {
-        constexpr int rl = c < 8 ? c / TPR : 0, tx = c < 8 ? c % TPR : 0;
-        const f2 P0 = c < 8 ? rp[rl][2 * tx] : hp[0], P1 = c < 8 ? rp[rl][2 * tx + 1] : hp[1], P2 = c < 8 ? rp[rl][2 * tx + 2] : hp[2];
-        if (k == 0) {
-          Vd = ldsb + wtab[c] + wbase;
-          pe = fmaf(k_nb2, P1.x, P2.x); po = fmaf(k_nb2, P0.y, P1.y);
-          re = fmaf(k_na2, P1.x, P2.x); ro = fmaf(k_na2, P0.y, P1.y);
-        }
-        if (k == 1) { v[0].x = fmaf(k_nab2, P1.x, P0.x + P2.x); v[0].y = fmaf(k_nab2, P1.y, P0.y + P2.y); }      // positions 0, 5
-        if (k == 2) { v[1].x = fmaf(k_a, po, pe); v[1].y = fmaf(-k_a, po, pe); v[2].x = fmaf(k_b, ro, re); v[2].y = fmaf(-k_b, ro, re); }   // 1, 2 | 3, 4
-        constexpr int q = k >= 3 ? (k - 3) / 3 : 0, ph3 = k >= 3 ? (k - 3) % 3 : -1;          // pair q of the tile: cut (4), trade (3), store (2 + 2)
-        if (ph3 == 0) {
-          xh = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[q], h2));
-          f2 rest;                                                  // v - hi in one mixed-precision instruction per component (exact)
-          asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rest.x) : "v"(xh), "v"(v[q].x));
-          asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest.y) : "v"(xh), "v"(v[q].y));
-          xl = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, h2));
-        }
-        if (ph3 == 1) {
-          give = odd ? xh : xl; keep = odd ? xl : xh;
-          got = (uint32_t)__builtin_amdgcn_update_dpp((int)give, (int)give, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
-        }
-        if (ph3 == 2) {
-#ifdef IDIFF_W1D_DIAG_NO_VWRITE    // timing-only build: the pairs are summed into one register instead of written
-          diag_sink += __builtin_amdgcn_perm(got, keep, sel0) + __builtin_amdgcn_perm(got, keep, sel1);
-#else
-          *reinterpret_cast<uint32_t *>(Vd + pos_lo[q] * POS) = __builtin_amdgcn_perm(got, keep, sel0);
-          *reinterpret_cast<uint32_t *>(Vd + pos_hi[q] * POS) = __builtin_amdgcn_perm(got, keep, sel1);
-#endif
-        }
-        // the pixels nobody reads any more receive the step after next (the transform read them in gaps 0 - 2)
-#ifdef IDIFF_W1D_DIAG_NO_XLOAD     // timing-only build: the input is loaded for the first two steps only
-        if (s + 2 <= 1)
-#endif
-        {
-          if (c < 8) {
-            if (k == 7) fetch_tile_part(c, s + 2, 0);
-            if (k == 10) fetch_tile_part(c, s + 2, 1);
-            if (k == 11) fetch_tile_part(c, s + 2, 2);
-          } else {
-            if (k == 7) fetch_halo_part(s + 2, 0);
-            if (k == 10) fetch_halo_part(s + 2, 1);
-            if (k == 11) fetch_halo_part(s + 2, 2);
-          }
-        }
+        // the staging slot of this gap: 7 per combination, 11 in the last one
+        constexpr int idx7 = k == 0 ? 0 : k == 3 ? 1 : k == 5 ? 2 : k == 7 ? 3 : k == 8 ? 4 : k == 10 ? 5 : k == 11 ? 6 : -1;
+        constexpr int idx11 = k < 4 ? k : (k == 4 ? -1 : k - 1);
+        constexpr int slot = c < 8 ? (idx7 < 0 ? -1 : 7 * c + idx7) : (idx11 < 0 ? -1 : 56 + idx11);
+        if (slot >= 0 && slot < 65)
+          tile_group(std::integral_constant<int, (slot >= 0 && slot < 65 ? slot / 13 : 0)>(), std::integral_constant<int, (slot >= 0 ? slot % 13 : 0)>(), wbase, s + 2);
       }
 #endif
     };
@@ -426,25 +389,31 @@ wino1d_kernel(const Wino1dParams p) {
     combo(std::integral_constant<int, 0>()); combo(std::integral_constant<int, 1>()); combo(std::integral_constant<int, 2>());
     combo(std::integral_constant<int, 3>()); combo(std::integral_constant<int, 4>()); combo(std::integral_constant<int, 5>());
     combo(std::integral_constant<int, 6>()); combo(std::integral_constant<int, 7>()); combo(std::integral_constant<int, 8>());
+#ifndef IDIFF_W1D_DIAG_NO_BARRIER  // timing-only build (a race by construction): what the step barrier and the waves' skew at it cost
     __syncthreads();
+#endif
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) ra[g][ky] ^= R1_STAGE_STRIDE;
   };
 
   // the zero entry of both stages
   if (tid < 192) {
     const int b = tid / 96, rem = tid - 96 * b;
-    *reinterpret_cast<uint32_t *>(ldsb + b * STAGE + (rem >> 4) * POS + G::EZ * 64 + (rem & 15) * 4) = 0u;
+    *reinterpret_cast<uint32_t *>(ldsb + b * R1_STAGE_STRIDE + (rem >> 4) * POS + r1_slot(G::EZ) * 64 + (rem & 15) * 4) = 0u;
   }
 #pragma unroll
   for (int c = 0; c < BRING; ++c) load_b(c, 0);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) fetch_tile(c, 0);
-  fetch_halo(0);
+  for (int g = 0; g < NSEG; ++g) fetch_px(g, 0, NPX - 1, 0);
+  fetch_hp(0, 5, 0);
 #ifdef IDIFF_W1D_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   IDIFF_W1D_T(1)                                     // first operands arrived
-#pragma unroll
-  for (int c = 0; c < 9; ++c) stage_part(0, c, 1);
+  tile_all(std::integral_constant<int, 0>(), 0u, 1); tile_all(std::integral_constant<int, 1>(), 0u, 1); tile_all(std::integral_constant<int, 2>(), 0u, 1);
+  tile_all(std::integral_constant<int, 3>(), 0u, 1); tile_all(std::integral_constant<int, 4>(), 0u, 1);
   __syncthreads();
   IDIFF_W1D_T(2)
   {
