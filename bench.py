@@ -53,7 +53,8 @@ HBM_PEAK_GBS = 8000.0
 # >= 2^-16) run on the bf16 matrix cores with fp32 accumulation -- 1.7e-7 against an fp64 contraction where the fp32 MFMA
 # chain gives 2.0e-7 (scripts/bf16x6_probe.hip); every parity bar of tests/ is unchanged.  IDIFF_NO_SPLIT=1 selects fp32 MFMAs.
 _CONV_ARITH = ("3x3 convs: Winograd F(4x4,3x3), fp32 transforms, fp32 MFMA contraction" if (os.environ.get("IDIFF_NO_WINO43H") or os.environ.get("IDIFF_NO_WINO43"))
-               else "3x3 convs: Winograd F(4x4,3x3), fp32 transforms, contraction on pairs of fp16 values -- 22 significand bits, 3 products, fp32 accumulate")
+               else ("3x3 convs: Winograd, fp32 transforms, contraction on pairs of fp16 values -- 22 significand bits, 3 products, fp32 accumulate"
+                     + (" (F(4x4,3x3))" if os.environ.get("IDIFF_NO_WINO1D") else " (F(4,3) along the rows x 3 filter rows on maps of 16x16 pixels and larger, F(4x4,3x3) below)")))
 _GEMM_ARITH = ("1x1/attention/dense contractions: fp32 MFMA" if os.environ.get("IDIFF_NO_SPLIT")
                else "1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate"
                + ("" if os.environ.get("IDIFF_NO_PAIRS") else "; the q/k/v projections of a GroupNorm's output: pairs of fp16 values, 3 products")
@@ -63,7 +64,8 @@ WORKLOAD = "ncsnpp nf128 ch(1,2,2,2) 4 resblocks attn@16 FIR, 32x32x3, VE-SDE t=
 # PMC traffic tables (separate FETCH_SIZE / WRITE_SIZE passes, scripts/profile_round.sh), each stamped with the sha256 of the kernel
 # source it was measured on: F(4x4,3x3) (the dominant kernel) and F(2x2,3x3)
 _CSRC = os.path.join("id-diff_amd", "csrc")
-TRAFFIC_TABLES = {"winograd43h_kernel": (os.path.join("profiles", "r05_wino43h_traffic.json"),
+TRAFFIC_TABLES = {"wino1d_kernel": (os.path.join("profiles", "r05_wino1d_traffic.json"), (os.path.join(_CSRC, "wino1d.hip"),)),
+                  "winograd43h_kernel": (os.path.join("profiles", "r05_wino43h_traffic.json"),
                                          (os.path.join(_CSRC, "winograd43h.hip"), os.path.join(_CSRC, "winograd43_shared.h"))),
                   "winograd43_kernel": (os.path.join("profiles", "r05_wino43_traffic.json"),
                                         (os.path.join(_CSRC, "winograd43.hip"), os.path.join(_CSRC, "winograd43_shared.h"))),
@@ -131,6 +133,11 @@ class KernelProbe:
             # pairs (winograd43h_kernel) each of them is three fp16 products: counted once, as one fp32-equivalent multiply-add
             return ("winograd43h_kernel" if pairs else "winograd43_kernel"), 2.0 * 36 * (B * H * W // 16) * Cin * Cout, f"{B}x{H}x{W}x{Cin}->{Cout}"
 
+        def wino1d(x, u, out, B, H, W, Cin, Cout, epilogue=None):
+            # executed flops of the row-wise F(4,3): 6 positions x 3 filter rows of [row-tiles x Cin] x [Cin x Cout]; on fp16 pairs each multiply-add
+            # is three fp16 products: counted once, as one fp32-equivalent multiply-add.  The implicit GEMM would be 2x that.
+            return "wino1d_kernel", 2.0 * 18 * (B * H * W // 4) * Cin * Cout, f"{B}x{H}x{W}x{Cin}->{Cout}"
+
         def gn_apply(x, C, x2, C2, B, HW, G, stats, gamma, beta, act, y, mod=None):
             return "gn_apply_rows", 8.0 * B * HW * (C + (C2 or 0)), f"{B}x{HW}x{C + (C2 or 0)}"
 
@@ -177,7 +184,7 @@ class KernelProbe:
         def softmax(x, y, rows, cols, scale):
             return "softmax_rows", 8.0 * rows * cols, f"{rows}x{cols}"
 
-        for name, fn in (("conv2d_winograd", wino), ("conv2d_winograd43", wino43), ("groupnorm_apply", gn_apply), ("groupnorm_apply_colstats", gn_apply_cs),
+        for name, fn in (("conv2d_winograd", wino), ("conv2d_winograd43", wino43), ("conv2d_wino1d", wino1d), ("groupnorm_apply", gn_apply), ("groupnorm_apply_colstats", gn_apply_cs),
                          ("gemm", gemm), ("gemm_2src", gemm_2src), ("gemm_pairs", gemm_pairs), ("gemm_pairs_2src", gemm_pairs_2src),
                          ("upfirdn2d_raw", ufd), ("softmax_rows", softmax), ("attention256", attn)):
             self._wrap(name, fn)
@@ -231,15 +238,38 @@ def winograd43h_l2_bytes(keys):
     return tot / len(keys)
 
 
+def wino1d_l2_bytes(keys):
+    """Bytes wino1d_kernel pulls from L2 per launch, by construction: per workgroup (512 pixels x 64 output channels) and K step (16
+    channels) the filter slab 18 x 64 x 16 x 4 B (fp16 pairs) and the block's image rows plus one halo row where the block is part of an image."""
+    tot = 0.0
+    for k in keys:
+        B, H, W, rest = k.split("x")
+        Cin, Cout = rest.split("->")
+        B, H, W, Cin, Cout = map(int, (B, H, W, Cin, Cout))
+        rb = 512 // W
+        wgs = ((B * H + rb - 1) // rb) * (Cout // 64)
+        rows = rb + (1 if H > rb else 0)
+        tot += wgs * (Cin // 16) * (18 * 64 * 16 * 4 + rows * W * 16 * 4)
+    return tot / len(keys)
+
+
 def roofline_report(probe):
+    dom1d = probe.group("wino1d_kernel")
     dom43h, dom43, dom22 = probe.group("winograd43h_kernel"), probe.group("winograd43_kernel"), probe.group("winograd_kernel")
-    dom = dom43h or dom43 or dom22
+    dom = dom1d or dom43h or dom43 or dom22
     if dom is None:
         return None
     tfl = dom["rate"] / 1e12
-    dom_name = "winograd43h_kernel" if dom43h is not None else ("winograd43_kernel" if dom43 is not None else "winograd_kernel")
+    dom_name = ("wino1d_kernel" if dom1d is not None else
+                "winograd43h_kernel" if dom43h is not None else ("winograd43_kernel" if dom43 is not None else "winograd_kernel"))
     traffic = winograd_traffic(dom["keys"], dom_name)
     kernels = []
+    if dom1d is not None and dom43h is not None:
+        t = dom43h["rate"] / 1e12
+        kernels.append({"kernel": "winograd43h_kernel (F(4x4,3x3) on fp16 pairs: the GroupNorm-fed 3x3 convs of the 8x8 and 4x4 maps) [3 fp16 products per "
+                                  "fp32 multiply-add]", "bound": "mfma", "achieved": t, "peak": F16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s (fp32-equivalent)",
+                        "frac": t / (F16_MFMA_PEAK_TFLOPS / 3.0), "launches_sampled": dom43h["launches"], "avg_launch_us": dom43h["avg_us"]})
+        dom43h = None
     if dom43h is not None and dom43 is not None:
         t43 = dom43["rate"] / 1e12
         kernels.append({"kernel": "winograd43_kernel (F(4x4,3x3), fp32 contraction: inputs not fed by a GroupNorm, Cin % 16 != 0)", "bound": "mfma",
@@ -289,7 +319,18 @@ def roofline_report(probe):
             kernels.append({"kernel": name, "bound": "hbm", "achieved": g["rate"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": g["rate"] / 1e9 / HBM_PEAK_GBS, "launches_sampled": g["launches"], "avg_launch_us": g["avg_us"]})
     peak, extra = FP32_MFMA_PEAK_TFLOPS, {}
-    if dom43h is not None:
+    if dom1d is not None:
+        name = ("wino1d_kernel (3x3 conv as F(4,3) along the rows, the three filter rows a direct sum: 18 [row-tiles x Cin] x [Cin x Cout] contractions "
+                "per launch on v_mfma_f32_32x32x16_f16, each fp32 operand a pair of fp16 values, 3 fp16 products per fp32 multiply-add)")
+        counted, ratio = ("executed Winograd-domain multiply-adds, each counted ONCE (fp32-equivalent; the matrix cores execute three fp16 products for "
+                          "it, so the peak is the dense fp16 peak / 3; 4.5 per output pixel and channel pair -- F(4x4,3x3) would execute 2.25, the implicit "
+                          "GEMM 9)"), 2.0
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0
+        l2 = wino1d_l2_bytes(dom["keys"]) / (dom["avg_us"] * 1e-6) / 1e9
+        extra = {"l2_read": {"achieved": l2, "peak": L2_READ_PEAK_GBS, "unit": "GB/s", "frac": l2 / L2_READ_PEAK_GBS,
+                             "bytes": "per workgroup (512 pixels x 64 channels) and 16-channel step: 73,728 B of filter pairs + 34,816 - 36,864 B of input "
+                                      "rows (every pixel once, one halo row), by construction"}}
+    elif dom43h is not None:
         name = ("winograd43h_kernel (3x3 conv as F(4x4,3x3): 36 [tiles x Cin] x [Cin x Cout] contractions per launch on "
                 "v_mfma_f32_32x32x16_f16, each fp32 operand a pair of fp16 values, 3 fp16 products per fp32 multiply-add)")
         counted, ratio = ("executed Winograd-domain multiply-adds, each counted ONCE (fp32-equivalent; the matrix cores execute three fp16 "

@@ -101,6 +101,7 @@ template <int W> struct R1Geo {
   static_assert(NR * TPR == 8, "a loader thread owns eight row-tiles");
   static_assert(STAGE_BYTES <= R1_STAGE_STRIDE, "a stage inside its half of the LDS allocation");
   static_assert(5 * POS_BYTES < 65536, "positions are reached by the LDS instructions' immediate offset");
+  static_assert(POS_BYTES % 256 == 0, "two positions of one entry: one ds_write2st64_b32");
 };
 
 struct Wino1dParams {
@@ -235,7 +236,7 @@ wino1d_kernel(const Wino1dParams p) {
   //   5 - 10  position grp - 5: the two channels' values -> one dword of hi parts, one of lo parts (v - hi in one mixed-precision fma each), stored
   //   11, 12  the pixels no later tile reads are requested for K step `next`
   float t_pe[2], t_po[2], t_re[2], t_ro[2], t_s04[2], t_s15[2], tv[2][6];
-  uint32_t w_hi = 0, w_lo = 0;
+  uint32_t w_hi = 0, w_lo = 0, p_hi = 0, p_lo = 0;
   auto tile_group = [&](auto ii, auto gg, uint32_t wbase, int next) __attribute__((always_inline)) {
     constexpr int i = decltype(ii)::value, grp = decltype(gg)::value;
     constexpr int sg = i < 4 ? i / TS : 0, t = i < 4 ? i % TS : 0;
@@ -253,6 +254,8 @@ wino1d_kernel(const Wino1dParams p) {
     if (grp == 3) { head(1, 1); head(1, 2); }
     if (grp == 4) { head(1, 3); head(1, 4); }
     if (grp >= 5 && grp <= 10) {
+      // positions in pairs (0, 1), (2, 3), (4, 5): the first group of a pair cuts its position, the second cuts the other and stores both -- two
+      // dwords of one plane at one base and a distance that is a multiple of 256 bytes go out as ONE ds_write2st64_b32
       constexpr int pos = grp >= 5 && grp <= 10 ? grp - 5 : 0;
       const f2 vv = {tv[0][pos], tv[1][pos]};
       const uint32_t xh = __builtin_bit_cast(uint32_t, __builtin_convertvector(vv, h2));
@@ -260,12 +263,15 @@ wino1d_kernel(const Wino1dParams p) {
       asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rest.x) : "v"(xh), "v"(vv.x));
       asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rest.y) : "v"(xh), "v"(vv.y));
       const uint32_t xl = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, h2));
+      if ((pos & 1) == 0) { p_hi = xh; p_lo = xl; }
+      else {
 #ifdef IDIFF_W1D_DIAG_NO_VWRITE    // timing-only build: the pairs are summed into one register instead of written
-      diag_sink += xh + xl;
+        diag_sink += xh + xl + p_hi + p_lo;
 #else
-      r1_lds_write4(w_hi + pos * POS, xh);
-      r1_lds_write4(w_lo + pos * POS, xl);
+        r1_lds_write4(w_hi + (pos - 1) * POS, p_hi); r1_lds_write4(w_hi + pos * POS, xh);
+        r1_lds_write4(w_lo + (pos - 1) * POS, p_lo); r1_lds_write4(w_lo + pos * POS, xl);
 #endif
+      }
     }
 #ifdef IDIFF_W1D_DIAG_NO_XLOAD     // timing-only build: the input is loaded for the first two steps only
     if (next <= 1)

@@ -187,6 +187,20 @@ def _winograd43_pays(B, H, W, cin, cout, normed=False):
     return ((B * (H // 4) * (W // 4) + 31) // 32) * (cout // 64) >= WINO43_MIN_WORKGROUPS
 
 
+# launches of fewer workgroups than this, and maps narrower than this, stay on the 2-D pair kernel (tests set the first to 1)
+WINO1D_MIN_WORKGROUPS = 256
+WINO1D_MIN_WIDTH = 16
+
+
+def _wino1d_pays(B, H, W, cin, cout):
+    """The row-wise F(4, 3) pair kernel (csrc/wino1d.hip: twice the matrix work of F(4x4, 3x3) for half the operand traffic) where it is served
+    and measured faster than the 2-D pair kernel: maps of 16 x 16 pixels and larger at one workgroup (512 pixels x 64 channels) per CU and more --
+    1.04-1.19x there, 1.00-1.02x on 8 x 8 maps (profiles/r05_wino1d_probe.txt, B = 2240)."""
+    if W < WINO1D_MIN_WIDTH or not _lib.conv2d_wino1d_ok(B, H, W, cin, cout):
+        return False
+    return ((B * H * W + 511) // 512) * (cout // 64) >= WINO1D_MIN_WORKGROUPS
+
+
 @utils.register_model(name='ncsnpp')
 class NCSNpp(HipScoreModel):
     def __init__(self, config):
@@ -407,6 +421,19 @@ class NCSNpp(HipScoreModel):
         y = self._new(B, OH, OW, cout, x.buf)
         if "rows_per_group" not in ep:
             ep["rows_per_group"] = OH * OW
+        if (kh, kw, stride, pad, ph) == (3, 3, 1, 1, 1) and ep["rows_per_group"] == OH * OW and normed and _wino1d_pays(B, x.H, x.W, cin, cout):
+            # Winograd F(4, 3) along the rows on fp16 pairs: 4.5 multiplications per output, half the operand traffic of the 2-D form
+            bank = self._packed.setdefault("wino1d", {})
+            key = id(wt)
+            if key not in bank:
+                bank[key] = (wt, _lib.wino1d_pack(wt, cin, cout))
+            if stats:
+                ns = _lib.conv2d_wino1d_colstats_split(B, x.H, x.W, cin, cout)
+                if ns > 0:
+                    y.stats = (torch.empty(B * ns * cout * 2, device=x.buf.device, dtype=torch.float64), ns)
+                    ep["colstats"] = y.stats[0]
+            _lib.conv2d_wino1d(x.buf, bank[key][1], y.buf, B, x.H, x.W, cin, cout, epilogue=_lib.make_epilogue(bias=bias, **ep))
+            return y
         if (kh, kw, stride, pad, ph) == (3, 3, 1, 1, 1) and ep["rows_per_group"] == OH * OW and _winograd43_pays(B, x.H, x.W, cin, cout, normed):
             # Winograd F(4x4, 3x3): 2.25 multiplications per output (F(2x2, 3x3) below: 4, the implicit GEMM: 9)
             bank = self._packed.setdefault("wino43", {})

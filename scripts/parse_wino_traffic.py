@@ -1,13 +1,14 @@
-"""parse_wino_traffic.py <log of wino_shapes.py> <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [43 | 43h]
+"""parse_wino_traffic.py <log of wino_shapes.py> <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [43 | 43h | 1d]
 (43: the F(4x4,3x3) kernel, winograd43_kernel / winograd43.hip, 36 transformed positions; 43h: its fp16-pair form, winograd43h_kernel /
-winograd43h.hip; default the F(2x2,3x3) kernel)
+winograd43h.hip; 1d: the row-wise F(4,3) pair kernel, wino1d_kernel / wino1d.hip, 18 transformed slots; default the F(2x2,3x3) kernel)
 HBM bytes per launch = FETCH_SIZE * 1024 * 2 (gfx950 counts half of a wide coalesced read, MI355X_MICROARCH.md section
 HBM) + WRITE_SIZE * 1024; the second isolated launch of each shape is taken."""
 import csv, glob, hashlib, json, os, sys
 log, fdir, wdir, out = sys.argv[1:5]
 MODE = sys.argv[5] if len(sys.argv) > 5 else ""
 KERNEL, NPOS, SRC = {"43": ("winograd43_kernel", 36, ["winograd43.hip", "winograd43_shared.h"]),
-                     "43h": ("winograd43h_kernel", 36, ["winograd43h.hip", "winograd43_shared.h"])}.get(MODE, ("winograd_kernel", 16, ["winograd.hip"]))
+                     "43h": ("winograd43h_kernel", 36, ["winograd43h.hip", "winograd43_shared.h"]),
+                     "1d": ("wino1d_kernel", 18, ["wino1d.hip"])}.get(MODE, ("winograd_kernel", 16, ["winograd.hip"]))
 keys = [(l.split()[1], int(l.split()[2])) for l in open(log) if l.startswith("KEY")]
 
 def counters(d, name):

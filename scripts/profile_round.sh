@@ -29,23 +29,29 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 python3 $R/scripts/parse_wino_traffic.py $O/shapes43h_fetch.log $O/fetch43h $O/write43h $O/${TAG}_wino43h_traffic.json 43h > $O/traffic43h_summary.txt 2>&1 || echo "traffic43h parse failed"
 cat $O/traffic43h_summary.txt
 [ -s $O/${TAG}_wino43h_traffic.json ] && cp $O/${TAG}_wino43h_traffic.json $R/profiles/${TAG}_wino43h_traffic.json
+echo "[1d] traffic passes, row-wise F(4,3) kernel on fp16 pairs"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch1d -- python3 $R/scripts/wino_shapes.py 2240 1d > $O/shapes1d_fetch.log 2>&1 || echo "fetch1d pass failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write1d -- python3 $R/scripts/wino_shapes.py 2240 1d > $O/shapes1d_write.log 2>&1 || echo "write1d pass failed"
+python3 $R/scripts/parse_wino_traffic.py $O/shapes1d_fetch.log $O/fetch1d $O/write1d $O/${TAG}_wino1d_traffic.json 1d > $O/traffic1d_summary.txt 2>&1 || echo "traffic1d parse failed"
+cat $O/traffic1d_summary.txt
+[ -s $O/${TAG}_wino1d_traffic.json ] && cp $O/${TAG}_wino1d_traffic.json $R/profiles/${TAG}_wino1d_traffic.json
 echo "[2] PMC of the dominant kernel (16x16 256->256)"
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" "TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum TCP_TCC_READ_REQ_sum"; do
   n=$(echo $set | cut -d' ' -f1)
-  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$n -- python3 $R/scripts/wino_one.py 16 256 256 2240 f43h > $O/pmc_$n.log 2>&1 || echo "pmc pass $n failed"
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$n -- python3 $R/scripts/wino_one.py 16 256 256 2240 w1d > $O/pmc_$n.log 2>&1 || echo "pmc pass $n failed"
 done
 python3 - <<PY > $O/${TAG}_pmc_winograd.txt
 import csv, glob, collections
-print("winograd43h_kernel (F(4x4,3x3) on fp16 pairs), conv [2240,16,16,256]->256, per launch (rocprofv3 --pmc, one pass per counter set):")
+print("wino1d_kernel (F(4,3) along the rows on fp16 pairs), conv [2240,16,16,256]->256, per launch (rocprofv3 --pmc, one pass per counter set):")
 for f in sorted(glob.glob("$O/pmc_*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "winograd43h_kernel" in r["Kernel_Name"]:
+        if "wino1d_kernel" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         print(f"  {k:32s} {sum(v)/max(1,len(v)):.4g}")
 for f in sorted(glob.glob("$O/pmc_SQ_VALU*/**/*kernel_trace.csv", recursive=True)):
-    d = [(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(f)) if 'winograd43h_kernel' in r['Kernel_Name']]
+    d = [(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(f)) if 'wino1d_kernel' in r['Kernel_Name']]
     print("  kernel duration us (that pass):", [round(x) for x in d])
 PY
 cat $O/${TAG}_pmc_winograd.txt

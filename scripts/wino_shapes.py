@@ -16,9 +16,10 @@ sde, eps = sde_lib.configure_sde(cfg)
 score_fn = mutils.get_score_fn(sde, model)
 # second argument: which kernel's calls to tabulate -- "43" = winograd43_kernel (F(4x4,3x3), fp32 contraction), "43h" = winograd43h_kernel
 # (the same on fp16 pairs), default winograd_kernel (F(2x2,3x3))
+# "1d" = wino1d_kernel (F(4,3) along the rows on fp16 pairs)
 MODE = sys.argv[2] if len(sys.argv) > 2 else ""
-F43, PAIRS = MODE in ("43", "43h"), MODE == "43h"
-OP, PACK = ("conv2d_winograd43", _lib.winograd43_pack) if F43 else ("conv2d_winograd", _lib.winograd_pack)
+F43, PAIRS, ROWWISE = MODE in ("43", "43h"), MODE == "43h", MODE == "1d"
+OP, PACK = ("conv2d_wino1d", _lib.wino1d_pack) if ROWWISE else (("conv2d_winograd43", _lib.winograd43_pack) if F43 else ("conv2d_winograd", _lib.winograd_pack))
 calls = []
 orig = getattr(_lib, OP)
 

@@ -433,6 +433,53 @@ def test_wide_ncsnpp_golden_through_winograd43(golden, wino43_everywhere):
     assert rel_err(raw32.cpu(), z["model_out"]) < NET_RTOL
 
 
+@pytest.fixture
+def wino1d_everywhere(monkeypatch, wino43_everywhere):
+    """... and the GroupNorm-fed 3x3 convolutions of 8 x 8 maps and larger through the row-wise F(4, 3) pair kernel, at test batch sizes."""
+    from id_diff_amd.models import ncsnpp as hip_ncsnpp
+    monkeypatch.setattr(hip_ncsnpp, "WINO1D_MIN_WORKGROUPS", 1)
+    monkeypatch.setattr(hip_ncsnpp, "WINO1D_MIN_WIDTH", 8)
+    calls = {"n": 0}
+    orig = _lib.conv2d_wino1d
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(_lib, "conv2d_wino1d", counted)
+    return calls
+
+
+def test_wide_networks_golden_through_wino1d(golden, wino1d_everywhere):
+    """The nf = 128 NCSN++ and the BeatGANs U-Net against the REFERENCE's outputs with the GroupNorm-fed 3x3 convolutions on the row-wise F(4, 3)
+    pair kernel (the form the benchmark runs on its 16 x 16 and 32 x 32 levels): NET_RTOL, as every other route; IDIFF_NO_WINO1D puts the same
+    layers back on the 2-D pair kernel."""
+    z = golden("ncsnpp_wide.npz")
+    model = mutils.create_model(ncsnpp_config(**overrides_from_golden(z)))
+    fill_from_seed(model, int(z["seed"]))
+    model.to(DEV)
+    model._invalidate()
+    x, t = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["t"]).to(DEV)
+    raw = model(x, t * 999)
+    assert wino1d_everywhere["n"] >= 8, wino1d_everywhere
+    assert rel_err(raw.cpu(), z["model_out"]) < NET_RTOL
+    n1 = wino1d_everywhere["n"]
+    model._invalidate()
+    with _lib.thread_option("IDIFF_NO_WINO1D", 1):
+        raw2 = model(x, t * 999)
+    assert wino1d_everywhere["n"] == n1                                  # the switch took them off the row-wise kernel
+    assert rel_err(raw2.cpu(), z["model_out"]) < NET_RTOL
+    assert rel_err(raw.cpu(), raw2.cpu()) < 1e-5 and not torch.equal(raw, raw2)     # two different kernels, the same function
+    zb = golden("beatgans_wide.npz")
+    mb = mutils.create_model(beatgans_config(**overrides_from_golden(zb)))
+    fill_from_seed(mb, int(zb["seed"]))
+    mb.to(DEV)
+    mb._invalidate()
+    before = wino1d_everywhere["n"]
+    out = mb(torch.from_numpy(zb["x"]).to(DEV), torch.from_numpy(zb["t"]).to(DEV) * 999)
+    assert wino1d_everywhere["n"] - before >= 4, wino1d_everywhere
+    assert rel_err(out.cpu(), zb["model_out"]) < NET_RTOL
+
+
 def _scaled_gamma_pair(z, factor, which="GroupNorm_1.weight"):
     """(oracle model, HIP model on the GPU, name) of the nf = 128 golden configuration with ONE GroupNorm's gamma multiplied by `factor`."""
     cfg = ncsnpp_config(**overrides_from_golden(z))

@@ -116,7 +116,7 @@ class _RouteCounter:
     NAMES = ("conv2d_winograd43", "conv2d_winograd", "conv2d_nhwc", "gemm_pairs", "gemm", "gemm_2src", "attention256", "softmax_rows")
 
     def __init__(self):
-        self.n = {"wino43_pairs": 0, "wino43_fp32": 0, "wino22": 0, "igemm_conv": 0, "gemm_pairs": 0, "gemm": 0, "gemm_2src": 0,
+        self.n = {"wino1d": 0, "wino43_pairs": 0, "wino43_fp32": 0, "wino22": 0, "igemm_conv": 0, "gemm_pairs": 0, "gemm": 0, "gemm_2src": 0,
                   "attention256": 0, "softmax_rows": 0}
         self._orig = {}
 
@@ -129,6 +129,7 @@ class _RouteCounter:
                 self.n[key(*a, **k)] += 1
                 return orig(*a, **k)
             setattr(_lib, name, counted)
+        wrap("conv2d_wino1d", lambda *a, **k: "wino1d")
         wrap("conv2d_winograd43", lambda *a, pairs=False, **k: "wino43_pairs" if pairs else "wino43_fp32")
         wrap("conv2d_winograd", lambda *a, **k: "wino22")
         wrap("conv2d_nhwc", lambda *a, **k: "igemm_conv")
@@ -150,8 +151,8 @@ def test_config3_full_size_production_routing_vs_oracle(golden, point):
     """(Two of the bench's points: their IDs differ -- 3070 and 3069 -- because the images differ.)
     The configuration the headline number is quoted on, at FULL size, through the routing the drivers use by default, against the
     CPU oracle on identical draws.  One point of bench.py's workload (nf = 128 NCSN++, init_scale = 1, seed-0
-    weights, bench image 1, the bench's point seed): S 4480 x 3072 in two 2240-row launch sets, 3x3 convs on the fp16-pair F(4x4,3x3)
-    kernel, q / k / v projections on pair GEMMs -- the launch counters are asserted so the routing cannot change silently.
+    weights, bench image 1, the bench's point seed): S 4480 x 3072 in two 2240-row launch sets, 3x3 convs on the fp16-pair kernels (row-wise F(4,3)
+    from 16 x 16 maps on, F(4x4,3x3) below), q / k / v projections on pair GEMMs -- the launch counters are asserted so the routing cannot change silently.
 
     The oracle side was computed once in the build container (tests/golden/make_cfg3_point.py: the oracle network on the draws of
     oracle/philox.py, 883 s on 8 cores) and is a fixture: 192 rows of its S over both launch sets, the fp32 gesdd spectrum exactly as
@@ -192,7 +193,9 @@ def test_config3_full_size_production_routing_vs_oracle(golden, point):
     # the 16-token middle block's q|k on pair GEMMs -- its V^T has N = 16 tokens, below the pair form's N > 64, and stays on six
     # products; the five 256-token blocks' QK^T -> softmax -> PV in ONE launch each, the middle block's in three); no conv on the fp32
     # F(4x4) or the F(2x2) kernel; the stem, the three stride-2 convs and the 128 -> 3 head on the implicit-GEMM entry point
-    assert routes.n["wino43_pairs"] == 2 * 88 and routes.n["wino43_fp32"] == 0 and routes.n["wino22"] == 0, routes.n
+    # (of the 88, the 42 on maps of 16 x 16 and 32 x 32 pixels on the row-wise F(4, 3) kernel, the 46 on 8 x 8 and 4 x 4 maps on F(4x4, 3x3))
+    assert routes.n["wino1d"] + routes.n["wino43_pairs"] == 2 * 88 and routes.n["wino43_fp32"] == 0 and routes.n["wino22"] == 0, routes.n
+    assert routes.n["wino1d"] == 2 * 42, routes.n
     assert routes.n["gemm_pairs"] == 2 * (5 * 3 + 1), routes.n
     assert routes.n["attention256"] == 2 * 5 and routes.n["softmax_rows"] == 2 * 1, routes.n
     assert routes.n["igemm_conv"] == 2 * 5, routes.n
@@ -514,7 +517,7 @@ def test_bench_main_two_ranks_real_workload_one_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak" and line["config"]["process_group"] == "gloo"
     assert line["value"] == pytest.approx(2 * 4480 / (line["ms_per_step"] * 1e-3), rel=1e-6)
     assert len(line["id_estimates_all_ranks"]) == 2 and line["id_estimates_all_ranks"][0] == line["id_estimates"][0]
-    assert line["roofline"] is not None and line["roofline"]["kernel"].startswith("winograd43h_kernel")
+    assert line["roofline"] is not None and line["roofline"]["kernel"].startswith("wino1d_kernel")
     # fp32-equivalent multiply-adds against the fp16 peak / 3; the kernel's own limiter is L2 read bandwidth
     assert 0.1 < line["roofline"]["frac"] < 1.0 and 0.4 < line["roofline"]["l2_read"]["frac"] < 1.2 and line["svd_wall_clock_ms_per_point"] > 0
 
