@@ -192,6 +192,9 @@ wino1d_kernel(const Wino1dParams p) {
     h_c0 = tx > 0; h_c5 = tx + 1 < TPR;
     e_halo = part ? (top ? tx : (RB + 1) * TPR + tx) : G::EZ;      // threads without a halo tile transform zeros into the zero entry
   }
+  // does any lane of this wave hold a halo tile that is inside the image?  (W = 32: wave 0 the row above, wave 1 the row below; else wave 0 both)
+  const bool halo_wave = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_ballot_w64(v_halo != R1_INVALID)) != 0
+                         || __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(v_halo != R1_INVALID) >> 32)) != 0;
   const int e_main0 = TPR + 4 * lk;                                // my four row-tiles' entries: consecutive
   f2 px[NSEG][NPX];                                                // (channel 2 lm, channel 2 lm + 1) per pixel
   f2 hp[6];
@@ -367,8 +370,11 @@ wino1d_kernel(const Wino1dParams p) {
         constexpr int idx7 = k == 0 ? 0 : k == 3 ? 1 : k == 5 ? 2 : k == 7 ? 3 : k == 8 ? 4 : k == 10 ? 5 : k == 11 ? 6 : -1;
         constexpr int idx11 = k < 4 ? k : (k == 4 ? -1 : k - 1);
         constexpr int slot = c < 8 ? (idx7 < 0 ? -1 : 7 * c + idx7) : (idx11 < 0 ? -1 : 56 + idx11);
-        if (slot >= 0 && slot < 65)
-          tile_group(std::integral_constant<int, (slot >= 0 && slot < 65 ? slot / 13 : 0)>(), std::integral_constant<int, (slot >= 0 ? slot % 13 : 0)>(), wbase, s + 2);
+        if (slot >= 0 && slot < 52)
+          tile_group(std::integral_constant<int, (slot >= 0 && slot < 52 ? slot / 13 : 0)>(), std::integral_constant<int, (slot >= 0 ? slot % 13 : 0)>(), wbase, s + 2);
+        // the halo tile: only in the waves that hold one (a wave-uniform branch; the others' gaps stay empty)
+        if (slot >= 52 && slot < 65 && halo_wave)
+          tile_group(std::integral_constant<int, 4>(), std::integral_constant<int, (slot >= 52 ? slot - 52 : 0)>(), wbase, s + 2);
       }
 #endif
     };
@@ -419,7 +425,8 @@ wino1d_kernel(const Wino1dParams p) {
 #endif
   IDIFF_W1D_T(1)                                     // first operands arrived
   tile_all(std::integral_constant<int, 0>(), 0u, 1); tile_all(std::integral_constant<int, 1>(), 0u, 1); tile_all(std::integral_constant<int, 2>(), 0u, 1);
-  tile_all(std::integral_constant<int, 3>(), 0u, 1); tile_all(std::integral_constant<int, 4>(), 0u, 1);
+  tile_all(std::integral_constant<int, 3>(), 0u, 1);
+  if (halo_wave) tile_all(std::integral_constant<int, 4>(), 0u, 1);
   __syncthreads();
   IDIFF_W1D_T(2)
   {
