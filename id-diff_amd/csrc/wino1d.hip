@@ -110,7 +110,6 @@ struct Wino1dParams {
   float *out;
   int B, H, W, Cin, Cout;
   int rows_total, blocks_m, tiles_n, ngroup;
-  int stagger;                                     // first-round workgroups wait ((blockIdx / 8) % 4) * stagger x 8128 cycles before they start (0: off)
   uint32_t x_bytes, u_bytes, out_bytes, res_bytes;
   idiff_epilogue ep;
   int has_ep;
@@ -132,13 +131,6 @@ wino1d_kernel(const Wino1dParams p) {
 #else
 #define IDIFF_W1D_T(k)
 #endif
-  // Every CU runs its workgroups back to back and all workgroups take the same time: without this the whole chip requests its first operands,
-  // runs its K loops and stores its outputs in step -- 32 MB of stores at once, then none for 50 us.  The FIRST workgroup of each CU starts a
-  // quarter, a half or three quarters of a workgroup's life late (by CU), and the offset stays for the whole launch.
-  if (p.stagger > 0 && blockIdx.x < 256) {
-    const int turns = (int)((blockIdx.x >> 3) & 3) * p.stagger;
-    for (int i = 0; i < turns; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   IDIFF_W1D_T(0)
   char *const ldsb = reinterpret_cast<char *>(lds);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(r1_lds_char *)ldsb;   // the allocation's LDS address
@@ -726,7 +718,6 @@ IDIFF_API int idiff_conv2d_wino1d_f32(const float *x, const float *u, float *out
     p.has_ep = 0; p.ep.rows_per_group = 1; p.ep.out_scale = 1.f;
   }
   p.c_nb2 = -R1_b2; p.c_na2 = -R1_a2; p.c_nab2 = -R1_ab2; p.c_a = R1_a; p.c_b = R1_b;
-  { const char *e = getenv("IDIFF_W1D_STAGGER"); p.stagger = e ? atoi(e) : 0; }     // EXPERIMENT (scripts/wino1d_probe.py): read per launch
 #ifdef IDIFF_W1D_STAMP
   { const char *e = getenv("IDIFF_W1D_STAMP_PTR"); p.stamps = e ? reinterpret_cast<uint64_t *>(strtoull(e, nullptr, 0)) : nullptr; }
 #endif
