@@ -216,13 +216,7 @@ gn_apply_rows_kernel(const float *__restrict__ x, int C, const float *__restrict
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-#if defined(IDIFF_GN_NT_LOAD)      // A/B builds (scripts/gn_nt_ab.py)
-      { typedef float fx4 __attribute__((ext_vector_type(4)));
-        const fx4 q = __builtin_nontemporal_load(reinterpret_cast<const fx4 *>(&src[(int64_t)(p + u * RP) * src_stride]));
-        v[u] = make_float4(q.x, q.y, q.z, q.w); }
-#else
       v[u] = src[(int64_t)(p + u * RP) * src_stride];
-#endif
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -231,12 +225,7 @@ gn_apply_rows_kernel(const float *__restrict__ x, int C, const float *__restrict
       o.y = act_apply((v[u].y - mu[1]) * s[1] + t[1], act);
       o.z = act_apply((v[u].z - mu[2]) * s[2] + t[2], act);
       o.w = act_apply((v[u].w - mu[3]) * s[3] + t[3], act);
-#if defined(IDIFF_GN_NT_STORE)
-      { typedef float fx4 __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(fx4{o.x, o.y, o.z, o.w}, reinterpret_cast<fx4 *>(&dst[(int64_t)(p + u * RP) * CVt])); }
-#else
       dst[(int64_t)(p + u * RP) * CVt] = o;
-#endif
     }
   }
   for (; p < p_hi; p += RP) {
