@@ -123,7 +123,7 @@ template <int W>
 __global__ void __launch_bounds__(R1_THREADS)
 wino1d_kernel(const Wino1dParams p) {
   using G = R1Geo<W>;
-  constexpr int TPR = G::TPR, RB = G::RB, NR = G::NR, POS = G::POS_BYTES, BRING = R1_BRING;
+  constexpr int TPR = G::TPR, RB = G::RB, POS = G::POS_BYTES, BRING = R1_BRING;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef IDIFF_W1D_STAMP
   uint64_t st[8];
@@ -432,33 +432,27 @@ wino1d_kernel(const Wino1dParams p) {
 #endif
 
   // ---------------------------------------------------------------- tail
+  // Two rounds, groups {0, 1} then {2, 3} (64 row-tiles each).  A wave PARKS its three positions' accumulators as they stand --
+  // zr[row-tile][position][cout], 98,304 B -- and after a barrier thread (4 channels, 4 row-tiles = 16 consecutive pixels) reads the six
+  // positions of a row-tile (six 16-byte reads), forms A^T m, applies the epilogue and stores 16 bytes per pixel.  (The first form had each
+  // wave mix its positions into four partial outputs, park half and read - add - write the other half on top of the partner's: a third more
+  // LDS writes, at 64 B per clock, and 128 dependent LDS round trips per lane: 5.7 us per workgroup against ...)
   const float descale = p.u[(int64_t)R1_NSLOT * p.Cin * p.Cout];
   const idiff_epilogue &ep = p.ep;
   const bool has_ep = p.has_ep != 0;
-  // z[row-tile][a][cout]: accumulator register `reg` of lane l is row-tile (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) of its group, cout wh * 32 + (l & 31)
-  float *zbase = lds + (size_t)(4 * (lane >> 5)) * 4 * R1_COUT + wh * 32 + (lane & 31);
-  auto mix = [&](auto grp, auto park) __attribute__((always_inline)) {
+  // accumulator register `reg` of lane l is row-tile (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) of its group, cout wh * 32 + (l & 31)
+  float *zbase = lds + (size_t)(4 * (lane >> 5)) * 6 * R1_COUT + (size_t)(3 * ph) * R1_COUT + wh * 32 + (lane & 31);
+  auto park = [&](auto grp) __attribute__((always_inline)) {
     constexpr int GI = decltype(grp)::value;
-    constexpr bool PARK = decltype(park)::value;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const float ma = acc[GI][0][reg], mb = acc[GI][1][reg], mc = acc[GI][2][reg];
-      float y0, y1, y2, y3;
-      if (ph == 0) {                                   // positions 0, 1, 2
-        const float s = mb + mc, d = mb - mc;
-        y0 = ma + s; y1 = R1_a * d; y2 = R1_a2 * s; y3 = R1_a3 * d;
-      } else {                                         // positions 3, 4, 5
-        const float s = ma + mb, d = ma - mb;
-        y0 = s; y1 = R1_b * d; y2 = R1_b2 * s; y3 = fmaf(R1_b3, d, mc);
-      }
-      float *zp = zbase + (size_t)(32 * GI + (reg & 3) + 8 * (reg >> 2)) * 4 * R1_COUT;
-      if (PARK) { zp[0] = y0; zp[R1_COUT] = y1; zp[2 * R1_COUT] = y2; zp[3 * R1_COUT] = y3; }
-      else { zp[0] += y0; zp[R1_COUT] += y1; zp[2 * R1_COUT] += y2; zp[3 * R1_COUT] += y3; }
+      float *zp = zbase + (size_t)(32 * (GI & 1) + (reg & 3) + 8 * (reg >> 2)) * 6 * R1_COUT;
+      zp[0] = acc[GI][0][reg]; zp[R1_COUT] = acc[GI][1][reg]; zp[2 * R1_COUT] = acc[GI][2][reg];
     }
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  // the finishing thread: channels n .. n + 3 of the 32 consecutive pixels of rows tl NR .. (row-tiles 8 tl .. 8 tl + 7): one sample
+  // the finishing thread: channels n .. n + 3 of row-tiles 64 round + 4 tl .. + 3: 16 consecutive pixels of one sample
   const int cq = tid & 15, tl = tid >> 4;
   const int n = n0 + 4 * cq;
 #ifdef IDIFF_W1D_DIAG_PLAIN_EP      // timing-only build: the epilogue's switches as compile-time constants (bias only)
@@ -473,94 +467,118 @@ wino1d_kernel(const Wino1dParams p) {
   const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)p.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)ep.residual, 0, (int)p.res_bytes, 0x00020000);
   const int ld_res = (int)ep.ld_residual;
-  const int orow = row0 + tl * NR;
-  const bool ook = orow < p.rows_total;
-  const uint32_t px0 = (uint32_t)orow * (uint32_t)W;
-  const uint32_t ooff = ook ? (px0 * (uint32_t)p.Cout + (uint32_t)n) * 4u : R1_INVALID;
-  const uint32_t roff = ook ? (px0 * (uint32_t)ld_res + (uint32_t)n) * 4u : R1_INVALID;
-  float4 badd = make_float4(0.f, 0.f, 0.f, 0.f);
-  float sc = has_ep ? ep.out_scale : 1.f;
-  if (has_ep && ep.bias) badd = *reinterpret_cast<const float4 *>(ep.bias + n);
-  if (has_ep && ook) {
-    const int img = orow / p.H;
-    if (ep.rowbias) {
-      const float4 rb = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)img * ep.ld_rowbias + n);
-      badd.x += rb.x; badd.y += rb.y; badd.z += rb.z; badd.w += rb.w;
-    }
-    if (ep.rowscale) sc *= ep.rowscale[img];
-  }
-  float4 res[2][8];
-  auto load_res = [&](int chunk) __attribute__((always_inline)) {
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (has_ep && ep.bias) bias4 = *reinterpret_cast<const float4 *>(ep.bias + n);
+  // the residual's 16 pixels of a round are requested one phase ahead (round 0: before the first park, round 1: behind round 0's outputs) and
+  // arrive behind the parks and barriers
+  float4 res[16];
+  auto request_res = [&](int rnd) __attribute__((always_inline)) {
+    const uint32_t pxl = (uint32_t)(4 * (64 * rnd + 4 * tl));
+    const bool ook = row0 + (int)(pxl / W) < p.rows_total;
+    const uint32_t roff = ook ? (((uint32_t)row0 * (uint32_t)W + pxl) * (uint32_t)ld_res + (uint32_t)n) * 4u : R1_INVALID;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      res[chunk & 1][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)roff, (8 * chunk + i) * ld_res * 4, 0));
+    for (int i = 0; i < 16; ++i) res[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)roff, i * ld_res * 4, 0));
   };
-  if (has_res) load_res(0);
-  // the last step ended with a barrier: nobody reads the stages any more
-  if (ph == 0) { mix(I2(), std::true_type()); mix(I3(), std::true_type()); } else { mix(I0(), std::true_type()); mix(I1(), std::true_type()); }
-  __syncthreads();
-  if (ph == 0) { mix(I0(), std::false_type()); mix(I1(), std::false_type()); } else { mix(I2(), std::false_type()); mix(I3(), std::false_type()); }
-  __syncthreads();
-  IDIFF_W1D_T(4)
-  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-  // The 32 pixels of this thread with the epilogue's switches as COMPILE-TIME constants: with `act`, `has_res`, ... tested at run time inside
-  // the loop every pixel became a chain of scalar branches between its LDS read and its store and nothing of one pixel overlapped the next --
-  // 9.6 us per workgroup where this form takes 1.7 (profiles/r05_wino1d_stamps.txt).  ACT < 0: the activation by its run-time code.
-  auto finish = [&](auto act_c, auto res_c, auto scaled_c, auto stats_c) __attribute__((always_inline)) {
-    constexpr int ACT = decltype(act_c)::value;
+  double s1[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, s2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  // One round's 16 pixels with the epilogue's switches as COMPILE-TIME constants: tested at run time inside the loop every pixel became a chain
+  // of scalar branches between its LDS reads and its store and nothing of one pixel overlapped the next -- 9.6 us per workgroup where the
+  // constant form took 1.7 (profiles/r05_wino1d_stamps.txt).  ACT < 0: the activation by its run-time code.
+  auto finish = [&](auto round_c, auto act_c, auto res_c, auto scaled_c, auto stats_c) __attribute__((always_inline)) {
+    constexpr int RND = decltype(round_c)::value, ACT = decltype(act_c)::value;
     constexpr bool RES = decltype(res_c)::value, SCALED = decltype(scaled_c)::value, STATS = decltype(stats_c)::value;
+    // row-tile m of the block is its pixels 4 m .. 4 m + 3 in row-major order
+    const uint32_t pxl = (uint32_t)(4 * (64 * RND + 4 * tl));                  // my first pixel, counted from the block's first
+    const int orow = row0 + (int)(pxl / W);
+    const bool ook = orow < p.rows_total;
+    const uint32_t px0 = (uint32_t)row0 * (uint32_t)W + pxl;
+    const uint32_t ooff = ook ? (px0 * (uint32_t)p.Cout + (uint32_t)n) * 4u : R1_INVALID;
+    float4 badd = bias4;
+    float sc = has_ep ? ep.out_scale : 1.f;
+    if (has_ep && ook) {
+      const int img = orow / p.H;
+      if (ep.rowbias) {
+        const float4 rb = *reinterpret_cast<const float4 *>(ep.rowbias + (int64_t)img * ep.ld_rowbias + n);
+        badd.x += rb.x; badd.y += rb.y; badd.z += rb.z; badd.w += rb.w;
+      }
+      if (ep.rowscale) sc *= ep.rowscale[img];
+    }
 #pragma unroll
-    for (int chunk = 0; chunk < 4; ++chunk) {
-      if (RES && chunk + 1 < 4) load_res(chunk + 1);
-      float4 z[8];
+    for (int j = 0; j < 4; ++j) {                      // row-tile 4 tl + j of the round
+      const float *zr = lds + (size_t)(4 * tl + j) * 6 * R1_COUT + 4 * cq;
+      float4 z[6];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) z[i] = *reinterpret_cast<const float4 *>(lds + (size_t)(32 * tl + 8 * chunk + i) * R1_COUT + 4 * cq);
+      for (int i = 0; i < 6; ++i) z[i] = *reinterpret_cast<const float4 *>(zr + i * R1_COUT);
+      float y[4][4];
+#define IDIFF_R1_AT(cmp, e)                                                                                  \
+      {                                                                                                      \
+        const float s12 = z[1].cmp + z[2].cmp, d12 = z[1].cmp - z[2].cmp, s34 = z[3].cmp + z[4].cmp, d34 = z[3].cmp - z[4].cmp; \
+        y[0][e] = z[0].cmp + (s12 + s34);                                                                     \
+        y[1][e] = fmaf(R1_b, d34, R1_a * d12);                                                                \
+        y[2][e] = fmaf(R1_b2, s34, R1_a2 * s12);                                                              \
+        y[3][e] = fmaf(R1_b3, d34, fmaf(R1_a3, d12, z[5].cmp));                                               \
+      }
+      IDIFF_R1_AT(x, 0) IDIFF_R1_AT(y, 1) IDIFF_R1_AT(z, 2) IDIFF_R1_AT(w, 3)
+#undef IDIFF_R1_AT
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float y[4] = {z[i].x * descale + badd.x, z[i].y * descale + badd.y, z[i].z * descale + badd.z, z[i].w * descale + badd.w};
+      for (int a = 0; a < 4; ++a) {
+        y[a][0] = fmaf(y[a][0], descale, badd.x); y[a][1] = fmaf(y[a][1], descale, badd.y);
+        y[a][2] = fmaf(y[a][2], descale, badd.z); y[a][3] = fmaf(y[a][3], descale, badd.w);
         if (ACT != (int)IDIFF_ACT_NONE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = idiff::act_apply(y[e], ACT < 0 ? act : ACT);
+          for (int e = 0; e < 4; ++e) y[a][e] = idiff::act_apply(y[a][e], ACT < 0 ? act : ACT);
         }
-        if (RES) { const float4 r = res[chunk & 1][i]; y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w; }
+        if (RES) { const float4 r = res[4 * j + a]; y[a][0] += r.x; y[a][1] += r.y; y[a][2] += r.z; y[a][3] += r.w; }
         if (SCALED) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] *= sc;
+          for (int e = 0; e < 4; ++e) y[a][e] *= sc;
         }
         if (STATS) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { s1[e] += (double)y[e]; s2[e] += (double)y[e] * (double)y[e]; }
+          for (int e = 0; e < 4; ++e) { s1[RND][e] += (double)y[a][e]; s2[RND][e] += (double)y[a][e] * (double)y[a][e]; }
         }
-#ifdef IDIFF_W1D_DIAG_NO_STORE     // timing-only build: one store per thread instead of 32
-        if (8 * chunk + i == 31)
+#ifdef IDIFF_W1D_DIAG_NO_STORE     // timing-only build: one store per thread and round instead of 16
+        if (4 * j + a == 15)
 #endif
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, make_float4(y[0], y[1], y[2], y[3])), rO, (int)ooff,
-                                               (8 * chunk + i) * p.Cout * 4, IDIFF_W1D_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, make_float4(y[a][0], y[a][1], y[a][2], y[a][3])), rO, (int)ooff,
+                                               (4 * j + a) * p.Cout * 4, IDIFF_W1D_STORE_AUX);
       }
     }
   };
-  {
+  auto finish_round = [&](auto round_c) __attribute__((always_inline)) {
     using T = std::true_type; using F = std::false_type;
     using ANone = std::integral_constant<int, (int)IDIFF_ACT_NONE>; using AAny = std::integral_constant<int, -1>;
-    auto by_stats = [&](auto a, auto r, auto sc_) __attribute__((always_inline)) { if (want_stats) finish(a, r, sc_, T()); else finish(a, r, sc_, F()); };
+    auto by_stats = [&](auto a, auto r, auto sc_) __attribute__((always_inline)) { if (want_stats) finish(round_c, a, r, sc_, T()); else finish(round_c, a, r, sc_, F()); };
     auto by_scale = [&](auto a, auto r) __attribute__((always_inline)) { if (scaled) by_stats(a, r, T()); else by_stats(a, r, F()); };
     auto by_res = [&](auto a) __attribute__((always_inline)) { if (has_res) by_scale(a, T()); else by_scale(a, F()); };
     if (act == (int)IDIFF_ACT_NONE) by_res(ANone()); else by_res(AAny());
-  }
+  };
+  // the last step ended with a barrier: nobody reads the stages any more
+  if (has_res) request_res(0);
+  park(I0()); park(I1());
+  __syncthreads();
+  IDIFF_W1D_T(4)
+  finish_round(I0());
+  if (has_res) request_res(1);
+  __syncthreads();
+  park(I2()); park(I3());
+  __syncthreads();
+  finish_round(I1());
   IDIFF_W1D_T(5)
   if (want_stats) {
     // per-sample (or per-block, where a sample spans several blocks) column sums for the GroupNorm that reads this output: thread sums ->
-    // [16 thread rows][64 channels] in LDS -> one thread per (slot, channel)
+    // [32 thread rows = (round, tl)][64 channels] in LDS -> one thread per (slot, channel)
     __syncthreads();
     double *red = reinterpret_cast<double *>(lds);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      red[((tl * R1_COUT) + 4 * cq + e) * 2] = s1[e];
-      red[((tl * R1_COUT) + 4 * cq + e) * 2 + 1] = s2[e];
-    }
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[(((16 * r + tl) * R1_COUT) + 4 * cq + e) * 2] = s1[r][e];
+        red[(((16 * r + tl) * R1_COUT) + 4 * cq + e) * 2 + 1] = s2[r][e];
+      }
     __syncthreads();
     const int slots = RB > p.H ? RB / p.H : 1;                     // samples per block
-    const int per = 16 / slots;                                    // thread rows per sample
+    const int per = 32 / slots;                                    // thread rows per sample
     for (int o = tid; o < slots * R1_COUT; o += R1_THREADS) {
       const int smp = o / R1_COUT, ch = o - smp * R1_COUT;
       const int64_t slot = (int64_t)tile_m * slots + smp;           // sample, or (sample, split) = block

@@ -38,7 +38,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             life = float((t[:, 6] - t[:, 0]).median())
             span = float(t[:, 6].max() - t[:, 0].min())
             print(f"{H}x{H} {Cin}->{Cout} [{name}]: {nwg} workgroups ({nwg / 256:.1f} per CU); median us per workgroup: first operands {m[0]:.1f}, first stage {m[1]:.1f}, "
-                  f"K loop {m[2]:.1f} ({steps} steps: {m[2] / steps:.2f} each), exchange {m[3]:.1f}, outputs {m[4]:.1f}, column sums {m[5]:.1f}; life {life:.1f}; "
+                  f"K loop {m[2]:.1f} ({steps} steps: {m[2] / steps:.2f} each), first park {m[3]:.1f}, outputs + second park {m[4]:.1f}, column sums {m[5]:.1f}; life {life:.1f}; "
                   f"kernel span {span:.0f} us = {span / (nwg / 256):.1f} per workgroup round", flush=True)
     sys.exit(0)
 

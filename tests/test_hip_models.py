@@ -438,7 +438,6 @@ def wino1d_everywhere(monkeypatch, wino43_everywhere):
     """... and the GroupNorm-fed 3x3 convolutions of 8 x 8 maps and larger through the row-wise F(4, 3) pair kernel, at test batch sizes."""
     from id_diff_amd.models import ncsnpp as hip_ncsnpp
     monkeypatch.setattr(hip_ncsnpp, "WINO1D_MIN_WORKGROUPS", 1)
-    monkeypatch.setattr(hip_ncsnpp, "WINO1D_MIN_WIDTH", 8)
     calls = {"n": 0}
     orig = _lib.conv2d_wino1d
 
