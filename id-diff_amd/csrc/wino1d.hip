@@ -22,20 +22,25 @@
 // K step: 16 input channels.  Per wave and step nine combinations (position, filter row) x four groups x three matrix instructions
 //   (hi hi, hi lo, lo hi); the V operand of (group, filter row ky) is the stage's rows 4 g + ky - 1 .. 4 g + ky + 2: the same LDS image read at a
 //   row's distance, no copy per filter row.  Rows that lie outside the image of an output row (a block of small maps holds several images) are
-//   read from an all-zero entry instead.
-// Loader: thread (channel c = tid % 16, k = tid / 16) holds the 32 pixels of the image rows k NR .. k NR + NR - 1 of the block (NR = RB / 16)
-//   for its channel -- 16 consecutive lanes read the 64 contiguous bytes of a pixel --, threads k < 2 W / 4 additionally one row-tile (six
-//   pixels) of the halo row above or below the block: 38 registers that hold the NEXT step's pixels while this step is contracted.  Per
-//   combination one row-tile is transformed (12 fmas), cut into pairs, exchanged with the neighbouring channel's lane and stored
-//   (as winograd43h_kernel's stage), and the pixels no later tile needs are requested again for the step after next.
-// Stage (LDS): [6 positions][(RB + 2) W / 4 + 1 entries][64 B], entry = (row slot, tile), the last one all zero; the four 16-byte pieces
-//   (plane, channel half) of entry e are stored at piece ^ ((e >> 2) & 3): a ds_read_b128 of 32 consecutive entries is conflict-free from any
-//   even first entry (checked by enumeration over the instruction's lane groups).  Two stages <= 111,360 B.
+//   read from an all-zero entry instead.  The step is written as 108 GAPS -- one matrix instruction, a hand-dealt slice of the other work, a
+//   scheduling fence (see step()): one wave per SIMD issues in order, and nothing else hides behind the matrix instructions.
+// Loader: lane lm = tid % 8 holds the channel PAIR 2 lm, 2 lm + 1 (8-byte loads; eight consecutive lanes read the 64 contiguous bytes of a
+//   pixel), segment set tid / 8: four row-tiles = 16 pixels + the neighbour left and right of one image row (W = 32: half a row, W = 16: a row,
+//   W = 8: two rows) -- 36 registers that hold the NEXT step's pixels while this step is contracted; threads tid / 8 < 2 W / 4 additionally one
+//   row-tile (six pixels) of the halo row above or below the block.  A row-tile's staging is 13 groups of <= 5 vector instructions: t = B^T d
+//   for both channels (12 plain fmas each), then per position one dword of hi parts (v_cvt_pk_f16_f32 of the two channels: no lane exchange)
+//   and one of lo parts (v - hi by v_fma_mix_f32, exact), two positions of a plane per ds_write2st64_b32, then the requests for the step after next.
+// Stage (LDS): [6 positions][(RB + 2) W / 4 + 1 entries, rounded up to eight][64 B], entry = (row slot, tile), the last one all zero; entry e lives
+//   in slot r1_slot(e) (pairs of every second group of four swapped: the four loader threads of a write pass then fall on four bank quarters),
+//   its four 16-byte pieces (plane, channel half) at piece ^ ((slot >> 2) & 3): a ds_read_b128 of 32 consecutive entries is conflict-free from
+//   any even first entry (checked by enumeration over the instruction's lane groups).  Two stages, 64 KB apart (the other stage: one XOR).
 // U (global): [Cin/16][Cout/64][18 slots = position * 3 + filter row][2 planes][64 cout][16 cin] fp16 + 4 floats of header (the factor that
 //   undoes the power-of-two scaling first).
-// Tail: each wave forms its half of A^T m (positions 0-2 or 3-5) for its 64 x 2 row-tiles, the two halves meet in LDS ([128 row-tiles][4 pixels]
-//   [64 channels] fp32: each wave parks two groups, then adds its other two onto what the partner parked), and thread (4 channels, 32
-//   consecutive pixels) applies the epilogue of idiff_conv2d_nhwc_f32 and stores 16 bytes per pixel.
+// Tail: two rounds (groups {0, 1}, {2, 3}); every wave parks its three positions' accumulators as they are ([64 row-tiles][6 positions][64
+//   channels] fp32), and thread (4 channels, 16 consecutive pixels) forms A^T m from six 16-byte reads per row-tile, applies the epilogue of
+//   idiff_conv2d_nhwc_f32 -- its switches as compile-time constants -- and stores 16 bytes per pixel.
+// Measured (profiles/r05_wino1d_*.txt, HISTORY_r05.md 5): 1.03 - 1.23x winograd43h_kernel by shape, matrix cores 52 % busy, 1,120 lines from L2 per
+// workgroup and step.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -436,7 +441,7 @@ wino1d_kernel(const Wino1dParams p) {
   // zr[row-tile][position][cout], 98,304 B -- and after a barrier thread (4 channels, 4 row-tiles = 16 consecutive pixels) reads the six
   // positions of a row-tile (six 16-byte reads), forms A^T m, applies the epilogue and stores 16 bytes per pixel.  (The first form had each
   // wave mix its positions into four partial outputs, park half and read - add - write the other half on top of the partner's: a third more
-  // LDS writes, at 64 B per clock, and 128 dependent LDS round trips per lane: 5.7 us per workgroup against ...)
+  // LDS writes, at 64 B per clock, and 128 dependent LDS round trips per lane: 72.4 -> 69.9 ms per forward with this one.)
   const float descale = p.u[(int64_t)R1_NSLOT * p.Cin * p.Cout];
   const idiff_epilogue &ep = p.ep;
   const bool has_ep = p.has_ep != 0;

@@ -1174,3 +1174,29 @@ def test_winograd43_colstats_feed_groupnorm(B, H, Cin, Cout):
     tot = cs.view(B, ns, Cout, 2).sum(1)
     torch.testing.assert_close(tot[..., 0], out.double().sum(1), rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(tot[..., 1], (out.double() ** 2).sum(1), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(3, 32, 64, 128), (6, 16, 128, 64), (5, 8, 64, 128), (7, 8, 32, 64), (70, 8, 32, 64)])
+def test_wino1d_colstats_feed_groupnorm(B, H, Cin, Cout):
+    """Column sums from the row-wise pair kernel's epilogue = a statistics pass over its output: two workgroups per sample (32x32), two and
+    eight whole samples per workgroup (16x16, 8x8), sample counts that leave the last workgroup partly empty."""
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, H * H, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    ns = _lib.conv2d_wino1d_colstats_split(B, H, H, Cin, Cout)
+    assert ns == max(1, H * H // 512)
+    cs = torch.full((B * ns * Cout * 2,), float("nan"), device=DEV, dtype=torch.float64)
+    out = torch.empty(B, H * H, Cout, device=DEV)
+    u = _lib.wino1d_pack(w, Cin, Cout)
+    _lib.conv2d_wino1d(x, u, out, B, H, H, Cin, Cout, epilogue=_lib.make_epilogue(bias=bias, act="silu", rows_per_group=H * H, colstats=cs))
+    G = 32
+    st_a, st_b = torch.empty(B * G * 2, device=DEV), torch.empty(B * G * 2, device=DEV)
+    _lib.groupnorm_finalize(cs, ns, Cout, None, 0, 0, B, H * H, G, 1e-6, st_a)
+    nsp = _lib.groupnorm_nsplit(B, H * H, Cout)
+    ws = torch.empty(B * nsp * Cout * 2, device=DEV, dtype=torch.float64)
+    _lib.groupnorm_stats(out, Cout, None, 0, B, H * H, G, 1e-6, ws, st_b)
+    torch.testing.assert_close(st_a, st_b, rtol=1e-6, atol=1e-7)
+    tot = cs.view(B, ns, Cout, 2).sum(1)
+    torch.testing.assert_close(tot[..., 0], out.double().sum(1), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(tot[..., 1], (out.double() ** 2).sum(1), rtol=1e-6, atol=1e-6)
