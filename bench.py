@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0
 # chain gives 2.0e-7 (scripts/bf16x6_probe.hip); every parity bar of tests/ is unchanged.  IDIFF_NO_SPLIT=1 selects fp32 MFMAs.
 _CONV_ARITH = ("3x3 convs: Winograd F(4x4,3x3), fp32 transforms, fp32 MFMA contraction" if (os.environ.get("IDIFF_NO_WINO43H") or os.environ.get("IDIFF_NO_WINO43"))
                else ("3x3 convs: Winograd, fp32 transforms, contraction on pairs of fp16 values -- 22 significand bits, 3 products, fp32 accumulate"
-                     + (" (F(4x4,3x3))" if os.environ.get("IDIFF_NO_WINO1D") else " (F(4,3) along the rows x 3 filter rows on maps of 8x8 pixels and larger, F(4x4,3x3) on the 4x4 maps)")))
+                     + (" (F(4x4,3x3))" if os.environ.get("IDIFF_NO_WINO1D") else " (F(4,3) along the rows x 3 filter rows)")))
 _GEMM_ARITH = ("1x1/attention/dense contractions: fp32 MFMA" if os.environ.get("IDIFF_NO_SPLIT")
                else "1x1/attention/dense contractions: fp32 operands split exactly into 3 bf16, 6 partial products, fp32 accumulate"
                + ("" if os.environ.get("IDIFF_NO_PAIRS") else "; the q/k/v projections of a GroupNorm's output: pairs of fp16 values, 3 products")
@@ -266,7 +266,7 @@ def roofline_report(probe):
     kernels = []
     if dom1d is not None and dom43h is not None:
         t = dom43h["rate"] / 1e12
-        kernels.append({"kernel": "winograd43h_kernel (F(4x4,3x3) on fp16 pairs: the GroupNorm-fed 3x3 convs of the 4x4 maps) [3 fp16 products per "
+        kernels.append({"kernel": "winograd43h_kernel (F(4x4,3x3) on fp16 pairs: GroupNorm-fed 3x3 convs the row-wise kernel does not serve) [3 fp16 products per "
                                   "fp32 multiply-add]", "bound": "mfma", "achieved": t, "peak": F16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s (fp32-equivalent)",
                         "frac": t / (F16_MFMA_PEAK_TFLOPS / 3.0), "launches_sampled": dom43h["launches"], "avg_launch_us": dom43h["avg_us"]})
         dom43h = None

@@ -509,7 +509,7 @@ def conv2d_winograd43(x, u, out, B, H, W, Cin, Cout, epilogue=None, pairs=False)
 
 
 def conv2d_wino1d_ok(B, H, W, Cin, Cout):
-    """True when the row-wise F(4, 3) kernel on fp16 pairs (csrc/wino1d.hip) serves this geometry (W in {8, 16, 32}; off under
+    """True when the row-wise F(4, 3) kernel on fp16 pairs (csrc/wino1d.hip) serves this geometry (W in {4, 8, 16, 32, 64}; off under
     IDIFF_NO_WINOGRAD / IDIFF_NO_WINO43H / IDIFF_NO_WINO1D)."""
     return bool(lib().idiff_conv2d_wino1d_ok(B, H, W, Cin, Cout))
 

@@ -15,7 +15,7 @@
 //   5.4 where the 2-D form has 29.3, so |x| may reach 12,000 before a pair overflows, and the rounding of the transform enters once)
 //
 // Workgroup: 256 threads = 4 waves, ONE PER SIMD (up to 512 registers each), 512 output pixels x 64 output channels:
-//   RB = 512 / W whole image rows (W = 32: half an image, 16: two images, 8: eight), 128 row-tiles of 1 x 4 pixels, six positions each.
+//   RB = 512 / W whole image rows (W = 64: eight rows, 32: half a 32 x 32 image, 16: two images, 8: eight, 4: thirty-two), 128 row-tiles of 1 x 4 pixels, six positions each.
 //   Wave (h, ph): output channels 32 h .. 32 h + 31, positions 3 ph .. 3 ph + 2, all four groups of 32 row-tiles: 12 accumulator tiles of
 //   32 x 32 = 192 registers.  Every U fragment (position, filter row, channel half: 2 KB of pairs) is loaded by exactly one wave, straight from
 //   L2 into registers, three (position, filter row) combinations ahead.
@@ -98,12 +98,11 @@ __device__ __forceinline__ int r1_slot(int e) { return e ^ ((e >> 2) & 1); }
 template <int W> struct R1Geo {
   static constexpr int TPR = W / 4;                                // row-tiles per image row
   static constexpr int RB = R1_PIXELS / W;                         // image rows per workgroup
-  static constexpr int NR = RB / 16;                               // rows per loader thread
   static constexpr int EZ = (RB + 2) * TPR;                        // stage entries: row slot 0 = the row above the block, RB + 1 = the row below, then the zero entry
   static constexpr int E = (EZ + 1 + 7) & ~7;                      // (whole groups of eight: r1_slot() stays inside)
   static constexpr int POS_BYTES = E * 64;
   static constexpr int STAGE_BYTES = 6 * POS_BYTES;
-  static_assert(NR * TPR == 8, "a loader thread owns eight row-tiles");
+  static_assert(RB * TPR == R1_RT, "128 row-tiles per workgroup");
   static_assert(STAGE_BYTES <= R1_STAGE_STRIDE, "a stage inside its half of the LDS allocation");
   static_assert(5 * POS_BYTES < 65536, "positions are reached by the LDS instructions' immediate offset");
   static_assert(POS_BYTES % 256 == 0, "two positions of one entry: one ds_write2st64_b32");
@@ -161,10 +160,10 @@ wino1d_kernel(const Wino1dParams p) {
   // ---------------------------------------------------------------- loader: thread = (channel pair, row segment)
   // Lane lm holds channels 2 lm and 2 lm + 1 (8-byte loads: eight consecutive lanes read the 64 contiguous bytes of a pixel), so the two halves of
   // every stage dword are in ONE lane and a value pair costs 2 conversions + 2 mixed fmas -- no exchange with a neighbouring lane, no selects.
-  // Segment set lk: W = 32: half a row (pixels 16 hf - 1 .. 16 hf + 16 of row lk / 2), W = 16: row lk, W = 8: rows 2 lk and 2 lk + 1 -- four
+  // Segment set lk: W = 64 / 32: a quarter / half of a row (16 pixels and their two neighbours), W = 16: row lk, W = 8 / 4: two / four whole rows -- four
   // row-tiles and 16 pixels (+ the neighbours left and right) per thread and step; lk < 2 W / 4 additionally one row-tile of a halo row.
-  constexpr int NSEG = W == 8 ? 2 : 1;                             // row segments of a thread
-  constexpr int TS = 4 / NSEG;                                     // row-tiles per segment
+  constexpr int TS = TPR < 4 ? TPR : 4;                            // row-tiles per segment
+  constexpr int NSEG = 4 / TS;                                     // row segments of a thread
   constexpr int NPX = 4 * TS + 2;                                  // its pixels, the one to the left and the one to the right included
   const int lm = tid & 7, lk = tid >> 3;
   // base one pixel to the LEFT: offset v + j * cin4 is the segment's pixel j - 1 ... (the range check covers the vector offset only)
@@ -174,11 +173,11 @@ wino1d_kernel(const Wino1dParams p) {
   int e_halo;
   {
 #ifdef IDIFF_W1D_DIAG_SAME_X       // timing-only build: every workgroup reads the first block's pixels (L2 hits instead of HBM misses)
-    const int rho = (W == 32 ? lk >> 1 : (W == 16 ? lk : 2 * lk));
+    const int rho = (W >= 32 ? lk / (W / 16) : NSEG * lk);
 #else
-    const int rho = row0 + (W == 32 ? lk >> 1 : (W == 16 ? lk : 2 * lk));
+    const int rho = row0 + (W >= 32 ? lk / (W / 16) : NSEG * lk);
 #endif
-    const int xf = W == 32 ? 16 * (lk & 1) : 0;                   // first pixel of my first tile
+    const int xf = W >= 32 ? 16 * (lk % (W / 16)) : 0;            // first pixel of my first tile
     v_main = rho < p.rows_total ? (uint32_t)rho * (uint32_t)roww + (uint32_t)xf * cin4 + (uint32_t)lm * 8u : R1_INVALID;
     m_l = xf > 0; m_r = xf + 4 * TS < W;                           // the neighbours are pixels of the row (else the zero padding)
     const bool part = lk < 2 * TPR, top = lk < TPR;
@@ -206,7 +205,7 @@ wino1d_kernel(const Wino1dParams p) {
     asm volatile("" : "+s"(invalid_s));
 #pragma unroll
     for (int j = j0; j <= j1; ++j) {
-      if (W != 32 && (j == 0 || j == NPX - 1)) continue;           // always the padding
+      if (W < 32 && (j == 0 || j == NPX - 1)) continue;            // always the padding
       const uint32_t vo = j == 0 ? (m_l ? v_main : invalid_s) : (j == NPX - 1 ? (m_r ? v_main : invalid_s) : v_main);
       px[g][j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rXm, (int)vo, choff + g * roww + j * (int)cin4, 0));
     }
@@ -657,7 +656,7 @@ __global__ void wino1d_pack_kernel(const float *wt, _Float16 *u, float *header, 
 
 bool r1_geometry_ok(int B, int H, int W, int Cin, int Cout) {
   if (B <= 0 || H <= 0 || Cin <= 0 || Cout <= 0) return false;
-  if (W != 8 && W != 16 && W != 32) return false;
+  if (W != 4 && W != 8 && W != 16 && W != 32 && W != 64) return false;
   const int RB = R1_PIXELS / W;
   if (H % 4 || (RB % H != 0 && H % RB != 0)) return false;                     // a block is whole images or a whole part of one
   if (Cin % R1_KC || Cin < 2 * R1_KC || Cin > 1024 || Cout % R1_COUT) return false;
@@ -745,8 +744,10 @@ IDIFF_API int idiff_conv2d_wino1d_f32(const float *x, const float *u, float *out
   { const char *e = getenv("IDIFF_W1D_STAMP_PTR"); p.stamps = e ? reinterpret_cast<uint64_t *>(strtoull(e, nullptr, 0)) : nullptr; }
 #endif
   switch (W) {
+    case 4: return r1_launch<4>(p, (hipStream_t)stream);
     case 8: return r1_launch<8>(p, (hipStream_t)stream);
     case 16: return r1_launch<16>(p, (hipStream_t)stream);
+    case 64: return r1_launch<64>(p, (hipStream_t)stream);
     default: return r1_launch<32>(p, (hipStream_t)stream);
   }
 }

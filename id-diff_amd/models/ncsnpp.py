@@ -189,13 +189,13 @@ def _winograd43_pays(B, H, W, cin, cout, normed=False):
 
 # launches of fewer workgroups than this, and maps narrower than this, stay on the 2-D pair kernel (tests set the first to 1)
 WINO1D_MIN_WORKGROUPS = 256
-WINO1D_MIN_WIDTH = 8
+WINO1D_MIN_WIDTH = 4
 
 
 def _wino1d_pays(B, H, W, cin, cout):
     """The row-wise F(4, 3) pair kernel (csrc/wino1d.hip: twice the matrix work of F(4x4, 3x3) for half the operand traffic) where it is served
-    and measured faster than the 2-D pair kernel: maps of 8 x 8 pixels and larger at one workgroup (512 pixels x 64 channels) per CU and more --
-    1.08-1.23x on 16 x 16 and 32 x 32 maps, 1.03-1.06x on 8 x 8 (profiles/r05_wino1d_probe.txt, B = 2240); 4 x 4 maps are not served."""
+    and measured at least as fast as the 2-D pair kernel: at one workgroup (512 pixels x 64 channels) per CU and more -- 1.08-1.23x on 16 x 16
+    and 32 x 32 maps, 1.03-1.06x on 8 x 8, 1.00-1.01x on 4 x 4 (profiles/r05_wino1d_probe.txt, B = 2240); 64-pixel rows (config 5) likewise."""
     if W < WINO1D_MIN_WIDTH or not _lib.conv2d_wino1d_ok(B, H, W, cin, cout):
         return False
     return ((B * H * W + 511) // 512) * (cout // 64) >= WINO1D_MIN_WORKGROUPS

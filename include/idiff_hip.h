@@ -265,7 +265,7 @@ int idiff_conv2d_winograd43h_f32(const float *x, const float *u, float *out, int
  * instead of two: gain 5.4 instead of 29.3, the input may reach |x| ~ 12,000 before a pair overflows to NaN).  Twice the matrix work for
  * half the operand traffic per output: a workgroup of 512 output pixels x 64 channels reads 18 instead of 36 transformed filter slots
  * per K step and every input pixel once instead of 2.25 times, which is what bounds the 2-D form on gfx950 (csrc/wino1d.hip).
- *   idiff_conv2d_wino1d_ok             1 when served: W in {8, 16, 32}, H % 4 == 0 with 512 / W a multiple or a divisor of H (a workgroup takes
+ *   idiff_conv2d_wino1d_ok             1 when served: W in {4, 8, 16, 32, 64}, H % 4 == 0 with 512 / W a multiple or a divisor of H (a workgroup takes
  *                                      whole images or a whole part of one), Cin % 16 == 0, 32 <= Cin <= 1024, Cout % 64 == 0, every tensor
  *                                      within one buffer descriptor; 0 under IDIFF_NO_WINOGRAD / IDIFF_NO_WINO43H / IDIFF_NO_WINO1D.
  *   idiff_conv2d_wino1d_colstats_split nsplit of epilogue.colstats ([samples, nsplit, Cout, 2]): H * W / 512 for maps above 512 pixels, else 1

@@ -1055,10 +1055,12 @@ def test_conv2d_winograd43_pairs_limits():
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 32, 32, 128, 128), (3, 8, 8, 256, 64), (5, 16, 16, 80, 64), (2, 16, 16, 512, 256), (1, 64, 32, 32, 64),
                                             (2, 8, 8, 32, 64), (33, 8, 8, 256, 256), (7, 16, 16, 384, 256), (3, 32, 16, 48, 128), (9, 4, 8, 64, 64),
-                                            (2, 128, 8, 32, 64)])
+                                            (2, 128, 8, 32, 64), (2, 64, 64, 128, 64), (1, 16, 64, 32, 128), (3, 8, 64, 64, 64), (130, 4, 4, 48, 64), (37, 4, 4, 256, 128),
+                                            (5, 8, 4, 32, 64)])
 def test_conv2d_wino1d_vs_cpu(B, H, W, Cin, Cout):
     """The 3x3 convolution by F(4, 3) along the rows, three filter rows summed directly, on fp16 pairs (wino1d_kernel) against the fp64 CPU
-    convolution with every epilogue term, the direct kernel and the column sums: blocks of half an image (W = 32), of several images
+    convolution with every epilogue term, the direct kernel and the column sums: blocks of an eighth of an image with a halo row on both sides
+    (W = 64), of half an image (W = 32), of several images
     (W = 16, 8: the rows of a neighbouring image must not leak into a sample's first / last row), partial last blocks, non-square maps with
     one or two halo rows per block, 2 to 32 K steps, several output-channel tiles.  Bar 3e-6, that of the 2-D pair form (measured below it:
     one transform instead of two).  Inputs span five decades with exact zeros among them, as in the 2-D form's test."""
@@ -1105,7 +1107,7 @@ def test_conv2d_wino1d_vs_cpu(B, H, W, Cin, Cout):
 def test_conv2d_wino1d_limits():
     """What the row-wise pair form refuses, its switches, and its documented failure: an input beyond the fp16 range of the transformed
     values gives NaN outputs, never finite wrong ones."""
-    assert not _lib.conv2d_wino1d_ok(2, 8, 12, 32, 64)           # W not 8 / 16 / 32
+    assert not _lib.conv2d_wino1d_ok(2, 8, 12, 32, 64)           # W not 4 / 8 / 16 / 32 / 64
     assert not _lib.conv2d_wino1d_ok(2, 8, 8, 24, 64)            # Cin % 16
     assert not _lib.conv2d_wino1d_ok(2, 8, 8, 16, 64)            # fewer than two K steps
     assert not _lib.conv2d_wino1d_ok(2, 24, 32, 32, 64)          # a block of 16 rows would straddle two images
@@ -1176,7 +1178,7 @@ def test_winograd43_colstats_feed_groupnorm(B, H, Cin, Cout):
     torch.testing.assert_close(tot[..., 1], (out.double() ** 2).sum(1), rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout", [(3, 32, 64, 128), (6, 16, 128, 64), (5, 8, 64, 128), (7, 8, 32, 64), (70, 8, 32, 64)])
+@pytest.mark.parametrize("B,H,Cin,Cout", [(3, 32, 64, 128), (6, 16, 128, 64), (5, 8, 64, 128), (7, 8, 32, 64), (70, 8, 32, 64), (2, 64, 32, 64), (11, 4, 32, 64), (70, 4, 32, 64)])
 def test_wino1d_colstats_feed_groupnorm(B, H, Cin, Cout):
     """Column sums from the row-wise pair kernel's epilogue = a statistics pass over its output: two workgroups per sample (32x32), two and
     eight whole samples per workgroup (16x16, 8x8), sample counts that leave the last workgroup partly empty."""

@@ -151,8 +151,7 @@ def test_config3_full_size_production_routing_vs_oracle(golden, point):
     """(Two of the bench's points: their IDs differ -- 3070 and 3069 -- because the images differ.)
     The configuration the headline number is quoted on, at FULL size, through the routing the drivers use by default, against the
     CPU oracle on identical draws.  One point of bench.py's workload (nf = 128 NCSN++, init_scale = 1, seed-0
-    weights, bench image 1, the bench's point seed): S 4480 x 3072 in two 2240-row launch sets, 3x3 convs on the fp16-pair kernels (row-wise F(4,3)
-    from 8 x 8 maps on, F(4x4,3x3) on the 4 x 4 maps), q / k / v projections on pair GEMMs -- the launch counters are asserted so the routing cannot change silently.
+    weights, bench image 1, the bench's point seed): S 4480 x 3072 in two 2240-row launch sets, 3x3 convs on the fp16-pair kernels (row-wise F(4,3) x 3 filter rows), q / k / v projections on pair GEMMs -- the launch counters are asserted so the routing cannot change silently.
 
     The oracle side was computed once in the build container (tests/golden/make_cfg3_point.py: the oracle network on the draws of
     oracle/philox.py, 883 s on 8 cores) and is a fixture: 192 rows of its S over both launch sets, the fp32 gesdd spectrum exactly as
@@ -193,9 +192,8 @@ def test_config3_full_size_production_routing_vs_oracle(golden, point):
     # the 16-token middle block's q|k on pair GEMMs -- its V^T has N = 16 tokens, below the pair form's N > 64, and stays on six
     # products; the five 256-token blocks' QK^T -> softmax -> PV in ONE launch each, the middle block's in three); no conv on the fp32
     # F(4x4) or the F(2x2) kernel; the stem, the three stride-2 convs and the 128 -> 3 head on the implicit-GEMM entry point
-    # (of the 88, the 64 on maps of 8 x 8, 16 x 16 and 32 x 32 pixels on the row-wise F(4, 3) kernel, the 24 on 4 x 4 maps on F(4x4, 3x3))
-    assert routes.n["wino1d"] + routes.n["wino43_pairs"] == 2 * 88 and routes.n["wino43_fp32"] == 0 and routes.n["wino22"] == 0, routes.n
-    assert routes.n["wino1d"] == 2 * 64, routes.n
+    # (all 88 on the row-wise F(4, 3) kernel, 4 x 4 to 32 x 32 maps; the 2-D pair kernel serves them under IDIFF_NO_WINO1D)
+    assert routes.n["wino1d"] == 2 * 88 and routes.n["wino43_pairs"] == 0 and routes.n["wino43_fp32"] == 0 and routes.n["wino22"] == 0, routes.n
     assert routes.n["gemm_pairs"] == 2 * (5 * 3 + 1), routes.n
     assert routes.n["attention256"] == 2 * 5 and routes.n["softmax_rows"] == 2 * 1, routes.n
     assert routes.n["igemm_conv"] == 2 * 5, routes.n
