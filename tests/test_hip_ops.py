@@ -1122,6 +1122,8 @@ def test_conv2d_wino1d_limits():
     with pytest.raises(RuntimeError, match="wino1d_pack"):        # another kernel's bank
         _lib.conv2d_wino1d(torch.zeros(2, 8, 8, 32, device=DEV), _lib.winograd43_pack(wt, 32, 64, pairs=True), torch.zeros(2, 8, 8, 64, device=DEV),
                            2, 8, 8, 32, 64)
+    with pytest.raises(RuntimeError, match="not supported"):      # a geometry the kernel does not serve is refused, not computed wrongly
+        _lib.conv2d_wino1d(torch.zeros(2, 8, 12, 32, device=DEV), u, torch.zeros(2, 8, 12, 64, device=DEV), 2, 8, 12, 32, 64)
     x = torch.randn(2, 8, 8, 32, generator=g).to(DEV)
     out = torch.empty(2, 8, 8, 64, device=DEV)
     ref = torch.empty_like(out)
